@@ -1,0 +1,333 @@
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+For every case the reference implementation (imported unmodified through
+``_refload``) is run on closed-form fixture weights / inputs
+(``oracle/fixture.py``), the oracle restatement is run on the same inputs and
+must agree (this is what pins the oracle), and the reference's outputs are
+written as small ``.npz`` fixtures.  Large tensors are stored as
+(l2-norm, strided sample) pairs -- see ``digest``.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import _refload  # noqa: E402
+from oracle import fixture as fx  # noqa: E402
+from oracle import frontend as ofe  # noqa: E402
+from oracle import model as om  # noqa: E402
+
+torch.set_num_threads(8)
+ref = _refload.load_reference()
+DS = ((2, 2), (2, 2))
+
+
+def digest(t, n=96):
+    """(norm, strided sample) summary of a tensor -- keeps fixtures small."""
+    f = t.detach().double().flatten()
+    stride = max(1, f.numel() // n)
+    return np.concatenate([[f.norm().item()], f[::stride][:n].numpy()]).astype(np.float64)
+
+
+def close(a, b, tol, what):
+    a, b = a.detach().double(), b.detach().double()
+    err = (a - b).abs().max().item()
+    scale = max(b.abs().max().item(), 1e-30)
+    assert err <= tol * scale, f'oracle != reference for {what}: max err {err:.3e} (scale {scale:.3e})'
+    return err / scale
+
+
+def build_ref(kind, reconstruction, training=True, xi=1e-6, eps=2.0):
+    cls = ref.UNet_Onset if kind == 'onset' else ref.UNet
+    net = cls(*DS, log=True, reconstruction=reconstruction, mode='imagewise', spec='Mel', XI=xi, eps=eps)
+    params = fx.fixture_params(kind, reconstruction)
+    missing = net.load_state_dict(params, strict=True)
+    net.train(training)
+    return net, fx.clone_params(params)
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        out[k] = v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}.npz  {os.path.getsize(path) / 1024:.0f} KiB')
+
+
+# ---------------------------------------------------------------------------------------------
+def g_frontend():
+    net, params = build_ref('onset', False)
+    audio = fx.fixture_audio(2, 65536)[:, :-1]
+    mel_ref = net.spectrogram(audio)
+    mel_orc = ofe.melspec_power(audio, params)
+    close(mel_orc, mel_ref, 1e-6, 'mel power')
+    ln_ref = net.normalize.transform(torch.log(mel_ref + 1e-5)).transpose(-1, -2).unsqueeze(1)
+    close(ofe.log_normalise(mel_orc), ln_ref, 1e-6, 'log-normalised mel')
+    # independent check of the un-pinned nnAudio restatement: torch.stft power
+    st = torch.stft(audio, 2048, 512, window=torch.from_numpy(ofe.hann_periodic().astype(np.float32)),
+                    center=True, pad_mode='reflect', return_complex=True).abs() ** 2
+    rel = ((params['spectrogram.mel_basis'] @ st - mel_ref).abs().max() / mel_ref.abs().max()).item()
+    assert rel < 1e-4, rel
+    # one full-length clip, digest only
+    a2 = fx.fixture_audio(1, 327680, 'audio_full')[:, :-1]
+    ln2 = ofe.frontend(a2, params)
+    close(ln2, net.normalize.transform(torch.log(net.spectrogram(a2) + 1e-5)).transpose(-1, -2).unsqueeze(1),
+          1e-6, 'full clip')
+    save('frontend', mel=mel_ref, lognorm=ln_ref, full_digest=digest(ln2, 512),
+         mel_nnz=(params['spectrogram.mel_basis'] != 0).sum().item(), stft_rel=rel)
+
+
+def g_unet():
+    """Encoder+Decoder of the onset transcriber: fwd, input grad, weight grads, BN running stats."""
+    net, params = build_ref('onset', False)
+    x = fx.fixture_spec(2, 64).requires_grad_(True)
+    cot = fx.hashed('cot_unet', (2, 2, 64, 229))
+    t = net.transcriber
+    xe, s, c = t.Unet1_encoder(x)
+    y = t.Unet1_decoder(xe, s, c)
+    (y * cot).sum().backward()
+
+    xo = x.detach().clone().requires_grad_(True)
+    for k in om.trainable_keys(params):
+        params[k].requires_grad_(True)
+    yo = om.unet(om.Net(params, True), xo, 'transcriber.Unet1_encoder', 'transcriber.Unet1_decoder')
+    (yo * cot).sum().backward()
+    close(yo, y, 1e-5, 'unet fwd')
+    close(xo.grad, x.grad, 1e-4, 'unet dx')
+    out = dict(y=y, dx=x.grad, x4=digest(xe))
+    sd = dict(net.named_parameters())
+    for k, p in sd.items():
+        if p.grad is None or 'Unet1' not in k:
+            continue
+        close(params[k].grad, p.grad, 2e-4, 'grad ' + k)
+        out['g:' + k] = digest(p.grad)
+    for k, b in net.state_dict().items():
+        if k.endswith(('running_mean', 'running_var')) and 'Unet1' in k:
+            close(params[k], b, 1e-5, k)
+            out['s:' + k] = b.clone()
+    save('unet', **out)
+
+
+def g_attention():
+    out = {}
+    for tag, fin, fout, groups in (('t176', 176, 768, 6), ('r88', 88, 916, 4), ('f229', 229, 916, 4)):
+        att = ref.UNet_onset.MutliHeadAttention1D(fin, fout, 31, position=True, groups=groups)
+        p = {'a.rel': fx.hashed_normalish(tag + 'rel', (1, fout, 31), 0.5)}
+        for w in ('W_q', 'W_k', 'W_v'):
+            p[f'a.{w}.weight'] = fx.hashed(tag + w, (fout, fin), float(np.sqrt(3.0 / fin)))
+        att.load_state_dict({k[2:]: v for k, v in p.items()})
+        x = fx.hashed(tag + 'x', (2, 64, fin), 1.0).requires_grad_(True)
+        cot = fx.hashed(tag + 'cot', (2, 64, fout), 1.0)
+        o, a = att(x)
+        (o * cot).sum().backward()
+        po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        xo = x.detach().clone().requires_grad_(True)
+        oo, ao = om.local_attention(om.Net(po), xo, 'a', groups)
+        (oo * cot).sum().backward()
+        close(oo, o, 1e-5, tag + ' out'); close(ao, a, 1e-5, tag + ' att'); close(xo.grad, x.grad, 1e-4, tag + ' dx')
+        out.update({f'{tag}_out': o, f'{tag}_att': a, f'{tag}_dx': x.grad,
+                    f'{tag}_drel': att.rel.grad,
+                    f'{tag}_dWq': digest(att.W_q.weight.grad, 256),
+                    f'{tag}_dWk': digest(att.W_k.weight.grad, 256),
+                    f'{tag}_dWv': digest(att.W_v.weight.grad, 256)})
+        for w in ('W_q', 'W_k', 'W_v'):
+            close(po[f'a.{w}.weight'].grad, getattr(att, w).weight.grad, 1e-4, tag + w)
+        close(po['a.rel'].grad, att.rel.grad, 1e-4, tag + 'rel')
+    save('attention', **out)
+
+
+def g_networks():
+    out = {}
+    for kind in ('onset', 'frame'):
+        net, params = build_ref(kind, True)
+        x = fx.fixture_spec(2, 128, 'spec_net')
+        with torch.no_grad():
+            r = net(x)
+            if kind == 'onset':
+                o = om.forward_onset(params, True, x, True)
+                names = ('rec', 'roll', 'onset', 'roll2', 'onset2', 'att')
+            else:
+                o = om.forward_frame(params, True, x, True)
+                names = ('rec', 'roll', 'roll2', 'att')
+        for n, a, b in zip(names, r, o):
+            close(b, a, 2e-5, f'{kind} forward {n}')
+            out[f'{kind}_{n}'] = a if n != 'att' else digest(a, 512)
+        # eval mode (running statistics) after that one training forward
+        net.eval()
+        with torch.no_grad():
+            r = net(x)
+            o = om.forward_onset(params, False, x, True) if kind == 'onset' else om.forward_frame(params, False, x, True)
+        for n, a, b in zip(names, r, o):
+            close(b, a, 2e-5, f'{kind} eval forward {n}')
+            if n in ('roll', 'rec'):
+                out[f'{kind}_eval_{n}'] = a
+    # one full-size clip through the onset transcriber
+    net, params = build_ref('onset', False)
+    x = fx.fixture_spec(1, 640, 'spec_full')
+    with torch.no_grad():
+        roll, onset, a = net.transcriber(x)
+        ro, oo, ao = om.spec2roll_onset(om.Net(params, True), x)
+    close(ro, roll, 2e-5, 'full roll'); close(oo, onset, 2e-5, 'full onset')
+    out['full_roll'] = roll; out['full_onset'] = onset
+    save('networks', **out)
+
+
+def g_vat():
+    out = {}
+    real_randn_like = torch.randn_like
+    for kind in ('onset', 'frame'):
+        for tag, xi, eps in (('wc', 1e-1, 2.0), ('real', 1e-6, 2.0)):
+            net, params = build_ref(kind, False, xi=xi, eps=eps)
+            x = fx.fixture_spec(2, 64, 'spec_vat')
+            d0 = fx.fixture_noise(x.shape, 'd0_' + kind)
+            grabbed = {}
+
+            def fake(t, **kw):
+                d = d0.clone()
+                if kw.get('requires_grad'):
+                    d.requires_grad_(True)
+                grabbed['d'] = d
+                return d
+            torch.randn_like = fake
+            try:
+                lds, r_adv, dn = net.vat_loss(net, x)
+            finally:
+                torch.randn_like = real_randn_like
+            g = grabbed['d'].grad
+            if kind == 'onset':
+                lo, ro, dno, go = om.vat_onset(params, True, x, xi, eps, d0)
+                close(lo['frame'], lds['frame'], 1e-3, 'lds frame'); close(lo['onset'], lds['onset'], 1e-3, 'lds onset')
+                out[f'{kind}_{tag}_lds'] = np.array([lds['frame'].item(), lds['onset'].item()])
+            else:
+                lo, ro, dno, go = om.vat_frame(params, True, x, xi, eps, d0)
+                close(lo, lds, 1e-3, 'lds')
+                out[f'{kind}_{tag}_lds'] = np.array([lds.item()])
+            out[f'{kind}_{tag}_rnorm'] = dn.abs().mean().item()
+            out[f'{kind}_{tag}_radv_rownorm'] = r_adv.norm(dim=-1).flatten()[:8]
+            if tag == 'wc':
+                close(go, g, 1e-3, 'd.grad'); close(ro, r_adv, 1e-3, 'r_adv')
+                out[f'{kind}_{tag}_g'] = g
+                out[f'{kind}_{tag}_radv'] = r_adv
+            print(kind, tag, 'cos(r_adv ref, oracle) =',
+                  F.cosine_similarity(ro.flatten(), r_adv.flatten(), dim=0).item())
+    save('vat', **out)
+
+
+def _batch(b, t, tag):
+    onset, frame = fx.fixture_labels(b, t, tag)
+    return {'audio': fx.fixture_audio(b, t * 512, tag), 'onset': onset, 'frame': frame}
+
+
+def g_run_on_batch():
+    out = {}
+    real_randn_like = torch.randn_like
+    for kind in ('onset', 'frame'):
+        for recon in (False, True):
+            for vat in (False, True):
+                for training in (True, False):
+                    net, params = build_ref(kind, recon, training)
+                    bl, bul = _batch(2, 64, 'L'), _batch(2, 64, 'UL')
+                    noises = [fx.fixture_noise((2, 1, 64, 229), 'd0_ul'), fx.fixture_noise((2, 1, 64, 229), 'd0_l')]
+                    use_ul = vat and training
+                    seq = list(noises if use_ul else noises[1:])
+
+                    def fake(t, **kw):
+                        d = seq.pop(0).clone()
+                        return d.requires_grad_(True) if kw.get('requires_grad') else d
+                    torch.randn_like = fake
+                    try:
+                        pr, lr, sr = net.run_on_batch(bl, bul if use_ul else None, vat)
+                    finally:
+                        torch.randn_like = real_randn_like
+                    fn = om.run_on_batch_onset if kind == 'onset' else om.run_on_batch_frame
+                    po, lo, so = fn(params, training, bl, bul if use_ul else None, vat, recon,
+                                    d0_l=noises[1], d0_ul=noises[0])
+                    assert list(lo.keys()) == list(lr.keys()), (list(lo.keys()), list(lr.keys()))
+                    key = f'{kind}_r{int(recon)}_v{int(vat)}_t{int(training)}'
+                    for k in lr:
+                        close(lo[k], lr[k], 1e-3 if 'LDS' in k else 2e-5, key + k)
+                    close(so, sr, 1e-6, 'spec')
+                    close(po['frame'], pr['frame'], 2e-5, 'frame')
+                    out[key + '_losses'] = np.array([v.item() for v in lr.values()])
+                    out[key + '_keys'] = np.array(list(lr.keys()))
+                    out[key + '_frame'] = digest(pr['frame'], 256)
+                    if 'reconstruction' in pr:
+                        out[key + '_rec'] = digest(pr['reconstruction'], 256)
+    save('run_on_batch', **out)
+
+
+def g_train_step():
+    """One iteration of the reference's own train_VAT_model (torch Adam + StepLR, decay every step so
+    the LR path is exercised).  Adam's first update is lr*sign(g): for weights whose gradient is
+    rounding noise the sign is arbitrary, so parameters are pinned by the FRACTION that agree and the
+    gradients (post-step clip_grad_norm_, helper_functions.py:606-607) by value."""
+    out = {}
+    real_randn_like = torch.randn_like
+    for kind in ('onset', 'frame'):
+        net, params = build_ref(kind, True)
+        opt = torch.optim.Adam(net.parameters(), 1e-3)
+        sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.98)
+
+        class Loader(list):
+            batch_size = 2
+        bl, bul = _batch(2, 64, 'L'), _batch(2, 64, 'UL')
+        noises = [fx.fixture_noise((2, 1, 64, 229), f'd0_{i}') for i in range(2)]
+        seq = [n.clone() for n in noises]
+
+        def fake(t, **kw):
+            d = seq.pop(0)
+            return d.requires_grad_(True) if kw.get('requires_grad') else d
+        torch.randn_like = fake
+        try:
+            pr, lr, _ = ref.train_VAT_model(net, 1, 1, Loader([bl]), Loader([bul]), opt, sched, 3, 1, True, 0)
+        finally:
+            torch.randn_like = real_randn_like
+        fn = om.run_on_batch_onset if kind == 'onset' else om.run_on_batch_frame
+        state = {}
+        po, lo, tot = om.train_step(params, state, 0, bl, bul, fn, alpha=1.0, lr0=1e-3, decay_steps=1,
+                                    decay_rate=0.98, clip=3.0, VAT=True, reconstruction=True,
+                                    d0_ul=noises[0], d0_l=noises[1])
+        for k in lr:
+            e = close(lo[k], lr[k], 1e-3 if 'LDS' in k else 2e-5, 'step ' + k)
+        sd = net.state_dict()
+        named = dict(net.named_parameters())
+        agree = total = 0
+        gmax = max(p.grad.abs().max().item() for p in named.values() if p.grad is not None)
+        out[f'{kind}_gmax'] = gmax
+        for k in om.trainable_keys(params):
+            diff = (params[k].detach() - sd[k]).abs()
+            agree += (diff < 1e-5).sum().item(); total += diff.numel()
+            out[f'{kind}_p:' + k] = digest(sd[k], 32)
+            if named[k].grad is not None:
+                # conv biases feeding a train-mode BN have an analytically zero gradient (pure
+                # rounding noise) -> tolerance is relative to the tensor AND to the global scale
+                err = (params[k].grad - named[k].grad).abs().max().item()
+                assert err <= 5e-3 * named[k].grad.abs().max().item() + 1e-5 * gmax, ('grad ' + k, err)
+                out[f'{kind}_g:' + k] = digest(named[k].grad, 32)
+        print(kind, f'params agreeing to 1e-5 after the Adam step: {agree}/{total}')
+        assert agree / total > 0.97
+        out[f'{kind}_agree'] = agree / total
+        out[f'{kind}_losses'] = np.array([v.item() for v in lr.values()])
+        out[f'{kind}_keys'] = np.array(list(lr.keys()))
+        out[f'{kind}_total'] = tot.item()
+        out[f'{kind}_lr'] = opt.param_groups[0]['lr']
+        out[f'{kind}_nograd'] = np.array([k for k, p in named.items() if p.grad is None])
+    save('train_step', **out)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['frontend', 'unet', 'attention', 'networks', 'vat', 'run_on_batch', 'train_step']
+    for w in which:
+        print('==', w)
+        globals()['g_' + w]()
