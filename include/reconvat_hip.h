@@ -1,0 +1,102 @@
+/*
+ * reconvat_hip.h -- C ABI of libreconvat_hip.so (gfx950 / MI355X only).
+ *
+ * The reference (KinWaiCheuk/ReconVAT) has no native layer: its hot path is a chain of generic
+ * PyTorch ops.  Each entry point below replaces the PyTorch call sites cited next to it (paths are
+ * relative to the reference root).  Conventions, for every function:
+ *   - plain `extern "C"`, raw DEVICE pointers, explicit sizes/strides, fp32 data;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); the call only ENQUEUES work:
+ *     it never allocates, never synchronises, never owns memory (the host framework's allocator owns
+ *     every buffer; scratch is passed in as `workspace`, sized by the *_workspace_bytes queries);
+ *   - returns 0 on success, <0 on error (-1 bad argument, -2 launch failure, -3 unsupported shape);
+ *     `rv_last_error()` returns the text of the last error on the calling thread;
+ *   - re-entrant per stream; no global mutable state.
+ *
+ * Activations are NHWC with an explicit pixel stride `*_ld` (floats between consecutive pixels), so a
+ * tensor may be a channel slice of a wider buffer (the decoder's concat buffers).
+ */
+#ifndef RECONVAT_HIP_H
+#define RECONVAT_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int rv_abi_version(void);
+const char* rv_last_error(void);
+
+/* ---- log-Mel front-end ------------------------------------------------------------------------
+ * replaces nnAudio MelSpectrogram.forward / STFT.forward (model/Spectrogram.py:187-231, :443-461),
+ * torch.log(spec + 1e-5) and Normalization('imagewise').transform (model/UNet_onset.py:419-423,
+ * :432-442; model/utils.py:94-100).  audio [B, nsamp] -> out [B, T, n_mels], T = 1 + nsamp/hop.
+ * twiddle: [1024][2] = (cos, -sin)(2*pi*k/2048); window: [2048]; sparse mel rows: start/len/w[n_mels][mel_ld].
+ * workspace: 2*B uint32. */
+int rv_melspec_lognorm_fwd(const float* audio, long audio_stride, int B, int nsamp, const float* window,
+                           const float* twiddle, const int* mel_start, const int* mel_len, const float* mel_w, int mel_ld,
+                           int n_mels, int hop, int do_log, int normalise, float* out, int T, void* workspace, void* stream);
+
+/* ---- convolutions (nn.Conv2d / nn.ConvTranspose2d call sites, model/UNet_onset.py:173-224) ------
+ * rv_pack_weights: PyTorch-layout weight -> MFMA fragment order for a logical Wm[tap][k][n]
+ *   value(tap,k,n) = w[k*s_k + n*s_n + (flip ? taps-1-tap : tap)];  scatter_cmid>0: 2x2/s2 scatter GEMM.
+ * rv_conv_fwd mode: 0 = 3x3 s1 p1, 1 = 1x1, 2 = 2x2/s2 gather (down fwd, up dgrad), 3 = 2x2/s2 scatter
+ *   (ConvTranspose2d(k=2,s=2)(x, output_size=...) fwd, down dgrad).  Forward AND input-gradient of
+ *   every layer are instances of it (the packing decides which).
+ * rv_conv_wgrad: G[tap][a][b] = sum_p U[f(p,tap)][a]*V[p][b] (+ column sums of V for the bias), written
+ *   to dw[a*s_a + b*s_b + tap'] / dbias[b]; mode 0 = 3x3, 1 = 1x1, 2 = 2x2/s2. */
+long rv_packed_weight_floats(int taps, int kdim, int ndim);
+int rv_pack_weights(const float* w, float* out, int taps, int kdim, int ndim, long s_k, long s_n, int flip,
+                    int scatter_cmid, int force_plain, void* stream);
+int rv_conv_fwd(int mode, const float* in, int in_ld, int B, int H, int W, int Cin, float* out, int out_ld, int Ho,
+                int Wo, int Cout, const float* wpack, const float* bias, int accumulate, void* stream);
+long rv_conv_wgrad_workspace_bytes(int taps, int B, int Hv, int Ca, int Cb);
+int rv_conv_wgrad(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, const float* V, int v_ld, int Hv, int Wv,
+                  int Cb, int B, float* dw, long s_a, long s_b, int flip, float* dbias, int accumulate, void* workspace,
+                  long workspace_bytes, void* stream);
+
+/* ---- BatchNorm2d(momentum=0.1) + leaky_relu (+ residual) (model/UNet_onset.py:183,196-199,221-223) --
+ * coef [4C] = mean, invstd, scale, shift (saved for backward); workspace: 2*C doubles. */
+int rv_bn_lrelu_fwd(const float* z, int z_ld, long P, int C, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, long* num_batches_tracked, float momentum, float eps, int training, float slope,
+                    const float* res, int res_ld, float* y, int y_ld, float* coef, void* workspace, void* stream);
+int rv_bn_lrelu_bwd(const float* dy, int dy_ld, const float* z, int z_ld, long P, int C, const float* coef, float slope,
+                    int frozen, float* dz, int dz_ld, float* dgamma, float* dbeta, void* workspace, void* stream);
+
+/* ---- linear layers (nn.Linear / torch.sigmoid call sites, model/UNet_onset.py:50-52,62-64,275,
+ * 292-293,307-313,324,330): C[m*scm+n*scn] (+)= act(sum_k A[m*sam+k*sak]*B[k*sbk+n*sbn] + bias[n]) */
+int rv_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm, long scn, float* C2,
+            long sc2m, long sc2n, const float* bias, int M, int N, int K, int act, int accumulate, int splitk, void* stream);
+int rv_sigmoid_bwd(const float* g1, int ld1, const float* g2, int ld2, const float* y, int ldy, float* dz, int ldz, long M,
+                   int N, void* stream);
+int rv_colsum(const float* x, int ld, long M, int N, float* out, int accumulate, void* stream);
+
+/* ---- 31-frame local multi-head attention (MutliHeadAttention1D.forward, model/UNet_onset.py:56-91)
+ * q,k,v,out [B,L,G*dh]; rel [G*dh,31]; att, de [B,L,G,31]. */
+int rv_local_attn_fwd(const float* q, const float* k, const float* v, const float* rel, float* out, float* att, int B, int L,
+                      int G, int dh, void* stream);
+int rv_local_attn_bwd(const float* dout, const float* q, const float* k, const float* v, const float* rel, const float* att,
+                      float* dq, float* dk, float* dv, float* de, int B, int L, int G, int dh, void* stream);
+
+/* ---- VAT primitives (UNet_VAT.forward / _l2_normalize, model/UNet_onset.py:126-151,165-171) --------
+ * x_adv = clamp(x + scale * rownormalise(prescale*d), 0, 1) over rows of n elements. */
+int rv_vat_perturb_fwd(const float* x, const float* d, long rows, int n, float prescale, float scale, float* x_adv,
+                       float* r_out, float* dn_out, int* nan_flag, void* stream);
+int rv_vat_perturb_bwd(const float* g, const float* x, const float* d, long rows, int n, float prescale, float scale,
+                       float* gd, void* stream);
+
+/* ---- losses (F.binary_cross_entropy / F.mse_loss / .abs().mean(), model/UNet_onset.py:136-137,
+ * 157-158,471-483); kind 0 BCE, 1 MSE, 2 mean|p|, 3 sqrt(sum p^2).  workspace: rv_reduce_workspace_bytes(n). */
+long rv_reduce_workspace_bytes(long n);
+int rv_reduce_mean(int kind, const float* p, const float* t, long n, float* out, void* workspace, void* stream);
+int rv_loss_bwd(int kind, const float* p, const float* t, long n, const float* gout, float* gp, void* stream);
+
+/* ---- optimiser (torch.optim.Adam + StepLR + clip_grad_norm_, train_UNet_Onset_VAT.py:113,124;
+ * model/helper_functions.py:602-607) on flat buffers; *step = optimiser steps already taken. */
+int rv_adam_step(float* p, const float* g, float* m, float* v, long n, const long* step, float lr0, long decay_steps,
+                 float decay_rate, float beta1, float beta2, float eps, float grad_scale, void* stream);
+int rv_counter_add(long* counter, long inc, void* stream);
+int rv_clip_scale(float* g, long n, const float* total_norm, float max_norm, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

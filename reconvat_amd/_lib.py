@@ -1,0 +1,92 @@
+"""ctypes binding of libreconvat_hip.so (include/reconvat_hip.h).
+
+The product path has NO fallback: if the shared library is missing, importing a symbol raises, and every
+op raises when its inputs are not on a HIP device.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libreconvat_hip.so')
+
+P = ctypes.c_void_p
+I = ctypes.c_int
+L = ctypes.c_long
+F = ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/reconvat_hip.h one to one
+SIGNATURES = {
+    'rv_abi_version': (I, []),
+    'rv_last_error': (ctypes.c_char_p, []),
+    'rv_melspec_lognorm_fwd': (I, [P, L, I, I, P, P, P, P, P, I, I, I, I, I, P, I, P, P]),
+    'rv_packed_weight_floats': (L, [I, I, I]),
+    'rv_pack_weights': (I, [P, P, I, I, I, L, L, I, I, I, P]),
+    'rv_conv_fwd': (I, [I, P, I, I, I, I, I, P, I, I, I, I, P, P, I, P]),
+    'rv_conv_wgrad_workspace_bytes': (L, [I, I, I, I, I]),
+    'rv_conv_wgrad': (I, [I, P, I, I, I, I, P, I, I, I, I, I, P, L, L, I, P, I, P, L, P]),
+    'rv_bn_lrelu_fwd': (I, [P, I, L, I, P, P, P, P, P, F, F, I, F, P, I, P, I, P, P, P]),
+    'rv_bn_lrelu_bwd': (I, [P, I, P, I, L, I, P, F, I, P, I, P, P, P, P]),
+    'rv_gemm': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, I, I, I, I, I, I, P]),
+    'rv_sigmoid_bwd': (I, [P, I, P, I, P, I, P, I, L, I, P]),
+    'rv_colsum': (I, [P, I, L, I, P, I, P]),
+    'rv_local_attn_fwd': (I, [P, P, P, P, P, P, I, I, I, I, P]),
+    'rv_local_attn_bwd': (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    'rv_vat_perturb_fwd': (I, [P, P, L, I, F, F, P, P, P, P, P]),
+    'rv_vat_perturb_bwd': (I, [P, P, P, L, I, F, F, P, P]),
+    'rv_reduce_workspace_bytes': (L, [L]),
+    'rv_reduce_mean': (I, [I, P, P, L, P, P, P]),
+    'rv_loss_bwd': (I, [I, P, P, L, P, P, P]),
+    'rv_adam_step': (I, [P, P, P, P, L, P, F, L, F, F, F, F, F, P]),
+    'rv_counter_add': (I, [P, L, P]),
+    'rv_clip_scale': (I, [P, L, P, F, P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and declare every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} is missing: the HIP extension has not been built. '
+            'Run `python -c "import __graft_entry__ as g; g.build()"` (or `python reconvat_amd/build.py`). '
+            'There is no CPU/PyTorch fallback for the product path.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().rv_last_error().decode()
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('reconvat_amd ops run on a HIP device only (got a CPU tensor); there is no CPU fallback')
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point and raise on a non-zero status."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f'{name} failed ({rc}): {lib.rv_last_error().decode()}')

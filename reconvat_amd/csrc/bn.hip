@@ -1,0 +1,212 @@
+// Train/eval BatchNorm2d + leaky-ReLU (+ residual add) on NHWC fp32 for gfx950.
+//
+// Reference semantics: nn.BatchNorm2d(C, momentum=0.1, eps=1e-5) followed by F.leaky_relu(0.01)
+// (model/UNet_onset.py:183-201, :216-224).  HBM-bound: every kernel streams [P, C] once with
+// coalesced channel-fastest accesses; per-channel sums are carried in fp64 (fp32 per-thread partials
+// over <= 64 pixels, fp64 across threads/blocks) so that var = E[x^2] - mean^2 is safe.
+//
+//   stats    : sum / sum-of-squares per channel                    (reads z)
+//   finalize : mean, invstd, scale/shift, running stats, num_batches_tracked
+//   apply    : y = lrelu(z*scale + shift) (+ residual)             (reads z [,res], writes y)
+//   bwd_red  : sum(dzh), sum(dzh*xhat)  with dzh = dy * lrelu'(zh) (reads dy, z)
+//   bwd_apply: dz = scale * (dzh - mean(dzh) - xhat*mean(dzh*xhat)) (reads dy, z, writes dz)
+#include "common.h"
+
+#define BN_PIX_PER_THREAD 64
+
+struct BnArgs {
+    const float* z; int z_ld;
+    const float* dy; int dy_ld;
+    float* out; int out_ld;
+    const float* res; int res_ld;
+    long P; int C;
+    double* sums;            // [2C] fp64 accumulators
+    const float* coef;       // [4C]: mean, invstd, scale, shift
+    float slope;
+    int frozen;              // eval-mode statistics: no batch-mean terms in the backward
+    float* dgamma; float* dbeta;
+    int accumulate;
+};
+
+// thread t -> channel t % C, pixel lane t / C ; PL = 256 / C pixel lanes per block
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_reduce_k(BnArgs a) {
+    __shared__ double sh[2][256];
+    const int C = a.C, PL = 256 / C;
+    const int t = threadIdx.x;
+    const int c = t % C, pl = t / C;
+    float s0 = 0.f, s1 = 0.f;
+    if (pl < PL) {
+        const long chunk = (long)PL * BN_PIX_PER_THREAD;
+        const long p0 = (long)blockIdx.x * chunk;
+        float mean = 0.f, invstd = 0.f, scale = 0.f, shift = 0.f;
+        if (BWD) { mean = a.coef[c]; invstd = a.coef[C + c]; scale = a.coef[2 * C + c]; shift = a.coef[3 * C + c]; }
+#pragma unroll 4
+        for (int k = 0; k < BN_PIX_PER_THREAD; ++k) {
+            long p = p0 + pl + (long)k * PL;
+            if (p >= a.P) break;
+            float z = a.z[p * a.z_ld + c];
+            if (BWD) {
+                float zh = fmaf(z, scale, shift);
+                float d = a.dy[p * a.dy_ld + c];
+                d = zh > 0.f ? d : d * a.slope;
+                s0 += d;
+                s1 += d * ((z - mean) * invstd);
+            } else {
+                s0 += z;
+                s1 = fmaf(z, z, s1);
+            }
+        }
+    }
+    sh[0][t] = (double)s0;
+    sh[1][t] = (double)s1;
+    __syncthreads();
+    if (t < C) {
+        double d0 = 0.0, d1 = 0.0;
+        for (int l = 0; l < PL; ++l) { d0 += sh[0][l * C + t]; d1 += sh[1][l * C + t]; }
+        atomicAdd(&a.sums[t], d0);
+        atomicAdd(&a.sums[C + t], d1);
+    }
+}
+
+struct BnFinalArgs {
+    const double* sums; long P; int C;
+    const float* gamma; const float* beta;
+    float* running_mean; float* running_var; long* nbt;
+    float* coef;      // [4C] out: mean, invstd, scale, shift
+    float momentum, eps;
+    int training;
+};
+
+__global__ void bn_finalize_k(BnFinalArgs a) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && a.training && a.nbt) *a.nbt += 1;
+    if (c >= a.C) return;
+    float mean, invstd;
+    if (a.training) {
+        double n = (double)a.P;
+        double m = a.sums[c] / n;
+        double var = a.sums[a.C + c] / n - m * m;
+        if (var < 0.0) var = 0.0;
+        mean = (float)m;
+        invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+        double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+        a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
+        a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
+    } else {
+        mean = a.running_mean[c];
+        invstd = 1.0f / sqrtf(a.running_var[c] + a.eps);
+    }
+    float scale = a.gamma[c] * invstd;
+    a.coef[c] = mean;
+    a.coef[a.C + c] = invstd;
+    a.coef[2 * a.C + c] = scale;
+    a.coef[3 * a.C + c] = a.beta[c] - mean * scale;
+}
+
+// elementwise, 4 channels per thread (C % 4 == 0)
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
+    const int C4 = a.C >> 2;
+    const long total = a.P * C4;
+    const double invn = 1.0 / (double)a.P;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long p = idx / C4;
+        const int c = (int)(idx - p * C4) * 4;
+        f32x4 z = *reinterpret_cast<const f32x4*>(a.z + p * a.z_ld + c);
+        f32x4 o;
+        if (!BWD) {
+            f32x4 r = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (a.res) r = *reinterpret_cast<const f32x4*>(a.res + p * a.res_ld + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float zh = fmaf(z[k], a.coef[2 * a.C + c + k], a.coef[3 * a.C + c + k]);
+                o[k] = (zh > 0.f ? zh : zh * a.slope) + r[k];
+            }
+        } else {
+            f32x4 d = *reinterpret_cast<const f32x4*>(a.dy + p * a.dy_ld + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cc = c + k;
+                const float mean = a.coef[cc], invstd = a.coef[a.C + cc], scale = a.coef[2 * a.C + cc],
+                            shift = a.coef[3 * a.C + cc];
+                float zh = fmaf(z[k], scale, shift);
+                float dz = zh > 0.f ? d[k] : d[k] * a.slope;
+                if (!a.frozen) {
+                    float xh = (z[k] - mean) * invstd;
+                    float k1 = (float)(a.sums[cc] * invn), k2 = (float)(a.sums[a.C + cc] * invn);
+                    dz = dz - k1 - xh * k2;
+                }
+                o[k] = dz * scale;
+            }
+        }
+        float* dst = a.out + p * a.out_ld + c;
+        if (a.accumulate) {
+            f32x4 old = *reinterpret_cast<f32x4*>(dst);
+            o += old;
+        }
+        *reinterpret_cast<f32x4*>(dst) = o;
+    }
+    if (BWD && blockIdx.x == 0 && a.dgamma) {
+        for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+            a.dgamma[c] = (float)a.sums[a.C + c];
+            a.dbeta[c] = (float)a.sums[c];
+        }
+    }
+}
+
+extern "C" {
+
+// workspace: 2*C doubles (sums).  coef: [4C] floats (mean, invstd, scale, shift) -- saved for backward.
+// training != 0: batch statistics, running stats / num_batches_tracked updated in place.
+// y = leaky_relu(bn(z), slope) (+ res).  slope = 1 -> no activation.
+int rv_bn_lrelu_fwd(const float* z, int z_ld, long P, int C, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, long* num_batches_tracked, float momentum, float eps, int training, float slope,
+                    const float* res, int res_ld, float* y, int y_ld, float* coef, void* workspace, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    RV_CHECK_ARG(C % 4 == 0 && C <= 256, "rv_bn_lrelu_fwd: C=%d must be a multiple of 4 and <= 256", C);
+    RV_CHECK_ARG((z_ld % 4) == 0 && (y_ld % 4) == 0 && (!res || (res_ld % 4) == 0), "rv_bn_lrelu_fwd: strides must be multiples of 4");
+    BnArgs a = {};
+    a.z = z; a.z_ld = z_ld; a.P = P; a.C = C; a.sums = (double*)workspace; a.slope = slope;
+    if (training) {
+        (void)hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, st);
+        const int PL = 256 / C;
+        hipLaunchKernelGGL(bn_reduce_k<false>, dim3(cdiv(P, (long)PL * BN_PIX_PER_THREAD)), dim3(256), 0, st, a);
+        RV_LAUNCH_CHECK("rv_bn_lrelu_fwd(stats)");
+    }
+    BnFinalArgs f;
+    f.sums = (const double*)workspace; f.P = P; f.C = C; f.gamma = gamma; f.beta = beta;
+    f.running_mean = running_mean; f.running_var = running_var; f.nbt = num_batches_tracked;
+    f.coef = coef; f.momentum = momentum; f.eps = eps; f.training = training;
+    hipLaunchKernelGGL(bn_finalize_k, dim3(cdiv(C, 64)), dim3(64), 0, st, f);
+    RV_LAUNCH_CHECK("rv_bn_lrelu_fwd(finalize)");
+    a.coef = coef; a.out = y; a.out_ld = y_ld; a.res = res; a.res_ld = res_ld;
+    long total = P * (C / 4);
+    int blocks = (int)(total / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(bn_apply_k<false>, dim3(blocks), dim3(256), 0, st, a);
+    RV_LAUNCH_CHECK("rv_bn_lrelu_fwd(apply)");
+    return RV_OK;
+}
+
+// dz (and dgamma/dbeta when non-null) from dy; z and coef are the forward's.  frozen != 0: eval-mode BN.
+int rv_bn_lrelu_bwd(const float* dy, int dy_ld, const float* z, int z_ld, long P, int C, const float* coef, float slope,
+                    int frozen, float* dz, int dz_ld, float* dgamma, float* dbeta, void* workspace, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    RV_CHECK_ARG(C % 4 == 0 && C <= 256, "rv_bn_lrelu_bwd: C=%d must be a multiple of 4 and <= 256", C);
+    BnArgs a = {};
+    a.z = z; a.z_ld = z_ld; a.dy = dy; a.dy_ld = dy_ld; a.P = P; a.C = C; a.sums = (double*)workspace;
+    a.coef = coef; a.slope = slope; a.frozen = frozen; a.out = dz; a.out_ld = dz_ld; a.dgamma = dgamma; a.dbeta = dbeta;
+    if (!frozen || dgamma) {
+        (void)hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, st);
+        const int PL = 256 / C;
+        hipLaunchKernelGGL(bn_reduce_k<true>, dim3(cdiv(P, (long)PL * BN_PIX_PER_THREAD)), dim3(256), 0, st, a);
+        RV_LAUNCH_CHECK("rv_bn_lrelu_bwd(reduce)");
+    }
+    long total = P * (C / 4);
+    int blocks = (int)(total / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(bn_apply_k<true>, dim3(blocks), dim3(256), 0, st, a);
+    RV_LAUNCH_CHECK("rv_bn_lrelu_bwd(apply)");
+    return RV_OK;
+}
+
+}  // extern "C"

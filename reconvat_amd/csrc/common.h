@@ -1,0 +1,63 @@
+// Shared device/host helpers for libreconvat_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define RV_OK 0
+#define RV_EINVAL (-1)
+#define RV_ELAUNCH (-2)
+#define RV_EUNSUPPORTED (-3)
+
+extern "C" void rv_set_error(const char* fmt, ...);
+
+#define RV_CHECK_ARG(cond, ...)                        \
+    do {                                               \
+        if (!(cond)) {                                 \
+            rv_set_error(__VA_ARGS__);                 \
+            return RV_EINVAL;                          \
+        }                                              \
+    } while (0)
+
+#define RV_LAUNCH_CHECK(name)                                                      \
+    do {                                                                           \
+        hipError_t e__ = hipGetLastError();                                        \
+        if (e__ != hipSuccess) {                                                   \
+            rv_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));   \
+            return RV_ELAUNCH;                                                     \
+        }                                                                          \
+    } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- wave64 reductions -------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// XCD-aware block remap (8 XCDs, dispatcher places block b on XCD b%8): give every XCD a
+// contiguous chunk of the logical grid so neighbouring tiles share an L2.  Bijective for any n.
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+    const int q = n >> 3, r = n & 7, x = bid & 7, k = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}

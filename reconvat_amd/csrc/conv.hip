@@ -1,0 +1,706 @@
+// Convolution family for the ReconVAT U-Nets on gfx950 (CDNA4), fp32 in / fp32 accumulate.
+//
+// All activations are NHWC fp32 with an explicit pixel stride ("ld", floats per pixel) so that a
+// tensor may be a channel slice of a wider buffer (the decoder's concat buffers).
+//
+// Everything 3x3 / 1x1 / 2x2-stride-2 in the U-Net (reference model/UNet_onset.py:173-224) is one
+// of two implicit GEMMs on v_mfma_f32_16x16x4_f32 (exact f32, 157 TF/s peak):
+//
+//   gather : out[b,oy,ox,co] = bias[co] + sum_{ky,kx,ci} in[b, oy*S-P+ky, ox*S-P+kx, ci] * Wm[ky,kx,ci,co]
+//            Conv2d 3x3 (fwd, dgrad), ConvTranspose2d 3x3 s1 p1 (fwd, dgrad), 1x1 skip (fwd, dgrad),
+//            2x2/s2 down-conv fwd, 2x2/s2 up-conv dgrad.
+//   scatter: out[b,2iy+ky,2ix+kx,co] = bias[co] + sum_ci in[b,iy,ix,ci] * Wm[ci,(ky,kx,co)]
+//            ConvTranspose2d 2x2/s2 fwd (with output_size -> bias-only padding row/col,
+//            model/UNet_onset.py:212-219) and down-conv dgrad.
+//
+// MFMA roles: A operand = weights  A[i=cout][k=cin],  B operand = activations B[k=cin][j=pixel],
+// so the accumulator lane (j = lane&15, g = lane>>4) holds 4 CONSECUTIVE output channels
+// (4g..4g+3) of ONE pixel -> one 16-byte store per lane, whole-wave stores are contiguous.
+// Activation fragments are read straight from global/L2 as 16-byte (R=4) or 8-byte (R=2) vectors:
+// lane (j,g) reads channels [c*4R + g*R, +R) of pixel j; MFMA r uses channel g*R+r as k=g.
+// Weight fragments are pre-packed in exactly this lane order (rv_pack_weights) so a wave reads one
+// contiguous 1 KiB line per fragment.  M is the flattened output-pixel index (no per-row tile waste).
+//
+// Weight gradients are pixel-reduction GEMMs (wgrad_mfma): per-wave partial sums are written to a
+// workspace and folded by a deterministic second pass (no atomics).
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------
+struct PackArgs {
+    const float* w;
+    float* out;
+    int taps, kdim, ndim;     // logical Wm[tap][k][n]
+    int R, ntile_n, nchunk;   // fragment geometry
+    long s_k, s_n;            // element strides of k and n in the PyTorch tensor (tap stride is 1)
+    int flip;                 // spatial flip of the tap index
+    int scatter_cmid;         // >0: n = tap4*cmid + c, taps==1, source = k*s_k + c*s_n + tap4
+    long total;
+};
+
+__global__ void pack_frag_k(PackArgs a) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.total) return;
+    const int R = a.R;
+    int r = (int)(idx % R);
+    long t = idx / R;
+    int lane = (int)(t % 64); t /= 64;
+    int nt = (int)(t % a.ntile_n); t /= a.ntile_n;
+    int c = (int)(t % a.nchunk);
+    int tap = (int)(t / a.nchunk);
+    int k = c * 4 * R + (lane >> 4) * R + r;
+    int n = nt * 16 + (lane & 15);
+    float v = 0.f;
+    if (k < a.kdim && n < a.ndim) {
+        if (a.scatter_cmid > 0) {
+            int tap4 = n / a.scatter_cmid, cc = n % a.scatter_cmid;
+            v = a.w[(long)k * a.s_k + (long)cc * a.s_n + tap4];
+        } else {
+            int tt = a.flip ? (a.taps - 1 - tap) : tap;
+            v = a.w[(long)k * a.s_k + (long)n * a.s_n + tt];
+        }
+    }
+    a.out[idx] = v;
+}
+
+// plain [tap][k][n] copy for the small-channel VALU kernels
+__global__ void pack_plain_k(PackArgs a) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.total) return;
+    int n = (int)(idx % a.ndim);
+    long t = idx / a.ndim;
+    int k = (int)(t % a.kdim);
+    int tap = (int)(t / a.kdim);
+    int tt = a.flip ? (a.taps - 1 - tap) : tap;
+    a.out[idx] = a.w[(long)k * a.s_k + (long)n * a.s_n + tt];
+}
+
+// ------------------------------------------------------------------------------------------
+// implicit-GEMM convolution on MFMA
+// ------------------------------------------------------------------------------------------
+struct ConvArgs {
+    const float* in;  int in_ld;  int H, W;       // input spatial dims
+    float* out;       int out_ld; int Ho, Wo;     // output spatial dims
+    int B, Cin, Cout;
+    const float* wpack; const float* bias;
+    int nchunk, ntile_n;
+    int Pw, Ph;       // pixel grid the GEMM's N dimension runs over (= Ho,Wo for gather; H+eh,W+ew for scatter)
+    long npix;        // B*Ph*Pw
+    int vec_store;    // out pointer/ld allow 16-byte stores
+    int accumulate;   // out += result
+};
+
+template <int R> struct VecR;
+template <> struct VecR<4> { typedef f32x4 T; };
+template <> struct VecR<2> { typedef f32x2 T; };
+
+template <int KH, int KW, int S, int P, int R, int NT, int MT, bool SCATTER>
+__global__ __launch_bounds__(256) void conv_mfma_k(ConvArgs a) {
+    typedef typename VecR<R>::T vec;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int bx = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt0 = blockIdx.y * NT;
+    const long tile0 = ((long)bx * 4 + wave) * MT;
+    if (tile0 * 16 >= a.npix) return;
+
+    int py[MT], px[MT], pb[MT];
+    long ibase[MT];
+    bool pv[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        long p = (tile0 + m) * 16 + j;
+        pv[m] = p < a.npix;
+        long pp = pv[m] ? p : 0;
+        int b = (int)(pp / ((long)a.Ph * a.Pw));
+        int rem = (int)(pp - (long)b * a.Ph * a.Pw);
+        py[m] = rem / a.Pw;
+        px[m] = rem - py[m] * a.Pw;
+        pb[m] = b;
+        ibase[m] = (((long)b * a.H + py[m] * S - P) * a.W + px[m] * S - P) * a.in_ld + g * R;
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* wp = a.wpack + ((long)nt0 * 64 + lane) * R;
+    const long wstep = (long)a.ntile_n * 64 * R;
+    const int nchunk = a.nchunk;
+    const int nsteps = KH * KW * nchunk;
+
+    // loader state (one tap ahead of the MFMAs at most)
+    int l_tap = 0, l_c = 0;
+    bool ok[MT];
+    long toff = 0;
+    auto set_tap = [&](int tap) {
+        const int ky = tap / KW, kx = tap - ky * KW;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            int iy = py[m] * S - P + ky, ix = px[m] * S - P + kx;
+            ok[m] = pv[m] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        }
+        toff = ((long)ky * a.W + kx) * a.in_ld;
+    };
+    auto load = [&](vec (&wf)[NT], vec (&xf)[MT], int s) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) wf[n] = *reinterpret_cast<const vec*>(wp + s * wstep + (long)n * 64 * R);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            vec v;
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = 0.f;
+            if (ok[m]) v = *reinterpret_cast<const vec*>(a.in + ibase[m] + toff + (long)l_c * 4 * R);
+            xf[m] = v;
+        }
+    };
+
+    vec wcur[NT], xcur[MT], wnxt[NT], xnxt[MT];
+    set_tap(0);
+    load(wcur, xcur, 0);
+    for (int s = 0; s < nsteps; ++s) {
+        if (s + 1 < nsteps) {
+            if (++l_c == nchunk) { l_c = 0; ++l_tap; set_tap(l_tap); }
+            load(wnxt, xnxt, s + 1);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[n][r], xcur[m][r], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) wcur[n] = wnxt[n];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xcur[m] = xnxt[m];
+    }
+
+    // epilogue: lane holds channels co0..co0+3 of pixel j of every (m, n) tile
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (!pv[m]) continue;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int ncol = (nt0 + n) * 16 + 4 * g;      // GEMM row index (cout')
+            int co0;
+            long opix;
+            bool inside = true;
+            if (SCATTER) {
+                const int tap4 = ncol / a.Cout;
+                co0 = ncol - tap4 * a.Cout;
+                const int oy = py[m] * 2 + (tap4 >> 1), ox = px[m] * 2 + (tap4 & 1);
+                inside = tap4 < 4 && oy < a.Ho && ox < a.Wo;
+                opix = ((long)pb[m] * a.Ho + oy) * a.Wo + ox;
+            } else {
+                co0 = ncol;
+                opix = (tile0 + m) * 16 + j;
+            }
+            if (!inside || co0 >= a.Cout) continue;
+            float* o = a.out + opix * a.out_ld + co0;
+            f32x4 v = acc[m][n];
+            if (a.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co0 + r < a.Cout) v[r] += a.bias[co0 + r];
+            }
+            if (a.vec_store && co0 + 3 < a.Cout) {
+                if (a.accumulate) {
+                    f32x4 old = *reinterpret_cast<f32x4*>(o);
+                    v += old;
+                }
+                *reinterpret_cast<f32x4*>(o) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co0 + r < a.Cout) o[r] = a.accumulate ? o[r] + v[r] : v[r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// small-channel convolution on the VALU (Cin==1, or Cout<=2): pure bandwidth kernels
+// ------------------------------------------------------------------------------------------
+struct SmallArgs {
+    const float* in;  int in_ld;  int H, W;
+    float* out;       int out_ld; int Ho, Wo;
+    int B;
+    const float* wplain;   // [tap][CIN][COUT]
+    const float* bias;
+    long npix;
+    int accumulate;
+};
+
+template <int CIN, int COUT, int KH, int KW, int S, int P>
+__global__ __launch_bounds__(256) void conv_small_k(SmallArgs a) {
+    long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.npix) return;
+    int b = (int)(p / ((long)a.Ho * a.Wo));
+    int rem = (int)(p - (long)b * a.Ho * a.Wo);
+    int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+    for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            int iy = oy * S - P + ky, ix = ox * S - P + kx;
+            if ((unsigned)iy >= (unsigned)a.H || (unsigned)ix >= (unsigned)a.W) continue;
+            const float* src = a.in + (((long)b * a.H + iy) * a.W + ix) * a.in_ld;
+            const float* w = a.wplain + (ky * KW + kx) * CIN * COUT;
+            float xin[CIN];
+            if constexpr (CIN % 4 == 0) {
+#pragma unroll
+                for (int c = 0; c < CIN; c += 4) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+                    xin[c] = v[0]; xin[c + 1] = v[1]; xin[c + 2] = v[2]; xin[c + 3] = v[3];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) xin[c] = src[c];
+            }
+#pragma unroll
+            for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(xin[c], w[c * COUT + co], acc[co]);
+        }
+    float* o = a.out + p * a.out_ld;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) o[co] = a.accumulate ? o[co] + acc[co] : acc[co];
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient: G[tap][a][b] = sum_p U[f(p,tap)][a] * V[p][b]   (+ colsum of V for the bias)
+// ------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* U; int u_ld, Hu, Wu, Ca;    // gathered tensor (conv input, or dY for the up-conv)
+    const float* V; int v_ld, Hv, Wv, Cb;    // dense tensor, one MFMA k per V pixel
+    int B;
+    float* part; long pstride;               // partial sums [nparts][taps*Ca*Cb (+Cb)]
+    int rows_per_wave, nparts, ngb;          // ngb = number of b-groups
+    int want_bias;
+};
+
+template <int KH, int KW, int S, int P, int TA, int TB>
+__global__ __launch_bounds__(256) void wgrad_mfma_k(WgradArgs a) {
+    constexpr int TAPS = KH * KW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int pw = blockIdx.x * 4 + wave;
+    if (pw >= a.nparts) return;
+    const int ga = blockIdx.y / a.ngb, gb = blockIdx.y - ga * a.ngb;
+    const int a0 = ga * TA * 16, b0 = gb * TB * 16;
+    const int nrows = a.B * a.Hv;
+    const int row0 = pw * a.rows_per_wave;
+    const int row1 = min(row0 + a.rows_per_wave, nrows);
+
+    f32x4 acc[TAPS][TA][TB];
+    f32x4 accb[TB];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int x = 0; x < TA; ++x)
+#pragma unroll
+            for (int y = 0; y < TB; ++y) acc[t][x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int y = 0; y < TB; ++y) accb[y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bool aval[TA], bval[TB];
+#pragma unroll
+    for (int x = 0; x < TA; ++x) aval[x] = a0 + x * 16 + i < a.Ca;
+#pragma unroll
+    for (int y = 0; y < TB; ++y) bval[y] = b0 + y * 16 + i < a.Cb;
+    const bool do_bias = a.want_bias && ga == 0;
+
+    for (int row = row0; row < row1; ++row) {
+        const int b = row / a.Hv, y = row - b * a.Hv;
+        const float* vrow = a.V + ((long)b * a.Hv + y) * a.Wv * a.v_ld + b0 + i;
+        for (int x0 = 0; x0 < a.Wv; x0 += 4) {
+            const int x = x0 + g;
+            const bool vx = x < a.Wv;
+            float vf[TB];
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb)
+                vf[tb] = (vx && bval[tb]) ? vrow[(long)x * a.v_ld + tb * 16] : 0.f;
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky) {
+                const int iy = y * S - P + ky;
+                const bool oky = (unsigned)iy < (unsigned)a.Hu;
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx) {
+                    const int ix = x * S - P + kx;
+                    const bool ok = vx && oky && (unsigned)ix < (unsigned)a.Wu;
+                    const float* up = a.U + (((long)b * a.Hu + iy) * a.Wu + ix) * a.u_ld + a0 + i;
+#pragma unroll
+                    for (int ta = 0; ta < TA; ++ta) {
+                        float uf = (ok && aval[ta]) ? up[ta * 16] : 0.f;
+#pragma unroll
+                        for (int tb = 0; tb < TB; ++tb)
+                            acc[ky * KW + kx][ta][tb] =
+                                __builtin_amdgcn_mfma_f32_16x16x4f32(uf, vf[tb], acc[ky * KW + kx][ta][tb], 0, 0, 0);
+                    }
+                }
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int tb = 0; tb < TB; ++tb)
+                    accb[tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, vf[tb], accb[tb], 0, 0, 0);
+            }
+        }
+    }
+    // D[row = a_local = 4g+r][col = b_local = i]
+    float* dst = a.part + (long)pw * a.pstride;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) {
+                const int bb = b0 + tb * 16 + i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int aa = a0 + ta * 16 + 4 * g + r;
+                    if (aa < a.Ca && bb < a.Cb) dst[((long)t * a.Ca + aa) * a.Cb + bb] = acc[t][ta][tb][r];
+                }
+            }
+    if (do_bias && g == 0) {
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) {
+            const int bb = b0 + tb * 16 + i;
+            if (bb < a.Cb) dst[(long)TAPS * a.Ca * a.Cb + bb] = accb[tb][0];
+        }
+    }
+}
+
+// VALU version for tiny channel counts (Ca*Cb*taps <= 144)
+template <int CA, int CB, int KH, int KW, int S, int P>
+__global__ __launch_bounds__(256) void wgrad_small_k(WgradArgs a) {
+    constexpr int TAPS = KH * KW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pw = blockIdx.x * 4 + wave;
+    if (pw >= a.nparts) return;
+    float acc[TAPS][CA][CB];
+    float accb[CB];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int x = 0; x < CA; ++x)
+#pragma unroll
+            for (int y = 0; y < CB; ++y) acc[t][x][y] = 0.f;
+#pragma unroll
+    for (int y = 0; y < CB; ++y) accb[y] = 0.f;
+    const long npix = (long)a.B * a.Hv * a.Wv;
+    const long per = (npix + a.nparts - 1) / a.nparts;
+    const long p0 = (long)pw * per, p1 = min(p0 + per, npix);
+    for (long p = p0 + lane; p < p1; p += 64) {
+        int b = (int)(p / ((long)a.Hv * a.Wv));
+        int rem = (int)(p - (long)b * a.Hv * a.Wv);
+        int y = rem / a.Wv, x = rem - y * a.Wv;
+        float v[CB];
+        const float* vp = a.V + p * a.v_ld;
+#pragma unroll
+        for (int c = 0; c < CB; ++c) { v[c] = vp[c]; accb[c] += v[c]; }
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                int iy = y * S - P + ky, ix = x * S - P + kx;
+                if ((unsigned)iy >= (unsigned)a.Hu || (unsigned)ix >= (unsigned)a.Wu) continue;
+                const float* up = a.U + (((long)b * a.Hu + iy) * a.Wu + ix) * a.u_ld;
+#pragma unroll
+                for (int ca = 0; ca < CA; ++ca) {
+                    float u = up[ca];
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+                        acc[ky * KW + kx][ca][cb] = fmaf(u, v[cb], acc[ky * KW + kx][ca][cb]);
+                }
+            }
+    }
+    float* dst = a.part + (long)pw * a.pstride;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int ca = 0; ca < CA; ++ca)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                float s = wave_sum(acc[t][ca][cb]);
+                if (lane == 0) dst[((long)t * CA + ca) * CB + cb] = s;
+            }
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        float s = wave_sum(accb[cb]);
+        if (lane == 0 && a.want_bias) dst[(long)TAPS * CA * CB + cb] = s;
+    }
+}
+
+// fold the per-wave partials and scatter into the PyTorch weight layout
+struct WreduceArgs {
+    const float* part; long pstride; int nparts;
+    int taps, Ca, Cb;
+    float* dw; long s_a, s_b; int flip;     // dw[a*s_a + b*s_b + tap']
+    float* dbias;                            // nullable, [Cb]
+    int accumulate;
+};
+
+__global__ void wgrad_reduce_k(WreduceArgs a) {
+    const long nel = (long)a.taps * a.Ca * a.Cb + (a.dbias ? a.Cb : 0);
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nel) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const float* p = a.part + e;
+    int k = 0;
+    for (; k + 3 < a.nparts; k += 4) {
+        s0 += p[(long)k * a.pstride];
+        s1 += p[(long)(k + 1) * a.pstride];
+        s2 += p[(long)(k + 2) * a.pstride];
+        s3 += p[(long)(k + 3) * a.pstride];
+    }
+    for (; k < a.nparts; ++k) s0 += p[(long)k * a.pstride];
+    float s = (s0 + s1) + (s2 + s3);
+    const long nw = (long)a.taps * a.Ca * a.Cb;
+    if (e < nw) {
+        int bb = (int)(e % a.Cb);
+        long t = e / a.Cb;
+        int aa = (int)(t % a.Ca);
+        int tap = (int)(t / a.Ca);
+        int tt = a.flip ? (a.taps - 1 - tap) : tap;
+        float* d = a.dw + (long)aa * a.s_a + (long)bb * a.s_b + tt;
+        *d = a.accumulate ? *d + s : s;
+    } else {
+        float* d = a.dbias + (e - nw);
+        *d = a.accumulate ? *d + s : s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host dispatch
+// ------------------------------------------------------------------------------------------
+template <int KH, int KW, int S, int P, int R, bool SC>
+static int launch_conv_rt(const ConvArgs& a, int NT, int MT, hipStream_t st) {
+    const long ntiles = (a.npix + 15) / 16;
+#define RV_CASE(nt, mt)                                                                          \
+    if (NT == nt && MT == mt) {                                                                  \
+        dim3 grid(cdiv(ntiles, 4 * mt), a.ntile_n / nt);                                         \
+        hipLaunchKernelGGL((conv_mfma_k<KH, KW, S, P, R, nt, mt, SC>), grid, dim3(256), 0, st, a); \
+        return RV_OK;                                                                            \
+    }
+    RV_CASE(1, 1) RV_CASE(1, 2) RV_CASE(1, 4)
+    RV_CASE(2, 1) RV_CASE(2, 2) RV_CASE(2, 4)
+    RV_CASE(3, 1) RV_CASE(3, 2) RV_CASE(3, 4)
+    RV_CASE(4, 1) RV_CASE(4, 2) RV_CASE(4, 4)
+#undef RV_CASE
+    return RV_EUNSUPPORTED;
+}
+
+// choose (NT, MT): as much register-level reuse as possible while keeping >= ~2048 waves in flight
+static void choose_tiles(long ntiles, int ntile_n, int* NT, int* MT) {
+    static const int nts[4] = {4, 3, 2, 1};
+    static const int mts[3] = {4, 2, 1};
+    int best_nt = 1, best_mt = 1;
+    long best_score = -1;
+    for (int a = 0; a < 4; ++a) {
+        int nt = nts[a];
+        if (ntile_n % nt) continue;
+        for (int b = 0; b < 3; ++b) {
+            int mt = mts[b];
+            long waves = ((ntiles + mt - 1) / mt) * (ntile_n / nt);
+            // reuse score = MFMAs per fragment load; penalise launches that cannot fill the chip
+            long reuse = (long)(nt * mt * 100) / (nt + mt);
+            long fill = waves >= 2048 ? 100 : (waves * 100) / 2048;
+            long score = reuse * fill;
+            if (score > best_score) { best_score = score; best_nt = nt; best_mt = mt; }
+        }
+    }
+    *NT = best_nt; *MT = best_mt;
+}
+
+static int frag_R(int kdim) { return (kdim % 16 == 0) ? 4 : ((kdim % 8 == 0) ? 2 : 0); }
+
+extern "C" {
+
+// Size (floats) of the packed fragment buffer for a logical Wm[taps][kdim][ndim].
+long rv_packed_weight_floats(int taps, int kdim, int ndim) {
+    int R = frag_R(kdim);
+    if (R == 0) return (long)taps * kdim * ndim;   // plain layout (small-channel kernels)
+    int nchunk = kdim / (4 * R), ntile_n = (ndim + 15) / 16;
+    return (long)taps * nchunk * ntile_n * 64 * R;
+}
+
+// Pack a PyTorch-layout weight into MFMA fragment order (or plain [tap][k][n] when the layer runs on
+// the small-channel VALU kernels: kdim not a multiple of 8, or ndim <= 2).
+//   value(tap,k,n) = w[k*s_k + n*s_n + (flip ? taps-1-tap : tap)]
+//   scatter_cmid>0 (2x2/s2 scatter GEMM): n = tap4*cmid + c, value = w[k*s_k + c*s_n + tap4], taps must be 1.
+int rv_pack_weights(const float* w, float* out, int taps, int kdim, int ndim, long s_k, long s_n, int flip,
+                    int scatter_cmid, int force_plain, void* stream) {
+    PackArgs a;
+    a.w = w; a.out = out; a.taps = taps; a.kdim = kdim; a.ndim = ndim;
+    a.s_k = s_k; a.s_n = s_n; a.flip = flip; a.scatter_cmid = scatter_cmid;
+    int R = force_plain ? 0 : frag_R(kdim);
+    hipStream_t st = (hipStream_t)stream;
+    if (R == 0) {
+        RV_CHECK_ARG(scatter_cmid == 0, "rv_pack_weights: plain layout has no scatter form");
+        a.R = 0; a.ntile_n = 0; a.nchunk = 0;
+        a.total = (long)taps * kdim * ndim;
+        hipLaunchKernelGGL(pack_plain_k, dim3(cdiv(a.total, 256)), dim3(256), 0, st, a);
+    } else {
+        a.R = R; a.nchunk = kdim / (4 * R); a.ntile_n = (ndim + 15) / 16;
+        a.total = (long)taps * a.nchunk * a.ntile_n * 64 * R;
+        hipLaunchKernelGGL(pack_frag_k, dim3(cdiv(a.total, 256)), dim3(256), 0, st, a);
+    }
+    RV_LAUNCH_CHECK("rv_pack_weights");
+    return RV_OK;
+}
+
+// mode: 0 = 3x3 s1 p1, 1 = 1x1, 2 = 2x2 s2 gather (down fwd / up dgrad), 3 = 2x2 s2 scatter (up fwd / down dgrad)
+// in  : [B,H,W,*] pixel stride in_ld, Cin channels read from the pointer
+// out : [B,Ho,Wo,*] pixel stride out_ld, Cout channels written
+int rv_conv_fwd(int mode, const float* in, int in_ld, int B, int H, int W, int Cin, float* out, int out_ld, int Ho,
+                int Wo, int Cout, const float* wpack, const float* bias, int accumulate, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    RV_CHECK_ARG(mode >= 0 && mode <= 3, "rv_conv_fwd: bad mode %d", mode);
+    if (mode == 0 || mode == 1) RV_CHECK_ARG(Ho == H && Wo == W, "rv_conv_fwd: same-size conv needs Ho==H, Wo==W");
+    if (mode == 2) RV_CHECK_ARG(Ho == H / 2 && Wo == W / 2, "rv_conv_fwd: down conv needs Ho=H/2, Wo=W/2");
+    if (mode == 3)
+        RV_CHECK_ARG(Ho >= 2 * H && Ho <= 2 * H + 1 && Wo >= 2 * W && Wo <= 2 * W + 1,
+                     "rv_conv_fwd: up conv needs 2H<=Ho<=2H+1 (got H=%d Ho=%d W=%d Wo=%d)", H, Ho, W, Wo);
+    const int R = frag_R(Cin);
+    const bool small = (R == 0) || (Cout <= 2 && mode != 3);
+    if (small) {
+        SmallArgs s;
+        s.in = in; s.in_ld = in_ld; s.H = H; s.W = W; s.out = out; s.out_ld = out_ld; s.Ho = Ho; s.Wo = Wo;
+        s.B = B; s.wplain = wpack; s.bias = bias; s.npix = (long)B * Ho * Wo; s.accumulate = accumulate;
+        dim3 grid(cdiv(s.npix, 256)), blk(256);
+#define RV_SMALL(ci, co, kh, kw, ss, pp)                                                          \
+    if (Cin == ci && Cout == co) {                                                               \
+        hipLaunchKernelGGL((conv_small_k<ci, co, kh, kw, ss, pp>), grid, blk, 0, st, s);         \
+        RV_LAUNCH_CHECK("conv_small");                                                           \
+        return RV_OK;                                                                            \
+    }
+        if (mode == 0) {
+            RV_SMALL(1, 16, 3, 3, 1, 1) RV_SMALL(16, 1, 3, 3, 1, 1)
+            RV_SMALL(8, 2, 3, 3, 1, 1)  RV_SMALL(2, 8, 3, 3, 1, 1)
+            RV_SMALL(8, 1, 3, 3, 1, 1)  RV_SMALL(1, 8, 3, 3, 1, 1)
+        } else if (mode == 1) {
+            RV_SMALL(1, 16, 1, 1, 1, 0) RV_SMALL(16, 1, 1, 1, 1, 0)
+        }
+#undef RV_SMALL
+        rv_set_error("rv_conv_fwd: no small-channel kernel for mode %d Cin=%d Cout=%d", mode, Cin, Cout);
+        return RV_EUNSUPPORTED;
+    }
+    ConvArgs a;
+    a.in = in; a.in_ld = in_ld; a.H = H; a.W = W; a.out = out; a.out_ld = out_ld; a.Ho = Ho; a.Wo = Wo;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.wpack = wpack; a.bias = bias;
+    a.nchunk = Cin / (4 * R);
+    a.accumulate = accumulate;
+    a.vec_store = ((out_ld & 3) == 0) && ((((uintptr_t)out) & 15) == 0);
+    RV_CHECK_ARG((in_ld % R) == 0 && ((((uintptr_t)in) & (4 * R - 1)) == 0), "rv_conv_fwd: input not %d-byte aligned", 4 * R);
+    if (mode == 3) {
+        RV_CHECK_ARG(Cout % 16 == 0, "rv_conv_fwd: scatter conv needs Cout %% 16 == 0");
+        a.ntile_n = 4 * Cout / 16;
+        a.Ph = H + (Ho - 2 * H); a.Pw = W + (Wo - 2 * W);
+    } else {
+        a.ntile_n = (Cout + 15) / 16;
+        a.Ph = Ho; a.Pw = Wo;
+    }
+    a.npix = (long)B * a.Ph * a.Pw;
+    int NT, MT;
+    choose_tiles((a.npix + 15) / 16, a.ntile_n, &NT, &MT);
+    int rc = RV_EUNSUPPORTED;
+    if (R == 4) {
+        if (mode == 0) rc = launch_conv_rt<3, 3, 1, 1, 4, false>(a, NT, MT, st);
+        else if (mode == 1) rc = launch_conv_rt<1, 1, 1, 0, 4, false>(a, NT, MT, st);
+        else if (mode == 2) rc = launch_conv_rt<2, 2, 2, 0, 4, false>(a, NT, MT, st);
+        else rc = launch_conv_rt<1, 1, 1, 0, 4, true>(a, NT, MT, st);
+    } else {
+        if (mode == 0) rc = launch_conv_rt<3, 3, 1, 1, 2, false>(a, NT, MT, st);
+        else if (mode == 1) rc = launch_conv_rt<1, 1, 1, 0, 2, false>(a, NT, MT, st);
+        else if (mode == 2) rc = launch_conv_rt<2, 2, 2, 0, 2, false>(a, NT, MT, st);
+        else rc = launch_conv_rt<1, 1, 1, 0, 2, true>(a, NT, MT, st);
+    }
+    if (rc != RV_OK) { rv_set_error("rv_conv_fwd: no kernel instance for NT=%d MT=%d", NT, MT); return rc; }
+    RV_LAUNCH_CHECK("rv_conv_fwd");
+    return RV_OK;
+}
+
+// Workspace (bytes) rv_conv_wgrad needs for the given problem.
+long rv_conv_wgrad_workspace_bytes(int taps, int B, int Hv, int Ca, int Cb) {
+    long nrows = (long)B * Hv;
+    long nparts = nrows < 1024 ? nrows : 1024;
+    return nparts * ((long)taps * Ca * Cb + Cb) * 4;
+}
+
+// G[tap][a][b] = sum_p U[f(p,tap)][a] * V[p][b], db[b] = sum_p V[p][b]; results scattered to
+//   dw[a*s_a + b*s_b + (flip ? taps-1-tap : tap)],  dbias[b]
+// mode: 0 = 3x3 s1 p1 (U = conv input, V = dY), 1 = 1x1, 2 = 2x2 s2 (U gathered at 2p+tap)
+int rv_conv_wgrad(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, const float* V, int v_ld, int Hv, int Wv,
+                  int Cb, int B, float* dw, long s_a, long s_b, int flip, float* dbias, int accumulate, void* workspace,
+                  long workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    RV_CHECK_ARG(mode >= 0 && mode <= 2, "rv_conv_wgrad: bad mode %d", mode);
+    const int taps = mode == 0 ? 9 : (mode == 1 ? 1 : 4);
+    WgradArgs a;
+    a.U = U; a.u_ld = u_ld; a.Hu = Hu; a.Wu = Wu; a.Ca = Ca; a.V = V; a.v_ld = v_ld; a.Hv = Hv; a.Wv = Wv; a.Cb = Cb;
+    a.B = B; a.want_bias = dbias != nullptr;
+    a.pstride = (long)taps * Ca * Cb + Cb;
+    const int nrows = B * Hv;
+    int nparts_max = nrows < 1024 ? nrows : 1024;
+    RV_CHECK_ARG(workspace_bytes >= nparts_max * a.pstride * 4, "rv_conv_wgrad: workspace too small");
+    a.part = (float*)workspace;
+    const bool small = (Ca * Cb * taps <= 144) && (Ca < 8 || Cb < 8);
+    if (small) {
+        a.nparts = nparts_max; a.rows_per_wave = 0; a.ngb = 1;
+        dim3 grid(cdiv(a.nparts, 4)), blk(256);
+#define RV_WS(ca, cb, kh, kw, ss, pp)                                                             \
+    if (Ca == ca && Cb == cb) {                                                                  \
+        hipLaunchKernelGGL((wgrad_small_k<ca, cb, kh, kw, ss, pp>), grid, blk, 0, st, a);        \
+        goto reduce;                                                                             \
+    }
+        if (mode == 0) { RV_WS(1, 16, 3, 3, 1, 1) RV_WS(8, 2, 3, 3, 1, 1) RV_WS(8, 1, 3, 3, 1, 1) }
+        else if (mode == 1) { RV_WS(1, 16, 1, 1, 1, 0) }
+#undef RV_WS
+        rv_set_error("rv_conv_wgrad: no small-channel kernel for mode %d Ca=%d Cb=%d", mode, Ca, Cb);
+        return RV_EUNSUPPORTED;
+    } else {
+        const int TA = Ca > 16 ? 2 : 1, TB = Cb > 16 ? 2 : 1;
+        const int nga = cdiv(Ca, TA * 16), ngb = cdiv(Cb, TB * 16);
+        // aim for ~2048 waves overall
+        int want = 2048 / (nga * ngb);
+        if (want < 8) want = 8;
+        if (want > nparts_max) want = nparts_max;
+        int rpw = cdiv(nrows, want);
+        if (rpw < 1) rpw = 1;
+        a.rows_per_wave = rpw;
+        a.nparts = cdiv(nrows, rpw);
+        RV_CHECK_ARG(a.nparts <= nparts_max, "rv_conv_wgrad: internal partition error");
+        a.ngb = ngb;
+        dim3 grid(cdiv(a.nparts, 4), nga * ngb), blk(256);
+#define RV_WG(kh, kw, ss, pp)                                                                     \
+    do {                                                                                         \
+        if (TA == 1 && TB == 1) hipLaunchKernelGGL((wgrad_mfma_k<kh, kw, ss, pp, 1, 1>), grid, blk, 0, st, a); \
+        else if (TA == 1 && TB == 2) hipLaunchKernelGGL((wgrad_mfma_k<kh, kw, ss, pp, 1, 2>), grid, blk, 0, st, a); \
+        else if (TA == 2 && TB == 1) hipLaunchKernelGGL((wgrad_mfma_k<kh, kw, ss, pp, 2, 1>), grid, blk, 0, st, a); \
+        else hipLaunchKernelGGL((wgrad_mfma_k<kh, kw, ss, pp, 2, 2>), grid, blk, 0, st, a);      \
+    } while (0)
+        if (mode == 0) RV_WG(3, 3, 1, 1);
+        else if (mode == 1) RV_WG(1, 1, 1, 0);
+        else RV_WG(2, 2, 2, 0);
+#undef RV_WG
+    }
+reduce:
+    RV_LAUNCH_CHECK("rv_conv_wgrad");
+    {
+        WreduceArgs r;
+        r.part = a.part; r.pstride = a.pstride; r.nparts = a.nparts; r.taps = taps; r.Ca = Ca; r.Cb = Cb;
+        r.dw = dw; r.s_a = s_a; r.s_b = s_b; r.flip = flip; r.dbias = dbias; r.accumulate = accumulate;
+        long nel = (long)taps * Ca * Cb + (dbias ? Cb : 0);
+        hipLaunchKernelGGL(wgrad_reduce_k, dim3(cdiv(nel, 128)), dim3(128), 0, st, r);
+        RV_LAUNCH_CHECK("rv_conv_wgrad(reduce)");
+    }
+    return RV_OK;
+}
+
+}  // extern "C"

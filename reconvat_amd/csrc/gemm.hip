@@ -1,0 +1,149 @@
+// Generic-stride fp32 GEMM on v_mfma_f32_16x16x4_f32 for the linear heads and the attention
+// projections (reference nn.Linear call sites: model/UNet_onset.py:50-52,62-64,275,292-293,324).
+//
+//   C[m][n] (+)= act( sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] + bias[n] )
+//
+// One kernel covers forward (X @ W^T), input-gradient (dY @ W) and weight-gradient (dY^T @ X, split
+// along the reduction dimension) through the strides.  64x64 block tile, BK = 16, four waves each
+// owning a 32x32 sub-tile.  The MFMA is issued as D^T = B^T A^T so that an accumulator lane holds four
+// consecutive n of one m (16-byte stores along the contiguous dimension of C).
+#include "common.h"
+
+#define GBM 64
+#define GBN 64
+#define GBK 16
+#define GPAD 4
+
+struct GemmArgs {
+    const float* A; long sam, sak;
+    const float* B; long sbk, sbn;
+    float* C; long scm, scn;
+    float* C2; long sc2m, sc2n;       // optional second destination (same values)
+    const float* bias;
+    int M, N, K;
+    int act;            // 0 none, 1 sigmoid
+    int accumulate;     // C += (plain read-modify-write; requires splitk == 1)
+    int splitk;         // >1: K split over blockIdx.z, atomicAdd epilogue (C pre-zeroed by the host wrapper)
+    int a_kfast, b_kfast;   // which global dimension is contiguous (load mapping only)
+};
+
+__global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a) {
+    __shared__ float As[GBK][GBM + GPAD];
+    __shared__ float Bs[GBK][GBN + GPAD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int kper = ((a.K + a.splitk - 1) / a.splitk + GBK - 1) / GBK * GBK;
+    const int k_begin = blockIdx.z * kper;
+    const int k_end = min(a.K, k_begin + kper);
+
+    f32x4 acc[2][2];   // [n-tile][m-tile]
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = k_begin; k0 < k_end; k0 += GBK) {
+        // stage A tile [GBK][GBM] and B tile [GBK][GBN]: 1024 elements each, 4 per thread
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int idx = e * 256 + tid;
+            int kk, mm;
+            if (a.a_kfast) { kk = idx & 15; mm = idx >> 4; } else { mm = idx & 63; kk = idx >> 6; }
+            int gm = m0 + mm, gk = k0 + kk;
+            As[kk][mm] = (gm < a.M && gk < k_end) ? a.A[(long)gm * a.sam + (long)gk * a.sak] : 0.f;
+            int kb, nn;
+            if (a.b_kfast) { kb = idx & 15; nn = idx >> 4; } else { nn = idx & 63; kb = idx >> 6; }
+            int gn = n0 + nn, gkb = k0 + kb;
+            Bs[kb][nn] = (gn < a.N && gkb < k_end) ? a.B[(long)gkb * a.sbk + (long)gn * a.sbn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < GBK; ks += 4) {
+            float af[2], bf[2];
+#pragma unroll
+            for (int y = 0; y < 2; ++y) af[y] = As[ks + g][wm + y * 16 + li];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) bf[x] = Bs[ks + g][wn + x * 16 + li];
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+                    // D[row = n_local][col = m_local] : A-operand = B tile (i = n), B-operand = A tile (j = m)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[x], af[y], acc[x][y], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const bool vec_ok = a.scn == 1 && (a.scm & 3) == 0 && ((((uintptr_t)a.C) & 15) == 0) && a.splitk == 1 && !a.C2;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int m = m0 + wm + y * 16 + li;
+            const int nb = n0 + wn + x * 16 + 4 * g;
+            if (m >= a.M || nb >= a.N) continue;
+            f32x4 v = acc[x][y];
+            if (a.splitk == 1 || blockIdx.z == 0) {
+                if (a.bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (nb + r < a.N) v[r] += a.bias[nb + r];
+                }
+            }
+            if (a.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = 1.f / (1.f + __expf(-v[r]));
+            }
+            float* c = a.C + (long)m * a.scm + (long)nb * a.scn;
+            if (vec_ok && nb + 3 < a.N) {
+                if (a.accumulate) { f32x4 o = *reinterpret_cast<f32x4*>(c); v += o; }
+                *reinterpret_cast<f32x4*>(c) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (nb + r >= a.N) continue;
+                    float* cc = c + (long)r * a.scn;
+                    if (a.splitk > 1) atomicAdd(cc, v[r]);
+                    else *cc = a.accumulate ? *cc + v[r] : v[r];
+                    if (a.C2) a.C2[(long)m * a.sc2m + (long)(nb + r) * a.sc2n] = v[r];
+                }
+            }
+        }
+}
+
+__global__ void zero_strided_k(float* c, long scm, long scn, int M, int N) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)M * N) return;
+    long m = i / N; int n = (int)(i - m * N);
+    c[m * scm + n * scn] = 0.f;
+}
+
+extern "C" {
+
+// C[m*scm + n*scn] (+)= act(sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] + bias[n]);  act: 0 none, 1 sigmoid.
+// splitk > 1 splits the reduction over extra workgroups (atomic fp32 accumulation into a zeroed C; act must be 0,
+// accumulate must be 0, C2 must be null).  C2 (nullable) receives a second copy with its own strides.
+int rv_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm, long scn, float* C2,
+            long sc2m, long sc2n, const float* bias, int M, int N, int K, int act, int accumulate, int splitk, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    RV_CHECK_ARG(M > 0 && N > 0 && K > 0, "rv_gemm: empty problem");
+    RV_CHECK_ARG(splitk >= 1, "rv_gemm: splitk must be >= 1");
+    if (splitk > 1) RV_CHECK_ARG(act == 0 && !accumulate && !C2, "rv_gemm: splitk excludes act/accumulate/C2");
+    GemmArgs a;
+    a.A = A; a.sam = sam; a.sak = sak; a.B = B; a.sbk = sbk; a.sbn = sbn; a.C = C; a.scm = scm; a.scn = scn;
+    a.C2 = C2; a.sc2m = sc2m; a.sc2n = sc2n; a.bias = bias; a.M = M; a.N = N; a.K = K; a.act = act;
+    a.accumulate = accumulate; a.splitk = splitk;
+    a.a_kfast = (sak <= sam); a.b_kfast = (sbk <= sbn);
+    if (splitk > 1) {
+        hipLaunchKernelGGL(zero_strided_k, dim3(cdiv((long)M * N, 256)), dim3(256), 0, st, C, scm, scn, M, N);
+        RV_LAUNCH_CHECK("rv_gemm(zero)");
+    }
+    dim3 grid(cdiv(N, GBN), cdiv(M, GBM), splitk);
+    hipLaunchKernelGGL(gemm_mfma_k, grid, dim3(256), 0, st, a);
+    RV_LAUNCH_CHECK("rv_gemm");
+    return RV_OK;
+}
+
+}  // extern "C"

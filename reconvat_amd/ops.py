@@ -1,0 +1,585 @@
+"""Host-side operators: thin ``torch.autograd.Function`` wrappers over the C ABI of
+libreconvat_hip.so.  PyTorch is used for device memory, streams and the autograd tape only; every
+numeric kernel is a hand-written HIP kernel (reconvat_amd/csrc).  There is no CPU fallback.
+
+Internal activation layout is NHWC ([B, H=time, W=bins, C]); a tensor handed to a conv may be a channel
+slice (view) of a wider buffer -- the pixel stride is taken from ``stride(2)``.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import call, ptr, stream, need_gpu
+
+SLOPE = 0.01            # F.leaky_relu default (model/UNet_onset.py:197-198)
+BN_MOMENTUM = 0.1       # model/UNet_onset.py:183
+BN_EPS = 1e-5
+
+_EPOCH = [0]
+
+
+def invalidate_weight_cache():
+    """Call after any out-of-band parameter update (custom optimiser step, load_state_dict)."""
+    _EPOCH[0] += 1
+
+
+# --------------------------------------------------------------------------------------------
+# geometry helpers
+# --------------------------------------------------------------------------------------------
+def _geom(t):
+    b, h, w, c = t.shape
+    ld = t.stride(2)
+    if t.stride(3) != 1 or t.stride(1) != w * ld or t.stride(0) != h * w * ld:
+        raise RuntimeError(f'expected an NHWC tensor or a channel slice of one, got shape {tuple(t.shape)} '
+                           f'strides {t.stride()}')
+    return b, h, w, c, ld
+
+
+def _new(b, h, w, c, like):
+    return torch.empty((b, h, w, c), device=like.device, dtype=torch.float32)
+
+
+# --------------------------------------------------------------------------------------------
+# convolution kinds: how forward / input-gradient / weight-gradient map onto the C ABI
+# --------------------------------------------------------------------------------------------
+#   kind   PyTorch module                         weight layout
+#   c3     Conv2d(k=3, p=1)                       [Cout, Cin, 3, 3]
+#   t3     ConvTranspose2d(k=3, p=1)              [Cin, Cout, 3, 3]
+#   c1     Conv2d(k=1)                            [Cout, Cin, 1, 1]
+#   down   Conv2d(k=2, s=2)                       [Cout, Cin, 2, 2]
+#   up     ConvTranspose2d(k=2, s=2, output_size) [Cin, Cout, 2, 2]
+def _channels(kind, w):
+    if kind in ('t3', 'up'):
+        return w.shape[0], w.shape[1]
+    return w.shape[1], w.shape[0]
+
+
+_pack_cache = {}
+
+
+def _pack(kind, w, which):
+    """Packed weight fragments for `which` in {'fwd', 'dgrad'} (cached per weight version)."""
+    key = (w.data_ptr(), kind, which)
+    tag = (_EPOCH[0], w._version, tuple(w.shape))
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    cin, cout = _channels(kind, w)
+    scatter = 0
+    if kind == 'c3':
+        args = (9, cin, cout, 9, cin * 9, 0) if which == 'fwd' else (9, cout, cin, cin * 9, 9, 1)
+    elif kind == 't3':
+        args = (9, cin, cout, cout * 9, 9, 1) if which == 'fwd' else (9, cout, cin, 9, cout * 9, 0)
+    elif kind == 'c1':
+        args = (1, cin, cout, 1, cin, 0) if which == 'fwd' else (1, cout, cin, cin, 1, 0)
+    elif kind == 'down':
+        if which == 'fwd':
+            args = (4, cin, cout, 4, cin * 4, 0)
+        else:
+            args, scatter = (1, cout, 4 * cin, cin * 4, 4, 0), cin
+    elif kind == 'up':
+        if which == 'fwd':
+            args, scatter = (1, cin, 4 * cout, cout * 4, 4, 0), cout
+        else:
+            args = (4, cout, cin, 4, cout * 4, 0)
+    else:
+        raise ValueError(kind)
+    taps, kdim, ndim, s_k, s_n, flip = args
+    plain = 1 if (kdim % 8 != 0 or (ndim <= 2 and not scatter)) else 0
+    lib = _lib.load()
+    n = lib.rv_packed_weight_floats(taps, kdim, ndim)
+    out = torch.empty(n, device=w.device, dtype=torch.float32)
+    call('rv_pack_weights', ptr(w), ptr(out), taps, kdim, ndim, s_k, s_n, flip, scatter, plain, stream())
+    _pack_cache[key] = (tag, out)
+    return out
+
+
+_FWD_MODE = {'c3': 0, 't3': 0, 'c1': 1, 'down': 2, 'up': 3}
+_DGRAD_MODE = {'c3': 0, 't3': 0, 'c1': 1, 'down': 3, 'up': 2}
+
+
+def conv_forward_into(kind, x, w, b, out):
+    """out (NHWC view) = conv(x) ; shapes are taken from the views."""
+    need_gpu(x, w, out)
+    bb, h, wd, cin, ild = _geom(x)
+    _, ho, wo, cout, old = _geom(out)
+    call('rv_conv_fwd', _FWD_MODE[kind], ptr(x), ild, bb, h, wd, cin, ptr(out), old, ho, wo, cout,
+         ptr(_pack(kind, w, 'fwd')), ptr(b), 0, stream())
+
+
+def conv_dgrad_into(kind, dy, w, dx):
+    """dx (NHWC view) = input gradient of the conv given dy (NHWC view)."""
+    bb, h, wd, c, ild = _geom(dy)
+    _, ho, wo, co, old = _geom(dx)
+    call('rv_conv_fwd', _DGRAD_MODE[kind], ptr(dy), ild, bb, h, wd, c, ptr(dx), old, ho, wo, co,
+         ptr(_pack(kind, w, 'dgrad')), None, 0, stream())
+
+
+def conv_wgrad(kind, x, dy, w, want_bias=True):
+    """(dw, db) in the PyTorch layouts of `w` / bias."""
+    bb, h, wd, cin, xld = _geom(x)
+    _, ho, wo, cout, yld = _geom(dy)
+    dw = torch.empty_like(w)
+    db = torch.empty(cout, device=w.device, dtype=torch.float32) if want_bias else None
+    lib = _lib.load()
+    if kind == 'up':
+        # G[tap][a=co][b=ci] = sum_p dY[2p+tap][co] * X[p][ci]  -> dWt[ci][co][tap]
+        taps, mode = 4, 2
+        u, uld, hu, wu, ca = dy, yld, ho, wo, cout
+        v, vld, hv, wv, cb = x, xld, h, wd, cin
+        s_a, s_b, flip = 4, cout * 4, 0
+        bias_ptr = None
+    else:
+        mode = {'c3': 0, 't3': 0, 'c1': 1, 'down': 2}[kind]
+        taps = {'c3': 9, 't3': 9, 'c1': 1, 'down': 4}[kind]
+        u, uld, hu, wu, ca = x, xld, h, wd, cin
+        v, vld, hv, wv, cb = dy, yld, ho, wo, cout
+        if kind == 't3':
+            s_a, s_b, flip = cout * 9, 9, 1
+        else:
+            s_a, s_b, flip = taps, cin * taps, 0
+        bias_ptr = ptr(db)
+    nbytes = lib.rv_conv_wgrad_workspace_bytes(taps, bb, hv, ca, cb)
+    ws = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+    call('rv_conv_wgrad', mode, ptr(u), uld, hu, wu, ca, ptr(v), vld, hv, wv, cb, bb, ptr(dw), s_a, s_b, flip,
+         bias_ptr, 0, ptr(ws), nbytes, stream())
+    if kind == 'up' and want_bias:
+        call('rv_colsum', ptr(dy), yld, bb * ho * wo, cout, ptr(db), 0, stream())
+    return dw, db
+
+
+def _out_hw(kind, h, w, size):
+    if kind == 'down':
+        return h // 2, w // 2
+    if kind == 'up':
+        return (2 * h, 2 * w) if size is None else (int(size[0]), int(size[1]))
+    return h, w
+
+
+class ConvFn(Function):
+    """y = conv(x) for any of the five conv kinds (new contiguous NHWC tensor)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, kind, size):
+        bb, h, wd, cin, _ = _geom(x)
+        _, cout = _channels(kind, w)
+        ho, wo = _out_hw(kind, h, wd, size)
+        y = _new(bb, ho, wo, cout, x)
+        conv_forward_into(kind, x, w, b, y)
+        ctx.kind = kind
+        ctx.xshape = tuple(x.shape)
+        ctx.save_for_backward(x if ctx.needs_input_grad[1] else None, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(ctx.xshape, device=dy.device, dtype=torch.float32)
+            conv_dgrad_into(ctx.kind, dy, w, dx)
+        if ctx.needs_input_grad[1]:
+            dw, db = conv_wgrad(ctx.kind, x, dy, w, ctx.needs_input_grad[2])
+        return dx, dw, db, None, None
+
+
+class UpCatFn(Function):
+    """cat = concat(up(x, output_size), conv3x3(skip_src)) along channels, written in place into one NHWC
+    buffer (d_block.forward's `self.us(x, output_size=size)` + `torch.cat((x, skip), 1)`,
+    model/UNet_onset.py:219-220, with the encoder's extra skip conv, :244-246, computed here)."""
+
+    @staticmethod
+    def forward(ctx, x, w_up, b_up, s, w_skip, b_skip, size):
+        bb, h, wd, cin, _ = _geom(x)
+        cu = w_up.shape[1]
+        cs = w_skip.shape[0]
+        ho, wo = int(size[0]), int(size[1])
+        cat = _new(bb, ho, wo, cu + cs, x)
+        conv_forward_into('up', x, w_up, b_up, cat[..., :cu])
+        conv_forward_into('c3', s, w_skip, b_skip, cat[..., cu:])
+        ctx.cu = cu
+        ctx.shapes = (tuple(x.shape), tuple(s.shape))
+        need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[4]
+        ctx.save_for_backward(x if need_w else None, s if need_w else None, w_up, w_skip)
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        x, s, w_up, w_skip = ctx.saved_tensors
+        dcat = dcat.contiguous()
+        cu = ctx.cu
+        d_up, d_sk = dcat[..., :cu], dcat[..., cu:]
+        dx = ds = dwu = dbu = dws = dbs = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(ctx.shapes[0], device=dcat.device, dtype=torch.float32)
+            conv_dgrad_into('up', d_up, w_up, dx)
+        if ctx.needs_input_grad[3]:
+            ds = torch.empty(ctx.shapes[1], device=dcat.device, dtype=torch.float32)
+            conv_dgrad_into('c3', d_sk, w_skip, ds)
+        if ctx.needs_input_grad[1]:
+            dwu, dbu = conv_wgrad('up', x, d_up, w_up, True)
+        if ctx.needs_input_grad[4]:
+            dws, dbs = conv_wgrad('c3', s, d_sk, w_skip, True)
+        return dx, dwu, dbu, ds, dws, dbs, None
+
+
+# --------------------------------------------------------------------------------------------
+# BatchNorm (train / eval) + leaky ReLU (+ residual)
+# --------------------------------------------------------------------------------------------
+class BnActFn(Function):
+    """y = leaky_relu(batch_norm(z)) (+ res).  Training mode updates running_mean / running_var /
+    num_batches_tracked in place exactly like nn.BatchNorm2d(momentum=0.1)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, nbt, res, training, slope):
+        need_gpu(z, gamma)
+        bb, h, wd, c, zld = _geom(z)
+        p = bb * h * wd
+        y = torch.empty_like(z, memory_format=torch.contiguous_format)
+        coef = torch.empty(4 * c, device=z.device, dtype=torch.float32)
+        ws = torch.empty(2 * c, device=z.device, dtype=torch.float64)
+        rld = _geom(res)[4] if res is not None else 0
+        call('rv_bn_lrelu_fwd', ptr(z), zld, p, c, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(nbt),
+             BN_MOMENTUM, BN_EPS, 1 if training else 0, slope, ptr(res), rld, ptr(y), c, ptr(coef), ptr(ws), stream())
+        ctx.training = training
+        ctx.slope = slope
+        ctx.save_for_backward(z, coef)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, coef = ctx.saved_tensors
+        dy = dy.contiguous()
+        bb, h, wd, c, zld = _geom(z)
+        p = bb * h * wd
+        need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dz = torch.empty_like(z, memory_format=torch.contiguous_format)
+        dg = torch.empty(c, device=z.device, dtype=torch.float32) if need_w else None
+        db = torch.empty(c, device=z.device, dtype=torch.float32) if need_w else None
+        ws = torch.empty(2 * c, device=z.device, dtype=torch.float64)
+        call('rv_bn_lrelu_bwd', ptr(dy), c, ptr(z), zld, p, c, ptr(coef), ctx.slope, 0 if ctx.training else 1,
+             ptr(dz), c, ptr(dg), ptr(db), ptr(ws), stream())
+        dres = dy if ctx.needs_input_grad[6] else None
+        return (dz if ctx.needs_input_grad[0] else None), dg, db, None, None, None, dres, None, None
+
+
+# --------------------------------------------------------------------------------------------
+# linear layers
+# --------------------------------------------------------------------------------------------
+def _mat(t):
+    """(ptr, rows, cols, row stride, col stride) of a 2-D view."""
+    assert t.dim() == 2
+    return ptr(t), t.shape[0], t.shape[1], t.stride(0), t.stride(1)
+
+
+def gemm(a, b_kn, c, bias=None, act=0, accumulate=False, splitk=1, c2=None):
+    """c[m,n] (+)= act(sum_k a[m,k] * b_kn[k,n] + bias[n]) on arbitrary 2-D views."""
+    need_gpu(a, b_kn, c)
+    pa, m, k, sam, sak = _mat(a)
+    pb, k2, n, sbk, sbn = _mat(b_kn)
+    pc, m2, n2, scm, scn = _mat(c)
+    assert k == k2 and m == m2 and n == n2, (a.shape, b_kn.shape, c.shape)
+    if c2 is not None:
+        pc2, _, _, s2m, s2n = _mat(c2)
+    else:
+        pc2, s2m, s2n = None, 0, 0
+    call('rv_gemm', pa, sam, sak, pb, sbk, sbn, pc, scm, scn, pc2, s2m, s2n, ptr(bias), m, n, k, act,
+         1 if accumulate else 0, splitk, stream())
+
+
+def colsum(x2d):
+    out = torch.empty(x2d.shape[1], device=x2d.device, dtype=torch.float32)
+    assert x2d.stride(1) == 1
+    call('rv_colsum', ptr(x2d), x2d.stride(0), x2d.shape[0], x2d.shape[1], ptr(out), 0, stream())
+    return out
+
+
+def _splitk_for(m_out, n_out, k):
+    blocks = ((m_out + 63) // 64) * ((n_out + 63) // 64)
+    if blocks >= 256 or k < 512:
+        return 1
+    return max(1, min(32, 512 // blocks, k // 128))
+
+
+class LinearFn(Function):
+    """y = act(x @ w.T + b) for a 2-D (possibly strided) x; act in {0: none, 1: sigmoid}."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        m, k = x.shape
+        n = w.shape[0]
+        y = torch.empty((m, n), device=x.device, dtype=torch.float32)
+        gemm(x, w.t(), y, b, act)
+        ctx.act = act
+        ctx.save_for_backward(x, w, y if act == 1 else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        m, k = x.shape
+        n = w.shape[0]
+        if ctx.act == 1:
+            dz = torch.empty_like(dy)
+            call('rv_sigmoid_bwd', ptr(dy), n, None, 0, ptr(y), n, ptr(dz), n, m, n, stream())
+        else:
+            dz = dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((m, k), device=dy.device, dtype=torch.float32)
+            gemm(dz, w, dx)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            gemm(dz.t(), x, dw, splitk=_splitk_for(n, k, m))
+        if b is not None and ctx.needs_input_grad[2]:
+            db = colsum(dz)
+        return dx, dw, db, None
+
+
+class OnsetHeadsFn(Function):
+    """Spec2Roll's two heads + concat (model/UNet_onset.py:307-312):
+         onset = sigmoid(linear_onset(y[..., 0])); feat = linear_feature(y[..., 1]); cat = [onset | feat]
+       y: decoder output NHWC [B, T, 229, 2].  Returns (cat [B*T, 176], onset [B*T, 88])."""
+
+    @staticmethod
+    def forward(ctx, y, wo, bo, wf, bf):
+        bb, t, nb, c = y.shape
+        assert c == 2 and y.is_contiguous()
+        m = bb * t
+        y2 = y.view(m, nb, 2)
+        cat = torch.empty((m, 176), device=y.device, dtype=torch.float32)
+        onset = torch.empty((m, 88), device=y.device, dtype=torch.float32)
+        gemm(y2[..., 0], wo.t(), cat[:, :88], bo, act=1, c2=onset)
+        gemm(y2[..., 1], wf.t(), cat[:, 88:], bf, act=0)
+        ctx.save_for_backward(y, wo, wf, onset)
+        return cat, onset
+
+    @staticmethod
+    def backward(ctx, dcat, donset):
+        y, wo, wf, onset = ctx.saved_tensors
+        bb, t, nb, _ = y.shape
+        m = bb * t
+        y2 = y.view(m, nb, 2)
+        dcat = dcat.contiguous()
+        dzo = torch.empty((m, 88), device=y.device, dtype=torch.float32)
+        call('rv_sigmoid_bwd', ptr(dcat), 176, ptr(donset.contiguous()) if donset is not None else None, 88,
+             ptr(onset), 88, ptr(dzo), 88, m, 88, stream())
+        dzf = dcat[:, 88:]
+        dy = dwo = dbo = dwf = dbf = None
+        if ctx.needs_input_grad[0]:
+            dy = torch.empty_like(y)
+            d2 = dy.view(m, nb, 2)
+            gemm(dzo, wo, d2[..., 0])
+            gemm(dzf, wf, d2[..., 1])
+        if ctx.needs_input_grad[1]:
+            dwo = torch.empty_like(wo)
+            gemm(dzo.t(), y2[..., 0], dwo, splitk=_splitk_for(88, nb, m))
+            dbo = colsum(dzo)
+        if ctx.needs_input_grad[3]:
+            dwf = torch.empty_like(wf)
+            gemm(dzf.t(), y2[..., 1], dwf, splitk=_splitk_for(88, nb, m))
+            dbf = torch.empty(88, device=y.device, dtype=torch.float32)
+            call('rv_colsum', ptr(dzf), 176, m, 88, ptr(dbf), 0, stream())
+        return dy, dwo, dbo, dwf, dbf
+
+
+# --------------------------------------------------------------------------------------------
+# local attention
+# --------------------------------------------------------------------------------------------
+class LocalAttnFn(Function):
+    """MutliHeadAttention1D.forward (model/UNet_onset.py:56-91) on x [B, L, Fin] (contiguous):
+       returns (out [B, L, F], attention [B, L, G, 31])."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, rel, groups):
+        need_gpu(x, wq)
+        bb, l, fin = x.shape
+        f = wq.shape[0]
+        x2 = x.reshape(bb * l, fin)
+        q = torch.empty((bb * l, f), device=x.device, dtype=torch.float32)
+        k = torch.empty_like(q)
+        v = torch.empty_like(q)
+        gemm(x2, wq.t(), q)
+        gemm(x2, wk.t(), k)
+        gemm(x2, wv.t(), v)
+        out = torch.empty((bb, l, f), device=x.device, dtype=torch.float32)
+        att = torch.empty((bb, l, groups, 31), device=x.device, dtype=torch.float32)
+        relc = rel.reshape(f, 31)
+        call('rv_local_attn_fwd', ptr(q), ptr(k), ptr(v), ptr(relc), ptr(out), ptr(att), bb, l, groups, f // groups,
+             stream())
+        ctx.groups = groups
+        ctx.save_for_backward(x2, wq, wk, wv, rel, q, k, v, att)
+        ctx.mark_non_differentiable(att)
+        return out, att
+
+    @staticmethod
+    def backward(ctx, dout, _datt):
+        x2, wq, wk, wv, rel, q, k, v, att = ctx.saved_tensors
+        g = ctx.groups
+        bb, l = att.shape[0], att.shape[1]
+        f = wq.shape[0]
+        dh = f // g
+        dout = dout.contiguous()
+        dq = torch.empty_like(q)
+        dk = torch.empty_like(q)
+        dv = torch.empty_like(q)
+        de = torch.empty_like(att)
+        relc = rel.reshape(f, 31)
+        call('rv_local_attn_bwd', ptr(dout), ptr(q), ptr(k), ptr(v), ptr(relc), ptr(att), ptr(dq), ptr(dk), ptr(dv),
+             ptr(de), bb, l, g, dh, stream())
+        dx = dwq = dwk = dwv = drel = None
+        m = bb * l
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x2)
+            gemm(dq, wq, dx)
+            gemm(dk, wk, dx, accumulate=True)
+            gemm(dv, wv, dx, accumulate=True)
+            dx = dx.view(bb, l, -1)
+        if ctx.needs_input_grad[1]:
+            sk = _splitk_for(f, x2.shape[1], m)
+            dwq, dwk, dwv = torch.empty_like(wq), torch.empty_like(wk), torch.empty_like(wv)
+            gemm(dq.t(), x2, dwq, splitk=sk)
+            gemm(dk.t(), x2, dwk, splitk=sk)
+            gemm(dv.t(), x2, dwv, splitk=sk)
+        if ctx.needs_input_grad[4]:
+            # drel[g*dh+f, w] = sum_{b,t} q[b,t,g,f] * de[b,t,g,w]
+            drel = torch.empty((f, 31), device=q.device, dtype=torch.float32)
+            de2 = de.view(m, g, 31)
+            for h in range(g):
+                gemm(q[:, h * dh:(h + 1) * dh].t(), de2[:, h, :], drel[h * dh:(h + 1) * dh], splitk=16)
+            drel = drel.view_as(rel)
+        return dx, dwq, dwk, dwv, drel, None
+
+
+# --------------------------------------------------------------------------------------------
+# losses and VAT primitives
+# --------------------------------------------------------------------------------------------
+def _reduce(kind, p, t):
+    need_gpu(p, t)
+    n = p.numel()
+    out = torch.empty((), device=p.device, dtype=torch.float32)
+    ws = torch.empty((n + 2047) // 2048, device=p.device, dtype=torch.float32)
+    call('rv_reduce_mean', kind, ptr(p), ptr(t), n, ptr(out), ptr(ws), stream())
+    return out
+
+
+class _MeanLoss(Function):
+    kind = 0
+
+    @classmethod
+    def _fwd(cls, ctx, p, t):
+        p = p.contiguous()
+        t = t.contiguous()
+        if p.shape != t.shape:
+            raise ValueError(f'target size {tuple(t.shape)} must match input size {tuple(p.shape)}')
+        ctx.save_for_backward(p, t)
+        return _reduce(cls.kind, p, t)
+
+    @classmethod
+    def _bwd(cls, ctx, gout):
+        p, t = ctx.saved_tensors
+        gp = torch.empty_like(p)
+        call('rv_loss_bwd', cls.kind, ptr(p), ptr(t), p.numel(), ptr(gout.contiguous()), ptr(gp), stream())
+        return gp, None
+
+
+class BceMeanFn(_MeanLoss):
+    """F.binary_cross_entropy(p, t) (mean; soft targets allowed; log clamped at -100)."""
+    kind = 0
+
+    @staticmethod
+    def forward(ctx, p, t):
+        return BceMeanFn._fwd(ctx, p, t)
+
+    @staticmethod
+    def backward(ctx, gout):
+        return BceMeanFn._bwd(ctx, gout)
+
+
+class MseMeanFn(_MeanLoss):
+    """F.mse_loss(p, t) (mean)."""
+    kind = 1
+
+    @staticmethod
+    def forward(ctx, p, t):
+        return MseMeanFn._fwd(ctx, p, t)
+
+    @staticmethod
+    def backward(ctx, gout):
+        return MseMeanFn._bwd(ctx, gout)
+
+
+def bce_mean(p, t):
+    return BceMeanFn.apply(p, t.detach())
+
+
+def mse_mean(p, t):
+    return MseMeanFn.apply(p, t.detach())
+
+
+def abs_mean(x):
+    return _reduce(2, x.detach().contiguous(), None)
+
+
+def l2_norm(x):
+    return _reduce(3, x.detach().contiguous(), None)
+
+
+class VatPerturbFn(Function):
+    """x_adv = clamp(x + scale * d / ||d||_2(last dim), 0, 1) with the gradient wrt d
+    (model/UNet_onset.py:130-131 through _l2_normalize :165-171)."""
+
+    @staticmethod
+    def forward(ctx, x, d, scale):
+        x = x.contiguous()
+        d = d.contiguous()
+        n = x.shape[-1]
+        rows = x.numel() // n
+        x_adv = torch.empty_like(x)
+        call('rv_vat_perturb_fwd', ptr(x), ptr(d), rows, n, 1.0, scale, ptr(x_adv), None, None, None, stream())
+        ctx.scale = scale
+        ctx.save_for_backward(x, d)
+        return x_adv
+
+    @staticmethod
+    def backward(ctx, g):
+        x, d = ctx.saved_tensors
+        n = x.shape[-1]
+        gd = torch.empty_like(d)
+        call('rv_vat_perturb_bwd', ptr(g.contiguous()), ptr(x), ptr(d), x.numel() // n, n, 1.0, ctx.scale, ptr(gd),
+             stream())
+        return None, gd, None
+
+
+def vat_adversarial(x, g, prescale, eps, nan_flag=None):
+    """d = g*prescale; r_adv = eps*d/||d||; x_adv = clamp(x + r_adv, 0, 1); also returns d/||d||
+    (model/UNet_onset.py:141-151,162).  No autograd."""
+    x = x.contiguous()
+    g = g.contiguous()
+    n = x.shape[-1]
+    x_adv, r_adv, dn = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    call('rv_vat_perturb_fwd', ptr(x), ptr(g), x.numel() // n, n, prescale, eps, ptr(x_adv), ptr(r_adv), ptr(dn),
+         ptr(nan_flag), stream())
+    return x_adv, r_adv, dn
+
+
+# --------------------------------------------------------------------------------------------
+# front-end
+# --------------------------------------------------------------------------------------------
+def melspec(audio, tables, do_log, normalise, hop=512):
+    """audio [B, nsamp] -> [B, T, n_mels] (time-major) log-mel / mel power; see rv_melspec_lognorm_fwd."""
+    need_gpu(audio)
+    audio = audio.float()
+    if audio.stride(-1) != 1:
+        audio = audio.contiguous()
+    bb, nsamp = audio.shape
+    t = 1 + nsamp // hop
+    n_mels = tables['mel_start'].numel()
+    out = torch.empty((bb, t, n_mels), device=audio.device, dtype=torch.float32)
+    ws = torch.empty(2 * bb, device=audio.device, dtype=torch.int32)
+    call('rv_melspec_lognorm_fwd', ptr(audio), audio.stride(0), bb, nsamp, ptr(tables['window']), ptr(tables['twiddle']),
+         ptr(tables['mel_start']), ptr(tables['mel_len']), ptr(tables['mel_w']), tables['mel_w'].shape[1], n_mels, hop,
+         1 if do_log else 0, 1 if normalise else 0, ptr(out), t, ptr(ws), stream())
+    return out

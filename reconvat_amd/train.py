@@ -1,0 +1,204 @@
+"""Training harness for the hot path.
+
+``train_VAT_model`` keeps the reference's signature and loop semantics
+(model/helper_functions.py:570-615).  ``FlatAdam`` is torch.optim.Adam + StepLR fused into one HIP kernel
+over flat parameter / gradient buffers (the same flat gradient buffer is what gets all-reduced over RCCL
+in data-parallel runs).  ``TrainStep`` runs one optimiser step -- optionally captured ONCE into a
+hipGraph and replayed, which removes the ~1.5-2 k kernel launches per step from the host critical path.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+from ._lib import call, ptr, stream
+
+
+def cycle(iterable):
+    while True:
+        for item in iterable:
+            yield item
+
+
+def weighted_loss(losses, alpha):
+    """model/helper_functions.py:589-595: every 'loss/train_LDS*' key weighs alpha/2, all others 1."""
+    loss = 0
+    for key in losses.keys():
+        if key.startswith('loss/train_LDS'):
+            loss = loss + alpha * losses[key] / 2
+        else:
+            loss = loss + losses[key]
+    return loss
+
+
+def train_VAT_model(model, iteration, ep, l_loader, ul_loader, optimizer, scheduler, clip_gradient_norm, alpha,
+                    VAT=False, VAT_start=0):
+    """Drop-in for model/helper_functions.py:570-615 (same arguments, same return value).  Works with any
+    torch optimiser/scheduler pair, or with ``FlatAdam`` (pass ``scheduler=None``: StepLR is built in)."""
+    model.train()
+    batch_size = l_loader.batch_size
+    total_loss = 0
+    l_loader = cycle(l_loader)
+    if ul_loader:
+        ul_loader = cycle(ul_loader)
+    for i in range(iteration):
+        optimizer.zero_grad()
+        batch_l = next(l_loader)
+        if (ep < VAT_start) or (VAT is False):
+            predictions, losses, _ = model.run_on_batch(batch_l, None, False)
+        else:
+            batch_ul = next(ul_loader)
+            predictions, losses, _ = model.run_on_batch(batch_l, batch_ul, VAT)
+        loss = weighted_loss(losses, alpha)
+        loss.backward()
+        total_loss += loss.item()
+        optimizer.step()
+        if scheduler is not None:
+            scheduler.step()
+        if clip_gradient_norm:
+            # the reference clips AFTER the step (no effect on the update); kept for .grad parity
+            if isinstance(optimizer, FlatAdam):
+                optimizer.clip_grad_norm_(clip_gradient_norm)
+            else:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), clip_gradient_norm)
+        print(f'Train Epoch: {ep} [{i * batch_size}/{iteration * batch_size}'
+              f'({100. * i / iteration:.0f}%)]'
+              f"\tMain Loss: {sum(losses.values()):.6f}\t", end='\r')
+    print(' ' * 100, end='\r')
+    print(f'Train Epoch: {ep}\tLoss: {total_loss / iteration:.6f}')
+    return predictions, losses, optimizer
+
+
+class FlatAdam:
+    """Adam(lr, betas=(0.9,0.999), eps=1e-8) + StepLR(step_size, gamma) on ONE flat fp32 buffer.
+
+    Parameters are re-pointed to views of ``flat_param`` and their ``.grad`` to views of ``flat_grad``,
+    so autograd accumulates straight into the bucket that data-parallel training all-reduces.
+    Parameters that never receive a gradient keep a zero gradient and zero moments -> they do not move,
+    which is what torch.optim.Adam does by skipping them (6 such tensors in UNet_Onset)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, step_size=1000, gamma=0.98):
+        self.params = [p for p in params if p.requires_grad]
+        assert self.params, 'no trainable parameters'
+        dev = self.params[0].device
+        if dev.type != 'cuda':
+            raise RuntimeError('FlatAdam runs on a HIP device only (no CPU fallback)')
+        n = sum(p.numel() for p in self.params)
+        self.flat_param = torch.empty(n, device=dev, dtype=torch.float32)
+        self.flat_grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.step_count = torch.zeros((), device=dev, dtype=torch.int64)
+        self.norm_buf = torch.zeros((), device=dev, dtype=torch.float32)
+        off = 0
+        self.offsets = []
+        for p in self.params:
+            k = p.numel()
+            self.flat_param[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat_param[off:off + k].view_as(p.data)
+            p.grad = self.flat_grad[off:off + k].view_as(p.data)
+            self.offsets.append(off)
+            off += k
+        self.n = n
+        self.lr, self.betas, self.eps, self.step_size, self.gamma = lr, betas, eps, step_size, gamma
+        self.grad_scale = 1.0
+        ops.invalidate_weight_cache()
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_grad.zero_()
+        for p, off in zip(self.params, self.offsets):      # re-attach if something replaced .grad
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
+                p.grad = self.flat_grad[off:off + p.numel()].view_as(p.data)
+
+    def step(self):
+        call('rv_adam_step', ptr(self.flat_param), ptr(self.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n,
+             ptr(self.step_count), self.lr, self.step_size, self.gamma, self.betas[0], self.betas[1], self.eps,
+             self.grad_scale, stream())
+        call('rv_counter_add', ptr(self.step_count), 1, stream())
+        ops.invalidate_weight_cache()
+
+    def clip_grad_norm_(self, max_norm):
+        ws = torch.empty((self.n + 2047) // 2048, device=self.flat_grad.device, dtype=torch.float32)
+        call('rv_reduce_mean', 3, ptr(self.flat_grad), None, self.n, ptr(self.norm_buf), ptr(ws), stream())
+        call('rv_clip_scale', ptr(self.flat_grad), self.n, ptr(self.norm_buf), float(max_norm), stream())
+        return self.norm_buf
+
+    def current_lr(self):
+        return self.lr * self.gamma ** (int(self.step_count.item()) // self.step_size)
+
+    def state_dict(self):
+        return {'step': self.step_count.clone(), 'exp_avg': self.exp_avg.clone(), 'exp_avg_sq': self.exp_avg_sq.clone(),
+                'lr': self.lr, 'betas': self.betas, 'eps': self.eps, 'step_size': self.step_size, 'gamma': self.gamma}
+
+    def load_state_dict(self, sd):
+        self.step_count.copy_(sd['step'])
+        self.exp_avg.copy_(sd['exp_avg'])
+        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+
+
+def allreduce_gradients(opt):
+    """ONE RCCL all-reduce (sum) of the flat gradient bucket per optimiser step, after the final backward
+    and never inside the VAT power iteration; the 1/world_size mean is folded into the Adam kernel."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(opt.flat_grad, op=dist.ReduceOp.SUM)
+        opt.grad_scale = 1.0 / dist.get_world_size()
+
+
+class TrainStep:
+    """One optimiser step of the reference loop body (zero_grad, run_on_batch, weighted sum, backward,
+    [all-reduce], Adam+StepLR) on static device buffers.  With ``graph=True`` the forward+backward is
+    captured once into a hipGraph and replayed; the all-reduce and the optimiser kernel stay outside the
+    graph so that the collective is an ordinary RCCL call."""
+
+    def __init__(self, model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=True):
+        self.model, self.opt, self.alpha, self.VAT, self.clip = model, opt, alpha, VAT, clip
+        self.batch = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
+        self.batch_ul = {k: v.clone() for k, v in batch_ul.items() if torch.is_tensor(v)} if batch_ul else None
+        self.graph = None
+        self.losses = None
+        self.loss = None
+        self.use_graph = graph
+
+    def _fwd_bwd(self):
+        self.opt.zero_grad()
+        _, losses, _ = self.model.run_on_batch(self.batch, self.batch_ul, self.VAT)
+        loss = weighted_loss(losses, self.alpha)
+        loss.backward()
+        self.losses = {k: v.detach() for k, v in losses.items()}
+        self.loss = loss.detach()
+
+    def load(self, batch, batch_ul=None):
+        for k, v in self.batch.items():
+            v.copy_(batch[k], non_blocking=True)
+        if self.batch_ul is not None and batch_ul is not None:
+            for k, v in self.batch_ul.items():
+                v.copy_(batch_ul[k], non_blocking=True)
+
+    def capture(self, warmup=2):
+        self.model.train()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                ops.invalidate_weight_cache()
+                self._fwd_bwd()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        ops.invalidate_weight_cache()          # the weight packing kernels must be part of the graph
+        with torch.cuda.graph(self.graph):
+            self._fwd_bwd()
+        ops.invalidate_weight_cache()
+
+    def __call__(self):
+        if self.use_graph:
+            if self.graph is None:
+                self.capture()
+            self.graph.replay()
+        else:
+            self.model.train()
+            self._fwd_bwd()
+        allreduce_gradients(self.opt)
+        self.opt.step()
+        if self.clip:
+            self.opt.clip_grad_norm_(self.clip)
+        return self.loss

@@ -1,0 +1,332 @@
+"""GPU parity of every HIP operator against a plain PyTorch fp32 CPU reference of the same op.
+Tolerances are relative to the reference tensor's max magnitude (fp32 accumulation-order noise)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+TOL_G = 1e-4
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+CONV_CASES = [
+    # kind, cin, cout, H, W
+    ('c3', 1, 16, 9, 21), ('c3', 16, 16, 9, 21), ('c3', 16, 32, 8, 14), ('c3', 32, 32, 8, 14),
+    ('c3', 32, 64, 6, 7), ('c3', 64, 64, 6, 7), ('c3', 64, 128, 5, 6), ('c3', 128, 128, 5, 6),
+    ('t3', 192, 96, 5, 6), ('t3', 96, 64, 5, 6), ('t3', 96, 48, 6, 9), ('t3', 48, 32, 6, 9),
+    ('t3', 48, 24, 8, 13), ('t3', 24, 16, 8, 13), ('t3', 16, 8, 9, 21), ('t3', 8, 2, 9, 21), ('t3', 8, 1, 9, 21),
+    ('c1', 1, 16, 9, 21), ('c1', 16, 32, 8, 14), ('c1', 32, 64, 6, 7), ('c1', 64, 128, 5, 6),
+    ('down', 16, 16, 9, 21), ('down', 32, 32, 8, 14), ('down', 64, 64, 6, 7), ('down', 128, 128, 4, 6),
+    ('up', 128, 128, 3, 4), ('up', 64, 64, 4, 6), ('up', 32, 32, 5, 7), ('up', 16, 16, 6, 9),
+]
+
+
+def torch_conv(kind, x, w, b, size=None):
+    if kind == 'c3':
+        return F.conv2d(x, w, b, padding=1)
+    if kind == 't3':
+        return F.conv_transpose2d(x, w, b, padding=1)
+    if kind == 'c1':
+        return F.conv2d(x, w, b)
+    if kind == 'down':
+        return F.conv2d(x, w, b, stride=2)
+    op = (size[0] - 2 * x.shape[2], size[1] - 2 * x.shape[3])
+    return F.conv_transpose2d(x, w, b, stride=2, output_padding=op)
+
+
+@pytest.mark.parametrize('kind,cin,cout,H,W', CONV_CASES)
+def test_conv_fwd_bwd(dev, kind, cin, cout, H, W):
+    from reconvat_amd import ops
+    B = 2
+    wshape = {'c3': (cout, cin, 3, 3), 't3': (cin, cout, 3, 3), 'c1': (cout, cin, 1, 1), 'down': (cout, cin, 2, 2),
+              'up': (cin, cout, 2, 2)}[kind]
+    x = rnd(B, cin, H, W, seed=1)
+    w = rnd(*wshape, seed=2, scale=0.3)
+    b = rnd(cout, seed=3)
+    sizes = [None]
+    if kind == 'up':
+        sizes = [(2 * H, 2 * W), (2 * H, 2 * W + 1), (2 * H + 1, 2 * W + 1)]
+    for size in sizes:
+        xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        yr = torch_conv(kind, xr, wr, br, size)
+        cot = rnd(*yr.shape, seed=4)
+        (yr * cot).sum().backward()
+        xg = nhwc(x).to(dev).requires_grad_(True)
+        wg = w.to(dev).requires_grad_(True)
+        bg = b.to(dev).requires_grad_(True)
+        ops.invalidate_weight_cache()
+        yg = ops.ConvFn.apply(xg, wg, bg, kind, size)
+        (yg * nhwc(cot).to(dev)).sum().backward()
+        assert rel_err(nchw(yg), yr) < TOL, 'fwd'
+        assert rel_err(nchw(xg.grad), xr.grad) < TOL_G, 'dgrad'
+        assert rel_err(wg.grad, wr.grad) < TOL_G, 'wgrad'
+        assert rel_err(bg.grad, br.grad) < TOL_G, 'bias grad'
+
+
+def test_conv_large_tiles(dev):
+    """Enough pixels that the (NT, MT) heuristic picks the big tiles, with a ragged tail."""
+    from reconvat_amd import ops
+    for kind, cin, cout, H, W in (('c3', 16, 16, 97, 229), ('c3', 64, 64, 40, 57), ('t3', 48, 24, 60, 114)):
+        x = rnd(2, cin, H, W, seed=5)
+        w = rnd(*((cout, cin, 3, 3) if kind == 'c3' else (cin, cout, 3, 3)), seed=6, scale=0.2)
+        b = rnd(cout, seed=7)
+        yr = torch_conv(kind, x, w, b)
+        yg = ops.ConvFn.apply(nhwc(x).to(dev), w.to(dev), b.to(dev), kind, None)
+        assert rel_err(nchw(yg), yr) < TOL
+
+
+def test_upcat(dev):
+    from reconvat_amd import ops
+    B, H, W = 2, 5, 7
+    x = rnd(B, 32, H, W, seed=1)
+    s = rnd(B, 16, 2 * H, 2 * W + 1, seed=2)
+    wu, bu = rnd(32, 32, 2, 2, seed=3, scale=0.3), rnd(32, seed=4)
+    ws, bs = rnd(16, 16, 3, 3, seed=5, scale=0.3), rnd(16, seed=6)
+    leaves = [t.clone().requires_grad_(True) for t in (x, wu, bu, s, ws, bs)]
+    size = (2 * H, 2 * W + 1)
+    ref = torch.cat((torch_conv('up', leaves[0], leaves[1], leaves[2], size), F.conv2d(leaves[3], leaves[4], leaves[5], padding=1)), 1)
+    cot = rnd(*ref.shape, seed=7)
+    (ref * cot).sum().backward()
+    g = [nhwc(x).to(dev), wu.to(dev), bu.to(dev), nhwc(s).to(dev), ws.to(dev), bs.to(dev)]
+    g = [t.requires_grad_(True) for t in g]
+    out = ops.UpCatFn.apply(*g, size)
+    (out * nhwc(cot).to(dev)).sum().backward()
+    assert rel_err(nchw(out), ref) < TOL
+    for i, (a, r) in enumerate(zip(g, leaves)):
+        ga = nchw(a.grad) if a.grad.dim() == 4 and i in (0, 3) else a.grad
+        assert rel_err(ga, r.grad) < TOL_G, i
+
+
+@pytest.mark.parametrize('C,training,with_res', [(16, True, False), (16, True, True), (24, True, False), (8, True, False),
+                                                 (96, True, False), (128, True, True), (48, False, False), (32, False, True)])
+def test_bn_lrelu(dev, C, training, with_res):
+    from reconvat_amd import ops
+    B, H, W = 2, 7, 13
+    z = rnd(B, C, H, W, seed=1) * 2 + 0.3
+    gamma, beta = rnd(C, seed=2) * 0.2 + 1, rnd(C, seed=3) * 0.1
+    rm, rv = rnd(C, seed=4) * 0.1, rnd(C, seed=5).abs() + 0.5
+    res = rnd(B, C, H, W, seed=6) if with_res else None
+    zr, gr, br = z.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if with_res else None
+    rmr, rvr = rm.clone(), rv.clone()
+    yr = F.leaky_relu(F.batch_norm(zr, rmr, rvr, gr, br, training, 0.1, 1e-5))
+    if with_res:
+        yr = yr + rr
+    cot = rnd(*yr.shape, seed=7)
+    (yr * cot).sum().backward()
+    zg = nhwc(z).to(dev).requires_grad_(True)
+    gg, bg = gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
+    rg = nhwc(res).to(dev).requires_grad_(True) if with_res else None
+    rmg, rvg, nbt = rm.to(dev), rv.to(dev), torch.zeros((), dtype=torch.long, device=dev)
+    yg = ops.BnActFn.apply(zg, gg, bg, rmg, rvg, nbt, rg, training, 0.01)
+    (yg * nhwc(cot).to(dev)).sum().backward()
+    assert rel_err(nchw(yg), yr) < TOL
+    assert rel_err(nchw(zg.grad), zr.grad) < TOL_G
+    assert rel_err(gg.grad, gr.grad) < TOL_G
+    assert rel_err(bg.grad, br.grad) < TOL_G
+    if with_res:
+        assert rel_err(nchw(rg.grad), rr.grad) < TOL_G
+    assert rel_err(rmg, rmr) < TOL and rel_err(rvg, rvr) < TOL
+    assert int(nbt.item()) == (1 if training else 0)
+
+
+@pytest.mark.parametrize('M,K,N,act', [(130, 229, 88, 1), (257, 176, 768, 0), (64, 768, 88, 1), (200, 916, 229, 1), (96, 88, 916, 0)])
+def test_linear(dev, M, K, N, act):
+    from reconvat_amd import ops
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
+    leaves = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    yr = F.linear(*leaves)
+    if act:
+        yr = torch.sigmoid(yr)
+    cot = rnd(M, N, seed=4)
+    (yr * cot).sum().backward()
+    g = [t.to(dev).requires_grad_(True) for t in (x, w, b)]
+    yg = ops.LinearFn.apply(g[0], g[1], g[2], act)
+    (yg * cot.to(dev)).sum().backward()
+    assert rel_err(yg, yr) < TOL
+    for a, r in zip(g, leaves):
+        assert rel_err(a.grad, r.grad) < TOL_G
+
+
+def test_onset_heads(dev):
+    from reconvat_amd import ops
+    B, T = 2, 37
+    y = rnd(B, 2, T, 229, seed=1)
+    wo, bo, wf, bf = rnd(88, 229, seed=2, scale=0.1), rnd(88, seed=3), rnd(88, 229, seed=4, scale=0.1), rnd(88, seed=5)
+    leaves = [t.clone().requires_grad_(True) for t in (y, wo, bo, wf, bf)]
+    onset = torch.sigmoid(F.linear(leaves[0][:, 0], leaves[1], leaves[2]))
+    feat = F.linear(leaves[0][:, 1], leaves[3], leaves[4])
+    cat = torch.cat((onset, feat), -1)
+    c1, c2 = rnd(B, T, 176, seed=6), rnd(B, T, 88, seed=7)
+    ((cat * c1).sum() + (onset * c2).sum()).backward()
+    g = [nhwc(y).to(dev)] + [t.to(dev) for t in (wo, bo, wf, bf)]
+    g = [t.requires_grad_(True) for t in g]
+    catg, onsetg = ops.OnsetHeadsFn.apply(*g)
+    ((catg.view(B, T, 176) * c1.to(dev)).sum() + (onsetg.view(B, T, 88) * c2.to(dev)).sum()).backward()
+    assert rel_err(catg.view(B, T, 176), cat) < TOL and rel_err(onsetg.view(B, T, 88), onset) < TOL
+    assert rel_err(nchw(g[0].grad), leaves[0].grad) < TOL_G
+    for a, r in zip(g[1:], leaves[1:]):
+        assert rel_err(a.grad, r.grad) < TOL_G
+
+
+@pytest.mark.parametrize('fin,fout,groups,L', [(176, 768, 6, 50), (88, 916, 4, 33), (229, 916, 4, 16)])
+def test_local_attention(dev, fin, fout, groups, L):
+    from oracle import model as om
+    from reconvat_amd import ops
+    B = 2
+    p = {'a.rel': rnd(1, fout, 31, seed=1, scale=0.5)}
+    for i, w in enumerate(('W_q', 'W_k', 'W_v')):
+        p[f'a.{w}.weight'] = rnd(fout, fin, seed=2 + i, scale=float(np.sqrt(3.0 / fin)))
+    x = rnd(B, L, fin, seed=9)
+    cot = rnd(B, L, fout, seed=10)
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xo = x.clone().requires_grad_(True)
+    oo, ao = om.local_attention(om.Net(po), xo, 'a', groups)
+    (oo * cot).sum().backward()
+    g = {k: v.to(dev).requires_grad_(True) for k, v in p.items()}
+    xg = x.to(dev).requires_grad_(True)
+    og, ag = ops.LocalAttnFn.apply(xg, g['a.W_q.weight'], g['a.W_k.weight'], g['a.W_v.weight'], g['a.rel'], groups)
+    (og * cot.to(dev)).sum().backward()
+    assert rel_err(og, oo) < TOL and rel_err(ag, ao) < TOL
+    assert rel_err(xg.grad, xo.grad) < TOL_G
+    for k in p:
+        assert rel_err(g[k].grad, po[k].grad) < TOL_G, k
+
+
+def test_attention_golden(dev):
+    """Same op against the vectors the reference itself produced (tests/golden/attention.npz)."""
+    import os
+    from oracle import fixture as fx
+    from reconvat_amd import ops
+    gold = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'attention.npz'))
+    for tag, fin, fout, groups in (('t176', 176, 768, 6), ('r88', 88, 916, 4), ('f229', 229, 916, 4)):
+        rel = fx.hashed_normalish(tag + 'rel', (1, fout, 31), 0.5).to(dev).requires_grad_(True)
+        ws = [fx.hashed(tag + w, (fout, fin), float(np.sqrt(3.0 / fin))).to(dev).requires_grad_(True) for w in ('W_q', 'W_k', 'W_v')]
+        x = fx.hashed(tag + 'x', (2, 64, fin), 1.0).to(dev).requires_grad_(True)
+        cot = fx.hashed(tag + 'cot', (2, 64, fout), 1.0).to(dev)
+        o, a = ops.LocalAttnFn.apply(x, ws[0], ws[1], ws[2], rel, groups)
+        (o * cot).sum().backward()
+        assert rel_err(o, torch.from_numpy(gold[tag + '_out'])) < TOL
+        assert rel_err(a, torch.from_numpy(gold[tag + '_att'])) < TOL
+        assert rel_err(x.grad, torch.from_numpy(gold[tag + '_dx'])) < TOL_G
+        assert rel_err(rel.grad, torch.from_numpy(gold[tag + '_drel'])) < TOL_G
+
+
+def test_losses(dev):
+    from reconvat_amd import ops
+    p = torch.sigmoid(rnd(3, 70, 88, seed=1) * 4)
+    p.view(-1)[:4] = torch.tensor([0.0, 1.0, 1e-30, 1 - 1e-8])     # exercises the -100 log clamp
+    t_soft = torch.sigmoid(rnd(3, 70, 88, seed=2) * 3)
+    t_hard = (rnd(3, 70, 88, seed=3) > 0.8).float()
+    for t in (t_soft, t_hard):
+        pr = p.clone().requires_grad_(True)
+        lr = F.binary_cross_entropy(pr, t)
+        (lr * 1.7).backward()
+        pg = p.to(dev).requires_grad_(True)
+        lg = ops.bce_mean(pg, t.to(dev))
+        (lg * 1.7).backward()
+        assert rel_err(lg, lr) < TOL and rel_err(pg.grad, pr.grad) < TOL_G
+    a, b = rnd(2, 50, 229, seed=4), rnd(2, 50, 229, seed=5)
+    ar = a.clone().requires_grad_(True)
+    lr = F.mse_loss(ar, b)
+    lr.backward()
+    ag = a.to(dev).requires_grad_(True)
+    lg = ops.mse_mean(ag, b.to(dev))
+    lg.backward()
+    assert rel_err(lg, lr) < TOL and rel_err(ag.grad, ar.grad) < TOL_G
+    assert rel_err(ops.abs_mean(a.to(dev)), a.abs().mean()) < TOL
+    assert rel_err(ops.l2_norm(a.to(dev)), a.norm()) < TOL
+
+
+def test_vat_perturb(dev):
+    from reconvat_amd import ops
+    x = rnd(2, 1, 33, 229, seed=1) * 0.5 + 0.5
+    x.view(-1)[:50] = 0.0
+    x.view(-1)[50:100] = 1.0                               # clamp is active on these
+    d = rnd(2, 1, 33, 229, seed=2)
+    for xi in (1e-1, 1e-6):
+        dr = d.clone().requires_grad_(True)
+        xa = (x + xi * dr / torch.norm(dr, dim=-1, keepdim=True)).clamp(0, 1)
+        cot = rnd(*x.shape, seed=3)
+        (xa * cot).sum().backward()
+        dg = d.to(dev).requires_grad_(True)
+        xg = ops.VatPerturbFn.apply(x.to(dev), dg, xi)
+        (xg * cot.to(dev)).sum().backward()
+        assert rel_err(xg, xa) < 1e-6
+        assert rel_err(dg.grad, dr.grad) < TOL_G
+    g = rnd(2, 1, 33, 229, seed=4) * 1e-11
+    dd = g * 1e10
+    dn = dd / torch.norm(dd, dim=-1, keepdim=True)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    xa, r, dng = ops.vat_adversarial(x.to(dev), g.to(dev), 1e10, 2.0, flag)
+    assert rel_err(r, 2.0 * dn) < 1e-5 and rel_err(dng, dn) < 1e-5
+    assert rel_err(xa, (x + 2.0 * dn).clamp(0, 1)) < 1e-5
+    assert int(flag.item()) == 0
+    g[0, 0, 3] = 0.0                                        # 0/0 -> NaN row -> flag, like the reference's assert
+    ops.vat_adversarial(x.to(dev), g.to(dev), 1e10, 2.0, flag)
+    assert int(flag.item()) == 1
+
+
+def test_frontend(dev):
+    import os
+    from oracle import fixture as fx, frontend as ofe
+    from reconvat_amd.frontend import MelSpectrogram
+    gold = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'frontend.npz'))
+    m = MelSpectrogram().to(dev)
+    audio = fx.fixture_audio(2, 65536)[:, :-1]
+    mel = m(audio.to(dev))
+    assert mel.shape == (2, 229, 128)
+    assert rel_err(mel, torch.from_numpy(gold['mel'])) < 1e-4
+    ln = m.lognorm(audio.to(dev))
+    assert ln.shape == (2, 1, 128, 229)
+    err = (ln.cpu() - torch.from_numpy(gold['lognorm'])).abs().max().item()
+    assert err < 1e-4, err                                 # values span [0,1]; north-star tolerance 1e-3
+    assert ln.min().item() == 0.0 and ln.max().item() == 1.0
+    bufs = ofe.frontend_buffers()
+    a2 = fx.fixture_audio(3, 40000, 'odd')[:, :-1]          # ragged length, 3 clips
+    ref = ofe.frontend(a2, bufs)
+    got = m.lognorm(a2.to(dev))
+    assert got.shape == ref.shape
+    assert (got.cpu() - ref).abs().max().item() < 1e-4
+
+
+def test_adam(dev):
+    from reconvat_amd.train import FlatAdam
+    ps = [torch.nn.Parameter(rnd(7, 5, seed=1)), torch.nn.Parameter(rnd(33, seed=2)), torch.nn.Parameter(rnd(4, 3, 2, seed=3))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    gp = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ps]
+    o_ref = torch.optim.Adam(ref, 1e-3)
+    sch = torch.optim.lr_scheduler.StepLR(o_ref, step_size=3, gamma=0.5)
+    o = FlatAdam(gp, lr=1e-3, step_size=3, gamma=0.5)
+    for it in range(7):
+        o.zero_grad()
+        o_ref.zero_grad()
+        for i, (a, r) in enumerate(zip(gp, ref)):
+            if i == 1 and it < 2:
+                continue                                     # a parameter with no gradient for a while
+            g = rnd(*a.shape, seed=10 * it + i)
+            r.grad = g.clone()
+            a.grad.copy_(g.to(dev))
+        o.step()
+        o_ref.step()
+        sch.step()
+    for a, r in zip(gp, ref):
+        assert rel_err(a, r) < 1e-5
+    assert abs(o.current_lr() - o_ref.param_groups[0]['lr']) < 1e-12
