@@ -1,0 +1,240 @@
+#!/usr/bin/env python
+"""Headline benchmark: training audio-seconds per second of the ReconVAT U-Net+Onset VAT+reconstruction
+step (BASELINE.json metric) on N MI355X GPUs of one node, one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the reference loop body (model/helper_functions.py:577-607) over one synthetic
+batch: zero_grad, log-Mel front-end of 8 labelled + 8 unlabelled 327 680-sample segments, VAT power
+iteration on both, transcriber -> reconstructor -> transcriber, the 11 losses, backward, [gradient
+all-reduce], Adam + StepLR, post-step gradient clip.  Inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line; at N=1 it also carries the conv-phase roofline (measured with HIP events on
+the launch stream) and the CPU baseline (the oracle timed on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEG = 327680
+SEG_SECONDS = SEG / 16000.0
+MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix peak (dense)
+
+
+def synthetic_batch(b, gen, device):
+    """Seeded synthetic segments: audio ~ U(-0.1, 0.1), ~5 % frame / ~1 % onset labels."""
+    audio = (torch.rand(b, SEG, generator=gen) * 0.2 - 0.1)
+    u = torch.rand(b, SEG // 512, 88, generator=gen)
+    return {'audio': audio.to(device), 'frame': (u > 0.95).float().to(device), 'onset': (u > 0.99).float().to(device)}
+
+
+# ---------------------------------------------------------------------------------------------
+# conv-phase roofline: every conv launch of one step is recorded (shapes only), then each distinct
+# launch is re-issued back-to-back between two HIP events on the launch stream.
+# ---------------------------------------------------------------------------------------------
+def conv_flops(name, a):
+    if name == 'rv_conv_fwd':
+        mode, b, h, w, cin, ho, wo, cout = a[0], a[3], a[4], a[5], a[6], a[9], a[10], a[11]
+        taps = {0: 9, 1: 1, 2: 4, 3: 1}[mode]
+        pix = b * h * w * 4 if mode == 3 else b * ho * wo
+        return 2.0 * pix * cin * cout * taps
+    mode, ca, hv, wv, cb, b = a[0], a[5], a[8], a[9], a[10], a[11]
+    return 2.0 * b * hv * wv * ca * cb * {0: 9, 1: 1, 2: 4}[mode]
+
+
+def measure_conv_phase(step_fn, device):
+    from reconvat_amd import _lib
+    lib = _lib.load()
+    records = []
+    real_call = _lib.call
+
+    def spy(name, *args):
+        if name in ('rv_conv_fwd', 'rv_conv_wgrad'):
+            records.append((name, args))
+        return real_call(name, *args)
+
+    import reconvat_amd.ops as ops
+    ops.call = spy
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+    finally:
+        ops.call = real_call
+    # group identical launches by their shape signature (pointers and stream excluded)
+    groups = {}
+    for name, a in records:
+        if name == 'rv_conv_fwd':
+            sig = (name, a[0]) + tuple(a[2:7]) + tuple(a[8:12])
+        else:
+            sig = (name, a[0]) + tuple(a[2:6]) + tuple(a[7:12])
+        g = groups.setdefault(sig, {'count': 0, 'name': name, 'args': a})
+        g['count'] += 1
+    big = torch.empty(400 * 1024 * 1024 // 4, device=device)      # scratch large enough for any operand
+    big.uniform_(-1, 1)
+    out = torch.empty_like(big)
+    ws = torch.empty(64 * 1024 * 1024 // 4, device=device)
+    st = torch.cuda.current_stream()
+    total_ms, total_flops, per_kernel = 0.0, 0.0, []
+    for sig, g in groups.items():
+        a = list(g['args'])
+        if g['name'] == 'rv_conv_fwd':
+            a[1], a[7] = big.data_ptr(), out.data_ptr()
+            a[12] = big.data_ptr() + 64 * 1024 * 1024
+            a[13] = None
+        else:
+            a[1], a[6] = big.data_ptr(), big.data_ptr() + 128 * 1024 * 1024
+            a[12], a[16], a[18] = out.data_ptr(), None, ws.data_ptr()
+            a[19] = ws.numel() * 4
+        a[-1] = st.cuda_stream
+        fn = getattr(lib, g['name'])
+        for _ in range(2):
+            fn(*a)
+        reps = 5
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            fn(*a)
+        e1.record(st)
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        fl = conv_flops(g['name'], g['args'])
+        total_ms += ms * g['count']
+        total_flops += fl * g['count']
+        per_kernel.append((ms * g['count'], g['count'], ms, fl / ms / 1e9, sig))
+    per_kernel.sort(reverse=True)
+    return total_ms, total_flops, per_kernel, len(records)
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """The oracle (CPU restatement pinned to the reference) timed on this host: one labelled + one
+    unlabelled full-length segment per step, VAT+recon, Adam -- a bounded sample of the same workload."""
+    from oracle import fixture as fx, model as om
+    torch.manual_seed(0)
+    params = fx.fixture_params('onset', True)
+    g = torch.Generator().manual_seed(1)
+    bl, bul = synthetic_batch(1, g, 'cpu'), synthetic_batch(1, g, 'cpu')
+    state, times = {}, []
+    t_start = time.time()
+    for i in range(4):
+        t0 = time.time()
+        om.train_step(params, state, i, bl, bul, om.run_on_batch_onset, VAT=True, reconstruction=True, xi=1e-6, eps=2.0)
+        times.append(time.time() - t0)
+        if time.time() - t_start > seconds_budget and i >= 1:
+            break
+    timed = times[1:] if len(times) > 1 else times
+    per_step = sorted(timed)[len(timed) // 2]
+    return {'value': round(2 * SEG_SECONDS / per_step, 3), 'unit': 'audio-s/s', 'cores': torch.get_num_threads(),
+            'kind': 'port',
+            'sample': f'B_l=1 + B_ul=1 full 327680-sample segments, UNet_Onset VAT+recon fp32, '
+                      f'{len(timed)} timed steps after 1 warm-up ({per_step:.2f} s/step)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=8, help='labelled AND unlabelled segments per GPU')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    import reconvat_amd as ra
+    torch.manual_seed(1234)                       # identical initial weights on every rank
+    model = ra.UNet_Onset((2, 2), (2, 2), log=True, reconstruction=True, mode='imagewise', spec='Mel', device=str(device),
+                          XI=1e-6, eps=2).to(device)
+    opt = ra.FlatAdam(model.parameters(), lr=1e-3, step_size=1000, gamma=0.98)
+    gen = torch.Generator().manual_seed(1000 + rank)      # distinct data shard per rank
+    batch, batch_ul = synthetic_batch(args.batch, gen, device), synthetic_batch(args.batch, gen, device)
+    torch.manual_seed(77 + rank)                  # VAT noise stream
+    step = ra.TrainStep(model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=not args.no_graph)
+    used_graph = not args.no_graph
+    if used_graph:
+        try:
+            step.capture()
+        except Exception as e:                     # noqa: BLE001 -- report and fall back to eager launches
+            if rank == 0:
+                print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager', file=sys.stderr)
+            torch.cuda.synchronize()
+            step.use_graph, step.graph, used_graph = False, None, False
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    loss = float(step.loss.item())
+    nan_flag = int(model.vat_loss.nan_flag.item())
+    ms = elapsed / args.steps * 1e3
+    audio_s = world * 2 * args.batch * SEG_SECONDS * args.steps / elapsed
+
+    line = {
+        'metric': 'training audio-sec/sec (node)', 'value': round(audio_s, 2), 'unit': 'audio-s/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'ReconVAT UNet_Onset VAT=True reconstruction=True, per-GPU B_l={args.batch} + '
+                               f'B_ul={args.batch} segments of 327680 samples (640 frames x 229 mel), Adam+StepLR, fp32',
+                   'parallelism': f'dp{world}', 'hipgraph': used_graph, 'labelled_only_audio_s_per_s': round(audio_s / 2, 2),
+                   'final_loss': round(loss, 5), 'vat_nan_flag': nan_flag},
+    }
+    if rank == 0 and world == 1:
+        if not args.no_roofline:
+            eager = ra.TrainStep(model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=False)
+            conv_ms, conv_flops_total, per_kernel, nlaunch = measure_conv_phase(eager, device)
+            achieved = conv_flops_total / conv_ms / 1e9
+            line['roofline'] = {
+                'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+                'kernel': 'conv_mfma_k / wgrad_mfma_k family (all conv launches of one step)',
+                'launches_per_step': nlaunch, 'conv_ms_per_step': round(conv_ms, 3),
+                'executed_gflop_per_step': round(conv_flops_total / 1e9, 1),
+                'reference_gflop_per_step': 1531.0,
+                'top': [{'ms_per_step': round(t, 3), 'count': c, 'ms': round(m, 4), 'tflops': round(tf, 1), 'sig': list(map(str, s))}
+                        for t, c, m, tf, s in per_kernel[:6]],
+            }
+        if not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

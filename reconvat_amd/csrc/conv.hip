@@ -626,11 +626,31 @@ int rv_conv_fwd(int mode, const float* in, int in_ld, int B, int H, int W, int C
     return RV_OK;
 }
 
+// wgrad partitioning shared by the workspace query and the launch
+struct WgradPlan { bool small; int TA, TB, nga, ngb, rows_per_wave, nparts; };
+static WgradPlan wgrad_plan(int taps, int B, int Hv, int Ca, int Cb) {
+    WgradPlan p;
+    const int nrows = B * Hv;
+    p.small = (Ca * Cb * taps <= 144) && (Ca < 8 || Cb < 8);
+    if (p.small) {
+        p.TA = p.TB = p.nga = p.ngb = 1; p.rows_per_wave = 0;
+        p.nparts = nrows < 1024 ? nrows : 1024;
+        return p;
+    }
+    p.TA = Ca > 16 ? 2 : 1; p.TB = Cb > 16 ? 2 : 1;
+    p.nga = cdiv(Ca, p.TA * 16); p.ngb = cdiv(Cb, p.TB * 16);
+    int want = 2048 / (p.nga * p.ngb);       // aim for ~2048 waves overall
+    if (want < 8) want = 8;
+    if (want > nrows) want = nrows;
+    p.rows_per_wave = cdiv(nrows, want);
+    p.nparts = cdiv(nrows, p.rows_per_wave);
+    return p;
+}
+
 // Workspace (bytes) rv_conv_wgrad needs for the given problem.
 long rv_conv_wgrad_workspace_bytes(int taps, int B, int Hv, int Ca, int Cb) {
-    long nrows = (long)B * Hv;
-    long nparts = nrows < 1024 ? nrows : 1024;
-    return nparts * ((long)taps * Ca * Cb + Cb) * 4;
+    WgradPlan p = wgrad_plan(taps, B, Hv, Ca, Cb);
+    return (long)p.nparts * ((long)taps * Ca * Cb + Cb) * 4;
 }
 
 // G[tap][a][b] = sum_p U[f(p,tap)][a] * V[p][b], db[b] = sum_p V[p][b]; results scattered to
@@ -646,13 +666,11 @@ int rv_conv_wgrad(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, co
     a.U = U; a.u_ld = u_ld; a.Hu = Hu; a.Wu = Wu; a.Ca = Ca; a.V = V; a.v_ld = v_ld; a.Hv = Hv; a.Wv = Wv; a.Cb = Cb;
     a.B = B; a.want_bias = dbias != nullptr;
     a.pstride = (long)taps * Ca * Cb + Cb;
-    const int nrows = B * Hv;
-    int nparts_max = nrows < 1024 ? nrows : 1024;
-    RV_CHECK_ARG(workspace_bytes >= nparts_max * a.pstride * 4, "rv_conv_wgrad: workspace too small");
+    const WgradPlan plan = wgrad_plan(taps, B, Hv, Ca, Cb);
+    RV_CHECK_ARG(workspace_bytes >= (long)plan.nparts * a.pstride * 4, "rv_conv_wgrad: workspace too small");
     a.part = (float*)workspace;
-    const bool small = (Ca * Cb * taps <= 144) && (Ca < 8 || Cb < 8);
-    if (small) {
-        a.nparts = nparts_max; a.rows_per_wave = 0; a.ngb = 1;
+    a.nparts = plan.nparts; a.rows_per_wave = plan.rows_per_wave; a.ngb = plan.ngb;
+    if (plan.small) {
         dim3 grid(cdiv(a.nparts, 4)), blk(256);
 #define RV_WS(ca, cb, kh, kw, ss, pp)                                                             \
     if (Ca == ca && Cb == cb) {                                                                  \
@@ -665,19 +683,8 @@ int rv_conv_wgrad(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, co
         rv_set_error("rv_conv_wgrad: no small-channel kernel for mode %d Ca=%d Cb=%d", mode, Ca, Cb);
         return RV_EUNSUPPORTED;
     } else {
-        const int TA = Ca > 16 ? 2 : 1, TB = Cb > 16 ? 2 : 1;
-        const int nga = cdiv(Ca, TA * 16), ngb = cdiv(Cb, TB * 16);
-        // aim for ~2048 waves overall
-        int want = 2048 / (nga * ngb);
-        if (want < 8) want = 8;
-        if (want > nparts_max) want = nparts_max;
-        int rpw = cdiv(nrows, want);
-        if (rpw < 1) rpw = 1;
-        a.rows_per_wave = rpw;
-        a.nparts = cdiv(nrows, rpw);
-        RV_CHECK_ARG(a.nparts <= nparts_max, "rv_conv_wgrad: internal partition error");
-        a.ngb = ngb;
-        dim3 grid(cdiv(a.nparts, 4), nga * ngb), blk(256);
+        const int TA = plan.TA, TB = plan.TB;
+        dim3 grid(cdiv(a.nparts, 4), plan.nga * plan.ngb), blk(256);
 #define RV_WG(kh, kw, ss, pp)                                                                     \
     do {                                                                                         \
         if (TA == 1 && TB == 1) hipLaunchKernelGGL((wgrad_mfma_k<kh, kw, ss, pp, 1, 1>), grid, blk, 0, st, a); \

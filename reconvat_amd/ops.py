@@ -28,8 +28,11 @@ def invalidate_weight_cache():
 # --------------------------------------------------------------------------------------------
 def _geom(t):
     b, h, w, c = t.shape
+    if t.is_contiguous():
+        return b, h, w, c, c
     ld = t.stride(2)
-    if t.stride(3) != 1 or t.stride(1) != w * ld or t.stride(0) != h * w * ld:
+    ok = (c == 1 or t.stride(3) == 1) and (h == 1 or t.stride(1) == w * ld) and (b == 1 or t.stride(0) == h * w * ld)
+    if not ok or w == 1:
         raise RuntimeError(f'expected an NHWC tensor or a channel slice of one, got shape {tuple(t.shape)} '
                            f'strides {t.stride()}')
     return b, h, w, c, ld
@@ -333,7 +336,7 @@ class LinearFn(Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             gemm(dz.t(), x, dw, splitk=_splitk_for(n, k, m))
-        if b is not None and ctx.needs_input_grad[2]:
+        if ctx.needs_input_grad[2]:
             db = colsum(dz)
         return dx, dw, db, None
 

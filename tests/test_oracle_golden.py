@@ -1,0 +1,106 @@
+"""The CPU oracle against the golden vectors produced by running the reference itself
+(tests/golden/make_golden.py).  Runs anywhere; needs neither a GPU nor /root/reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import fixture as fx, frontend as ofe, model as om
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def load(name):
+    return np.load(os.path.join(G, name + '.npz'), allow_pickle=False)
+
+
+def digest(t, n=96):
+    f = t.detach().double().flatten()
+    stride = max(1, f.numel() // n)
+    return np.concatenate([[f.norm().item()], f[::stride][:n].numpy()])
+
+
+def close_digest(t, gold, tol, n=96):
+    d = digest(t, n)
+    scale = max(np.abs(gold[1:]).max(), 1e-30)
+    assert abs(d[0] - gold[0]) <= tol * max(gold[0], 1e-30)
+    assert np.abs(d[1:] - gold[1:]).max() <= tol * scale
+
+
+def test_frontend():
+    g = load('frontend')
+    bufs = ofe.frontend_buffers()
+    assert int((bufs['spectrogram.mel_basis'] != 0).sum()) == int(g['mel_nnz']) == 2025
+    audio = fx.fixture_audio(2, 65536)[:, :-1]
+    mel = ofe.melspec_power(audio, bufs)
+    assert rel_err(mel, torch.from_numpy(g['mel'])) < 1e-5
+    ln = ofe.log_normalise(mel)
+    assert (ln - torch.from_numpy(g['lognorm'])).abs().max().item() < 1e-5
+    assert float(g['stft_rel']) < 1e-4        # independent torch.stft cross-check recorded at generation time
+
+
+def test_unet_forward_backward():
+    g = load('unet')
+    params = fx.fixture_params('onset', False)
+    x = fx.fixture_spec(2, 64).requires_grad_(True)
+    for k in om.trainable_keys(params):
+        params[k].requires_grad_(True)
+    y = om.unet(om.Net(params, True), x, 'transcriber.Unet1_encoder', 'transcriber.Unet1_decoder')
+    (y * fx.hashed('cot_unet', (2, 2, 64, 229))).sum().backward()
+    assert rel_err(y, torch.from_numpy(g['y'])) < 1e-5
+    assert rel_err(x.grad, torch.from_numpy(g['dx'])) < 1e-4
+    for k in g.files:
+        if k.startswith('g:'):
+            close_digest(params[k[2:]].grad, g[k], 5e-4)
+        elif k.startswith('s:'):
+            assert rel_err(params[k[2:]], torch.from_numpy(g[k])) < 1e-5
+
+
+def test_networks():
+    g = load('networks')
+    x = fx.fixture_spec(2, 128, 'spec_net')
+    with torch.no_grad():
+        p = fx.fixture_params('onset', True)
+        rec, roll, onset, roll2, onset2, a = om.forward_onset(p, True, x, True)
+        for n, t in (('rec', rec), ('roll', roll), ('onset', onset), ('roll2', roll2), ('onset2', onset2)):
+            assert rel_err(t, torch.from_numpy(g['onset_' + n])) < 5e-5, n
+        rec_e, roll_e = om.forward_onset(p, False, x, True)[:2]
+        assert rel_err(roll_e, torch.from_numpy(g['onset_eval_roll'])) < 5e-5
+        p = fx.fixture_params('frame', True)
+        rec, roll, roll2, a = om.forward_frame(p, True, x, True)
+        for n, t in (('rec', rec), ('roll', roll), ('roll2', roll2)):
+            assert rel_err(t, torch.from_numpy(g['frame_' + n])) < 5e-5, n
+
+
+def test_vat_well_conditioned():
+    g = load('vat')
+    x = fx.fixture_spec(2, 64, 'spec_vat')
+    p = fx.fixture_params('onset', False)
+    lds, r_adv, dn, grad = om.vat_onset(p, True, x, 1e-1, 2.0, fx.fixture_noise(x.shape, 'd0_onset'))
+    assert rel_err(grad, torch.from_numpy(g['onset_wc_g'])) < 2e-3
+    assert rel_err(r_adv, torch.from_numpy(g['onset_wc_radv'])) < 2e-3
+    assert abs(lds['frame'].item() - g['onset_wc_lds'][0]) < 1e-3 * g['onset_wc_lds'][0]
+    # every frame of r_adv has L2 norm eps
+    assert torch.allclose(r_adv.norm(dim=-1), torch.full_like(r_adv.norm(dim=-1), 2.0), rtol=1e-5)
+
+
+@pytest.mark.parametrize('kind', ['onset', 'frame'])
+def test_run_on_batch_losses(kind):
+    g = load('run_on_batch')
+    fn = om.run_on_batch_onset if kind == 'onset' else om.run_on_batch_frame
+    onset, frame = fx.fixture_labels(2, 64, 'L')
+    bl = {'audio': fx.fixture_audio(2, 64 * 512, 'L'), 'onset': onset, 'frame': frame}
+    o2, f2 = fx.fixture_labels(2, 64, 'UL')
+    bul = {'audio': fx.fixture_audio(2, 64 * 512, 'UL'), 'onset': o2, 'frame': f2}
+    n_ul, n_l = fx.fixture_noise((2, 1, 64, 229), 'd0_ul'), fx.fixture_noise((2, 1, 64, 229), 'd0_l')
+    for recon, vat, training in ((True, True, True), (False, False, True), (True, True, False)):
+        key = f'{kind}_r{int(recon)}_v{int(vat)}_t{int(training)}'
+        p = fx.fixture_params(kind, recon)
+        use_ul = vat and training
+        _, losses, _ = fn(p, training, bl, bul if use_ul else None, vat, recon, d0_l=n_l, d0_ul=n_ul)
+        assert list(losses.keys()) == list(g[key + '_keys'])
+        for (k, v), ref in zip(losses.items(), g[key + '_losses']):
+            tol = 2e-3 if 'LDS' in k else 1e-4
+            assert abs(v.item() - ref) <= tol * max(abs(ref), 1e-6), (key, k, v.item(), ref)
