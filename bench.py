@@ -81,7 +81,7 @@ def measure_conv_phase(step_fn, device):
     big = torch.empty(400 * 1024 * 1024 // 4, device=device)      # scratch large enough for any operand
     big.uniform_(-1, 1)
     out = torch.empty_like(big)
-    ws = torch.empty(64 * 1024 * 1024 // 4, device=device)
+    ws = torch.empty(256 * 1024 * 1024 // 4, device=device)
     st = torch.cuda.current_stream()
     total_ms, total_flops, per_kernel = 0.0, 0.0, []
     for sig, g in groups.items():
@@ -97,7 +97,8 @@ def measure_conv_phase(step_fn, device):
         a[-1] = st.cuda_stream
         fn = getattr(lib, g['name'])
         for _ in range(2):
-            fn(*a)
+            if fn(*a) != 0:
+                raise RuntimeError(f"{g['name']} {sig}: {_lib.last_error()}")
         reps = 5
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
@@ -147,6 +148,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--verbose', action='store_true', help='dump the per-launch conv table to stderr')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -218,6 +220,9 @@ def main():
             eager = ra.TrainStep(model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=False)
             conv_ms, conv_flops_total, per_kernel, nlaunch = measure_conv_phase(eager, device)
             achieved = conv_flops_total / conv_ms / 1e9
+            if args.verbose:
+                for t, c, m_, tf, sg in per_kernel:
+                    print(f'[conv] {t:8.3f} ms/step  x{c:3d}  {m_:8.4f} ms  {tf:7.1f} TF/s  {sg}', file=sys.stderr)
             line['roofline'] = {
                 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,

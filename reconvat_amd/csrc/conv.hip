@@ -286,18 +286,30 @@ struct WgradArgs {
     int want_bias;
 };
 
+// LDS-staged pixel-reduction GEMM.  One workgroup owns a run of V rows (b, y) and one (a-group, b-group)
+// of up to 32x32 channels.  Per V row it stages that row (CB channels) and the KH input rows it touches
+// (CA channels, front/back zero padding so the tap shifts need no predicates) into LDS with 16-byte
+// loads -- for the 3x3 convs the KH-row window slides, so every input row is fetched once per workgroup
+// -- and the four waves walk the row in 4-pixel MFMA k-steps (wave w takes steps w, w+4, ...), reading
+// A/B fragments with ds_read_b32 (lane (i, g): channel i of pixel x0+g, which is what the f32 MFMA wants).
+// Accumulators stay in registers across all rows; at the end the four waves are folded through LDS and
+// ONE partial per workgroup goes to the workspace (deterministic second pass: wgrad_reduce_k).
 template <int KH, int KW, int S, int P, int TA, int TB>
 __global__ __launch_bounds__(256) void wgrad_mfma_k(WgradArgs a) {
-    constexpr int TAPS = KH * KW;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int TAPS = KH * KW, CA = TA * 16, CB = TB * 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const int pw = blockIdx.x * 4 + wave;
-    if (pw >= a.nparts) return;
     const int ga = blockIdx.y / a.ngb, gb = blockIdx.y - ga * a.ngb;
-    const int a0 = ga * TA * 16, b0 = gb * TB * 16;
+    const int a0 = ga * CA, b0 = gb * CB;
     const int nrows = a.B * a.Hv;
-    const int row0 = pw * a.rows_per_wave;
+    const int row0 = blockIdx.x * a.rows_per_wave;          // rows per WORKGROUP here
     const int row1 = min(row0 + a.rows_per_wave, nrows);
+    const int Wv4 = (a.Wv + 3) & ~3;
+    const int UP = S * (Wv4 - 1) + KW + (S == 1 ? 0 : 0);    // pixels per staged input row (incl. zero padding)
+    float* ubuf = smem;                                      // [KH][UP][CA]
+    float* vbuf = smem + KH * UP * CA;                       // [Wv4][CB]
+    const int stage_floats = KH * UP * CA + Wv4 * CB;
 
     f32x4 acc[TAPS][TA][TB];
     f32x4 accb[TB];
@@ -309,35 +321,68 @@ __global__ __launch_bounds__(256) void wgrad_mfma_k(WgradArgs a) {
             for (int y = 0; y < TB; ++y) acc[t][x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int y = 0; y < TB; ++y) accb[y] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bool aval[TA], bval[TB];
-#pragma unroll
-    for (int x = 0; x < TA; ++x) aval[x] = a0 + x * 16 + i < a.Ca;
-#pragma unroll
-    for (int y = 0; y < TB; ++y) bval[y] = b0 + y * 16 + i < a.Cb;
     const bool do_bias = a.want_bias && ga == 0;
 
+    for (int k = tid; k < stage_floats; k += 256) smem[k] = 0.f;   // padding stays zero for the whole kernel
+    __syncthreads();
+
+    // channel validity of this workgroup's float4 columns
+    const int ca_valid = min(CA, a.Ca - a0), cb_valid = min(CB, a.Cb - b0);
+
+    auto load_urow = [&](int b, int r, int slot) {
+        float* dst = ubuf + slot * UP * CA + P * CA;
+        const bool inside = r >= 0 && r < a.Hu;
+        const float* src = a.U + ((long)b * a.Hu + (inside ? r : 0)) * a.Wu * a.u_ld + a0;
+        constexpr int C4 = CA / 4;
+        const int npx = min(a.Wu, UP - P);
+        for (int idx = tid; idx < npx * C4; idx += 256) {
+            int px = idx / C4, c4 = (idx - px * C4) * 4;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (inside && c4 < ca_valid) v = *reinterpret_cast<const f32x4*>(src + (long)px * a.u_ld + c4);
+            *reinterpret_cast<f32x4*>(dst + px * CA + c4) = v;
+        }
+    };
+    auto load_vrow = [&](int b, int y) {
+        const float* src = a.V + ((long)b * a.Hv + y) * a.Wv * a.v_ld + b0;
+        constexpr int C4 = CB / 4;
+        for (int idx = tid; idx < a.Wv * C4; idx += 256) {
+            int px = idx / C4, c4 = (idx - px * C4) * 4;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (c4 < cb_valid) v = *reinterpret_cast<const f32x4*>(src + (long)px * a.v_ld + c4);
+            *reinterpret_cast<f32x4*>(vbuf + px * CB + c4) = v;
+        }
+    };
+
+    int prev_b = -1, prev_y = -2;
     for (int row = row0; row < row1; ++row) {
         const int b = row / a.Hv, y = row - b * a.Hv;
-        const float* vrow = a.V + ((long)b * a.Hv + y) * a.Wv * a.v_ld + b0 + i;
-        for (int x0 = 0; x0 < a.Wv; x0 += 4) {
+        __syncthreads();                                      // everyone is done with the previous row's buffers
+        const bool slide = (S == 1) && (b == prev_b) && (y == prev_y + 1);
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) {
+            const int r = y * S - P + ky;
+            const int slot = (S == 1) ? ((r + KH) % KH) : ky;
+            if (!slide || ky == KH - 1) load_urow(b, r, slot);
+        }
+        load_vrow(b, y);
+        prev_b = b; prev_y = y;
+        __syncthreads();
+        int slot_of[KH];
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) slot_of[ky] = (S == 1) ? ((y - P + ky + KH) % KH) : ky;
+        for (int x0 = wave * 4; x0 < Wv4; x0 += 16) {
             const int x = x0 + g;
-            const bool vx = x < a.Wv;
             float vf[TB];
 #pragma unroll
-            for (int tb = 0; tb < TB; ++tb)
-                vf[tb] = (vx && bval[tb]) ? vrow[(long)x * a.v_ld + tb * 16] : 0.f;
+            for (int tb = 0; tb < TB; ++tb) vf[tb] = vbuf[x * CB + tb * 16 + i];
 #pragma unroll
             for (int ky = 0; ky < KH; ++ky) {
-                const int iy = y * S - P + ky;
-                const bool oky = (unsigned)iy < (unsigned)a.Hu;
+                const float* ur = ubuf + slot_of[ky] * UP * CA + (S * x) * CA + i;
 #pragma unroll
                 for (int kx = 0; kx < KW; ++kx) {
-                    const int ix = x * S - P + kx;
-                    const bool ok = vx && oky && (unsigned)ix < (unsigned)a.Wu;
-                    const float* up = a.U + (((long)b * a.Hu + iy) * a.Wu + ix) * a.u_ld + a0 + i;
 #pragma unroll
                     for (int ta = 0; ta < TA; ++ta) {
-                        float uf = (ok && aval[ta]) ? up[ta * 16] : 0.f;
+                        const float uf = ur[kx * CA + ta * 16];
 #pragma unroll
                         for (int tb = 0; tb < TB; ++tb)
                             acc[ky * KW + kx][ta][tb] =
@@ -352,8 +397,46 @@ __global__ __launch_bounds__(256) void wgrad_mfma_k(WgradArgs a) {
             }
         }
     }
+    // fold the four waves through LDS (wave w > 0 publishes, wave 0 accumulates)
+    constexpr int NACC = (TAPS * TA * TB + TB) * 4;
+    for (int w = 1; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+            int q = 0;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) smem[(q++) * 64 + lane] = acc[t][ta][tb][r];
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) smem[(q++) * 64 + lane] = accb[tb][r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            int q = 0;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[t][ta][tb][r] += smem[(q++) * 64 + lane];
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accb[tb][r] += smem[(q++) * 64 + lane];
+        }
+    }
+    static_assert(NACC > 0, "");
+    if (wave != 0) return;
     // D[row = a_local = 4g+r][col = b_local = i]
-    float* dst = a.part + (long)pw * a.pstride;
+    float* dst = a.part + (long)blockIdx.x * a.pstride;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
@@ -446,21 +529,25 @@ struct WreduceArgs {
     int accumulate;
 };
 
-__global__ void wgrad_reduce_k(WreduceArgs a) {
+__global__ __launch_bounds__(256) void wgrad_reduce_k(WreduceArgs a) {
+    __shared__ float sh[4][64];
     const long nel = (long)a.taps * a.Ca * a.Cb + (a.dbias ? a.Cb : 0);
-    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nel) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    const float* p = a.part + e;
-    int k = 0;
-    for (; k + 3 < a.nparts; k += 4) {
-        s0 += p[(long)k * a.pstride];
-        s1 += p[(long)(k + 1) * a.pstride];
-        s2 += p[(long)(k + 2) * a.pstride];
-        s3 += p[(long)(k + 3) * a.pstride];
+    const int el = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * 64 + el;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < nel) {
+        const float* p = a.part + e;
+        int k = pl;
+        for (; k + 4 < a.nparts; k += 8) {
+            s0 += p[(long)k * a.pstride];
+            s1 += p[(long)(k + 4) * a.pstride];
+        }
+        for (; k < a.nparts; k += 4) s0 += p[(long)k * a.pstride];
     }
-    for (; k < a.nparts; ++k) s0 += p[(long)k * a.pstride];
-    float s = (s0 + s1) + (s2 + s3);
+    sh[pl][el] = s0 + s1;
+    __syncthreads();
+    if (pl != 0 || e >= nel) return;
+    const float s = (sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el]);
     const long nw = (long)a.taps * a.Ca * a.Cb;
     if (e < nw) {
         int bb = (int)(e % a.Cb);
@@ -639,10 +726,10 @@ static WgradPlan wgrad_plan(int taps, int B, int Hv, int Ca, int Cb) {
     }
     p.TA = Ca > 16 ? 2 : 1; p.TB = Cb > 16 ? 2 : 1;
     p.nga = cdiv(Ca, p.TA * 16); p.ngb = cdiv(Cb, p.TB * 16);
-    int want = 2048 / (p.nga * p.ngb);       // aim for ~2048 waves overall
-    if (want < 8) want = 8;
+    int want = 768 / (p.nga * p.ngb);        // workgroups along the row axis: ~3 per CU overall
+    if (want < 4) want = 4;
     if (want > nrows) want = nrows;
-    p.rows_per_wave = cdiv(nrows, want);
+    p.rows_per_wave = cdiv(nrows, want);     // rows per WORKGROUP for the LDS-staged kernel
     p.nparts = cdiv(nrows, p.rows_per_wave);
     return p;
 }
@@ -684,18 +771,33 @@ int rv_conv_wgrad(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, co
         return RV_EUNSUPPORTED;
     } else {
         const int TA = plan.TA, TB = plan.TB;
-        dim3 grid(cdiv(a.nparts, 4), plan.nga * plan.ngb), blk(256);
+        dim3 grid(a.nparts, plan.nga * plan.ngb), blk(256);
+        const int KH = mode == 0 ? 3 : (mode == 1 ? 1 : 2), SS = mode == 2 ? 2 : 1;
+        const int Wv4 = (Wv + 3) & ~3;
+        const int UP = SS * (Wv4 - 1) + KH;
+        size_t lds = ((size_t)KH * UP * TA * 16 + (size_t)Wv4 * TB * 16) * sizeof(float);
+        const size_t fold = (size_t)((mode == 0 ? 9 : (mode == 1 ? 1 : 4)) * TA * TB + TB) * 4 * 64 * sizeof(float);
+        if (lds < fold) lds = fold;
+        RV_CHECK_ARG(lds <= 160 * 1024, "rv_conv_wgrad: row of %d pixels x %d channels does not fit LDS", Wv, TA * 16);
+#define RV_WG1(kh, kw, ss, pp, ta, tb)                                                            \
+    do {                                                                                         \
+        auto kern = wgrad_mfma_k<kh, kw, ss, pp, ta, tb>;                                        \
+        if (lds > 64 * 1024)                                                                     \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, grid, blk, lds, st, a);                                         \
+    } while (0)
 #define RV_WG(kh, kw, ss, pp)                                                                     \
     do {                                                                                         \
-        if (TA == 1 && TB == 1) hipLaunchKernelGGL((wgrad_mfma_k<kh, kw, ss, pp, 1, 1>), grid, blk, 0, st, a); \
-        else if (TA == 1 && TB == 2) hipLaunchKernelGGL((wgrad_mfma_k<kh, kw, ss, pp, 1, 2>), grid, blk, 0, st, a); \
-        else if (TA == 2 && TB == 1) hipLaunchKernelGGL((wgrad_mfma_k<kh, kw, ss, pp, 2, 1>), grid, blk, 0, st, a); \
-        else hipLaunchKernelGGL((wgrad_mfma_k<kh, kw, ss, pp, 2, 2>), grid, blk, 0, st, a);      \
+        if (TA == 1 && TB == 1) RV_WG1(kh, kw, ss, pp, 1, 1);                                    \
+        else if (TA == 1 && TB == 2) RV_WG1(kh, kw, ss, pp, 1, 2);                               \
+        else if (TA == 2 && TB == 1) RV_WG1(kh, kw, ss, pp, 2, 1);                               \
+        else RV_WG1(kh, kw, ss, pp, 2, 2);                                                       \
     } while (0)
         if (mode == 0) RV_WG(3, 3, 1, 1);
         else if (mode == 1) RV_WG(1, 1, 1, 0);
         else RV_WG(2, 2, 2, 0);
 #undef RV_WG
+#undef RV_WG1
     }
 reduce:
     RV_LAUNCH_CHECK("rv_conv_wgrad");
@@ -704,7 +806,7 @@ reduce:
         r.part = a.part; r.pstride = a.pstride; r.nparts = a.nparts; r.taps = taps; r.Ca = Ca; r.Cb = Cb;
         r.dw = dw; r.s_a = s_a; r.s_b = s_b; r.flip = flip; r.dbias = dbias; r.accumulate = accumulate;
         long nel = (long)taps * Ca * Cb + (dbias ? Cb : 0);
-        hipLaunchKernelGGL(wgrad_reduce_k, dim3(cdiv(nel, 128)), dim3(128), 0, st, r);
+        hipLaunchKernelGGL(wgrad_reduce_k, dim3(cdiv(nel, 64)), dim3(256), 0, st, r);
         RV_LAUNCH_CHECK("rv_conv_wgrad(reduce)");
     }
     return RV_OK;
