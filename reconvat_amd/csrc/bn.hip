@@ -2,8 +2,8 @@
 //
 // Reference semantics: nn.BatchNorm2d(C, momentum=0.1, eps=1e-5) followed by F.leaky_relu(0.01)
 // (model/UNet_onset.py:183-201, :216-224).  HBM-bound: every kernel streams [P, C] once with
-// coalesced channel-fastest accesses; per-channel sums are carried in fp64 (fp32 per-thread partials
-// over <= 64 pixels, fp64 across threads/blocks) so that var = E[x^2] - mean^2 is safe.
+// coalesced channel-fastest 16-byte accesses; per-channel sums are carried in fp64 (fp32 per-thread
+// partials over <= 16 pixels, fp64 across threads/blocks) so that var = E[x^2] - mean^2 is safe.
 //
 //   stats    : sum / sum-of-squares per channel                    (reads z)
 //   finalize : mean, invstd, scale/shift, running stats, num_batches_tracked
@@ -12,7 +12,7 @@
 //   bwd_apply: dz = scale * (dzh - mean(dzh) - xhat*mean(dzh*xhat)) (reads dy, z, writes dz)
 #include "common.h"
 
-#define BN_PIX_PER_THREAD 64
+#define BN_PIX_PER_THREAD 16
 
 struct BnArgs {
     const float* z; int z_ld;
@@ -28,44 +28,58 @@ struct BnArgs {
     int accumulate;
 };
 
-// thread t -> channel t % C, pixel lane t / C ; PL = 256 / C pixel lanes per block
+// thread t -> channel quad t % (C/4), pixel lane t / (C/4); 16-byte loads, BN_PIX_PER_THREAD pixels each.
 template <bool BWD>
 __global__ __launch_bounds__(256) void bn_reduce_k(BnArgs a) {
-    __shared__ double sh[2][256];
-    const int C = a.C, PL = 256 / C;
+    __shared__ float sh[256 * 8];
+    const int C = a.C, C4 = C >> 2, PL = 256 / C4;
     const int t = threadIdx.x;
-    const int c = t % C, pl = t / C;
-    float s0 = 0.f, s1 = 0.f;
+    const int c = (t % C4) * 4, pl = t / C4;
+    f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (pl < PL) {
-        const long chunk = (long)PL * BN_PIX_PER_THREAD;
-        const long p0 = (long)blockIdx.x * chunk;
-        float mean = 0.f, invstd = 0.f, scale = 0.f, shift = 0.f;
-        if (BWD) { mean = a.coef[c]; invstd = a.coef[C + c]; scale = a.coef[2 * C + c]; shift = a.coef[3 * C + c]; }
+        const long p0 = (long)blockIdx.x * PL * BN_PIX_PER_THREAD;
+        f32x4 mean, invstd, scale, shift;
+        if (BWD) {
+            mean = *reinterpret_cast<const f32x4*>(a.coef + c);
+            invstd = *reinterpret_cast<const f32x4*>(a.coef + C + c);
+            scale = *reinterpret_cast<const f32x4*>(a.coef + 2 * C + c);
+            shift = *reinterpret_cast<const f32x4*>(a.coef + 3 * C + c);
+        }
 #pragma unroll 4
         for (int k = 0; k < BN_PIX_PER_THREAD; ++k) {
-            long p = p0 + pl + (long)k * PL;
+            const long p = p0 + pl + (long)k * PL;
             if (p >= a.P) break;
-            float z = a.z[p * a.z_ld + c];
+            const f32x4 z = *reinterpret_cast<const f32x4*>(a.z + p * a.z_ld + c);
             if (BWD) {
-                float zh = fmaf(z, scale, shift);
-                float d = a.dy[p * a.dy_ld + c];
-                d = zh > 0.f ? d : d * a.slope;
-                s0 += d;
-                s1 += d * ((z - mean) * invstd);
+                const f32x4 d = *reinterpret_cast<const f32x4*>(a.dy + p * a.dy_ld + c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float zh = fmaf(z[q], scale[q], shift[q]);
+                    float dd = zh > 0.f ? d[q] : d[q] * a.slope;
+                    s0[q] += dd;
+                    s1[q] += dd * ((z[q] - mean[q]) * invstd[q]);
+                }
             } else {
                 s0 += z;
-                s1 = fmaf(z, z, s1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s1[q] = fmaf(z[q], z[q], s1[q]);
             }
         }
     }
-    sh[0][t] = (double)s0;
-    sh[1][t] = (double)s1;
+    // sh[(pl*C + ch)*2 + {0,1}]
+    if (pl < PL) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sh[(pl * C + c + q) * 2] = s0[q];
+            sh[(pl * C + c + q) * 2 + 1] = s1[q];
+        }
+    }
     __syncthreads();
-    if (t < C) {
-        double d0 = 0.0, d1 = 0.0;
-        for (int l = 0; l < PL; ++l) { d0 += sh[0][l * C + t]; d1 += sh[1][l * C + t]; }
-        atomicAdd(&a.sums[t], d0);
-        atomicAdd(&a.sums[C + t], d1);
+    if (t < 2 * C) {
+        const int ch = t >> 1, which = t & 1;
+        double d = 0.0;
+        for (int l = 0; l < PL; ++l) d += (double)sh[(l * C + ch) * 2 + which];
+        atomicAdd(&a.sums[which * C + ch], d);
     }
 }
 
@@ -104,40 +118,55 @@ __global__ void bn_finalize_k(BnFinalArgs a) {
     a.coef[3 * a.C + c] = a.beta[c] - mean * scale;
 }
 
-// elementwise, 4 channels per thread (C % 4 == 0)
+// elementwise, 4 channels per thread (C % 4 == 0).  The grid is a multiple of 3 workgroups, so the
+// grid stride is a multiple of every C/4 in the model and a thread keeps ONE channel quad: its
+// coefficients live in registers for the whole kernel.
 template <bool BWD>
 __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
-    const int C4 = a.C >> 2;
+    const int C = a.C, C4 = C >> 2;
     const long total = a.P * C4;
-    const double invn = 1.0 / (double)a.P;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool fixed = (stride % C4) == 0;
+    int c = (int)(idx % C4) * 4;
+    f32x4 mean, invstd, scale, shift, k1, k2;
+    auto fetch = [&](int cc) {
+        scale = *reinterpret_cast<const f32x4*>(a.coef + 2 * C + cc);
+        shift = *reinterpret_cast<const f32x4*>(a.coef + 3 * C + cc);
+        if (BWD) {
+            mean = *reinterpret_cast<const f32x4*>(a.coef + cc);
+            invstd = *reinterpret_cast<const f32x4*>(a.coef + C + cc);
+            const double invn = 1.0 / (double)a.P;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                k1[q] = a.frozen ? 0.f : (float)(a.sums[cc + q] * invn);
+                k2[q] = a.frozen ? 0.f : (float)(a.sums[C + cc + q] * invn);
+            }
+        }
+    };
+    fetch(c);
+    for (; idx < total; idx += stride) {
         const long p = idx / C4;
-        const int c = (int)(idx - p * C4) * 4;
-        f32x4 z = *reinterpret_cast<const f32x4*>(a.z + p * a.z_ld + c);
+        if (!fixed) { c = (int)(idx - p * C4) * 4; fetch(c); }
+        const f32x4 z = *reinterpret_cast<const f32x4*>(a.z + p * a.z_ld + c);
         f32x4 o;
         if (!BWD) {
             f32x4 r = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (a.res) r = *reinterpret_cast<const f32x4*>(a.res + p * a.res_ld + c);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float zh = fmaf(z[k], a.coef[2 * a.C + c + k], a.coef[3 * a.C + c + k]);
-                o[k] = (zh > 0.f ? zh : zh * a.slope) + r[k];
+            for (int q = 0; q < 4; ++q) {
+                float zh = fmaf(z[q], scale[q], shift[q]);
+                o[q] = (zh > 0.f ? zh : zh * a.slope) + r[q];
             }
         } else {
-            f32x4 d = *reinterpret_cast<const f32x4*>(a.dy + p * a.dy_ld + c);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(a.dy + p * a.dy_ld + c);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int cc = c + k;
-                const float mean = a.coef[cc], invstd = a.coef[a.C + cc], scale = a.coef[2 * a.C + cc],
-                            shift = a.coef[3 * a.C + cc];
-                float zh = fmaf(z[k], scale, shift);
-                float dz = zh > 0.f ? d[k] : d[k] * a.slope;
-                if (!a.frozen) {
-                    float xh = (z[k] - mean) * invstd;
-                    float k1 = (float)(a.sums[cc] * invn), k2 = (float)(a.sums[a.C + cc] * invn);
-                    dz = dz - k1 - xh * k2;
-                }
-                o[k] = dz * scale;
+            for (int q = 0; q < 4; ++q) {
+                float zh = fmaf(z[q], scale[q], shift[q]);
+                float dz = zh > 0.f ? d[q] : d[q] * a.slope;
+                float xh = (z[q] - mean[q]) * invstd[q];
+                dz = dz - k1[q] - xh * k2[q];
+                o[q] = dz * scale[q];
             }
         }
         float* dst = a.out + p * a.out_ld + c;
@@ -148,11 +177,18 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
         *reinterpret_cast<f32x4*>(dst) = o;
     }
     if (BWD && blockIdx.x == 0 && a.dgamma) {
-        for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
-            a.dgamma[c] = (float)a.sums[a.C + c];
-            a.dbeta[c] = (float)a.sums[c];
+        for (int cc = threadIdx.x; cc < a.C; cc += blockDim.x) {
+            a.dgamma[cc] = (float)a.sums[a.C + cc];
+            a.dbeta[cc] = (float)a.sums[cc];
         }
     }
+}
+
+static int bn_apply_blocks(long total) {
+    long b = (total + 255) / 256;
+    if (b > 3072) b = 3072;
+    b = ((b + 2) / 3) * 3;          // multiple of 3: see bn_apply_k
+    return (int)b;
 }
 
 extern "C" {
@@ -164,13 +200,13 @@ int rv_bn_lrelu_fwd(const float* z, int z_ld, long P, int C, const float* gamma,
                     float* running_var, long* num_batches_tracked, float momentum, float eps, int training, float slope,
                     const float* res, int res_ld, float* y, int y_ld, float* coef, void* workspace, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    RV_CHECK_ARG(C % 4 == 0 && C <= 256, "rv_bn_lrelu_fwd: C=%d must be a multiple of 4 and <= 256", C);
+    RV_CHECK_ARG(C % 4 == 0 && C <= 128, "rv_bn_lrelu_fwd: C=%d must be a multiple of 4 and <= 128", C);
     RV_CHECK_ARG((z_ld % 4) == 0 && (y_ld % 4) == 0 && (!res || (res_ld % 4) == 0), "rv_bn_lrelu_fwd: strides must be multiples of 4");
     BnArgs a = {};
     a.z = z; a.z_ld = z_ld; a.P = P; a.C = C; a.sums = (double*)workspace; a.slope = slope;
     if (training) {
         (void)hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, st);
-        const int PL = 256 / C;
+        const int PL = 256 / (C / 4);
         hipLaunchKernelGGL(bn_reduce_k<false>, dim3(cdiv(P, (long)PL * BN_PIX_PER_THREAD)), dim3(256), 0, st, a);
         RV_LAUNCH_CHECK("rv_bn_lrelu_fwd(stats)");
     }
@@ -181,9 +217,7 @@ int rv_bn_lrelu_fwd(const float* z, int z_ld, long P, int C, const float* gamma,
     hipLaunchKernelGGL(bn_finalize_k, dim3(cdiv(C, 64)), dim3(64), 0, st, f);
     RV_LAUNCH_CHECK("rv_bn_lrelu_fwd(finalize)");
     a.coef = coef; a.out = y; a.out_ld = y_ld; a.res = res; a.res_ld = res_ld;
-    long total = P * (C / 4);
-    int blocks = (int)(total / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(bn_apply_k<false>, dim3(blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bn_apply_k<false>, dim3(bn_apply_blocks(P * (C / 4))), dim3(256), 0, st, a);
     RV_LAUNCH_CHECK("rv_bn_lrelu_fwd(apply)");
     return RV_OK;
 }
@@ -192,19 +226,17 @@ int rv_bn_lrelu_fwd(const float* z, int z_ld, long P, int C, const float* gamma,
 int rv_bn_lrelu_bwd(const float* dy, int dy_ld, const float* z, int z_ld, long P, int C, const float* coef, float slope,
                     int frozen, float* dz, int dz_ld, float* dgamma, float* dbeta, void* workspace, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    RV_CHECK_ARG(C % 4 == 0 && C <= 256, "rv_bn_lrelu_bwd: C=%d must be a multiple of 4 and <= 256", C);
+    RV_CHECK_ARG(C % 4 == 0 && C <= 128, "rv_bn_lrelu_bwd: C=%d must be a multiple of 4 and <= 128", C);
     BnArgs a = {};
     a.z = z; a.z_ld = z_ld; a.dy = dy; a.dy_ld = dy_ld; a.P = P; a.C = C; a.sums = (double*)workspace;
     a.coef = coef; a.slope = slope; a.frozen = frozen; a.out = dz; a.out_ld = dz_ld; a.dgamma = dgamma; a.dbeta = dbeta;
     if (!frozen || dgamma) {
         (void)hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, st);
-        const int PL = 256 / C;
+        const int PL = 256 / (C / 4);
         hipLaunchKernelGGL(bn_reduce_k<true>, dim3(cdiv(P, (long)PL * BN_PIX_PER_THREAD)), dim3(256), 0, st, a);
         RV_LAUNCH_CHECK("rv_bn_lrelu_bwd(reduce)");
     }
-    long total = P * (C / 4);
-    int blocks = (int)(total / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(bn_apply_k<true>, dim3(blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bn_apply_k<true>, dim3(bn_apply_blocks(P * (C / 4))), dim3(256), 0, st, a);
     RV_LAUNCH_CHECK("rv_bn_lrelu_bwd(apply)");
     return RV_OK;
 }

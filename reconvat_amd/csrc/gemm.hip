@@ -4,15 +4,19 @@
 //   C[m][n] (+)= act( sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] + bias[n] )
 //
 // One kernel covers forward (X @ W^T), input-gradient (dY @ W) and weight-gradient (dY^T @ X, split
-// along the reduction dimension) through the strides.  64x64 block tile, BK = 16, four waves each
-// owning a 32x32 sub-tile.  The MFMA is issued as D^T = B^T A^T so that an accumulator lane holds four
-// consecutive n of one m (16-byte stores along the contiguous dimension of C).
+// along the reduction dimension) through the strides.  64x64 block tile, BK = 32, four waves each
+// owning a 32x32 sub-tile.  Operand tiles are fetched with 16-byte loads along whichever dimension is
+// contiguous in memory (scalar fallback for unaligned rows such as K = 229), kept in registers while
+// the previous tile is multiplied (software prefetch) and written to LDS in the matching orientation.
+// The MFMA is issued as D^T = B^T A^T so that an accumulator lane holds four consecutive n of one m
+// (16-byte stores along the contiguous dimension of C).
 #include "common.h"
 
 #define GBM 64
 #define GBN 64
-#define GBK 16
-#define GPAD 4
+#define GBK 32
+#define LDK (GBK + 4)    // row stride of a [rows][k] tile
+#define LDM (GBM + 4)    // row stride of a [k][rows] tile
 
 struct GemmArgs {
     const float* A; long sam, sak;
@@ -24,12 +28,63 @@ struct GemmArgs {
     int act;            // 0 none, 1 sigmoid
     int accumulate;     // C += (plain read-modify-write; requires splitk == 1)
     int splitk;         // >1: K split over blockIdx.z, atomicAdd epilogue (C pre-zeroed by the host wrapper)
-    int a_kfast, b_kfast;   // which global dimension is contiguous (load mapping only)
+    int a_vec, b_vec;   // 16-byte loads along the contiguous dimension are legal
 };
 
+// One operand tile: `rows` (m or n) x GBK.  KFAST: memory is contiguous along k -> LDS layout [row][k];
+// otherwise contiguous along the row index -> LDS layout [k][row].  Each thread owns 8 elements = 2 float4.
+template <bool KFAST>
+struct TileIO {
+    f32x4 r[2];
+    __device__ __forceinline__ void load(const float* base, long s_row, long s_k, int row0, int nrows, int k0, int k_end,
+                                         bool vec, int tid) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int idx = tid + e * 256;
+            int row, k;
+            if (KFAST) { row = idx >> 3; k = (idx & 7) * 4; } else { k = idx >> 4; row = (idx & 15) * 4; }
+            const int gr = row0 + row, gk = k0 + k;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (KFAST) {
+                if (gr < nrows) {
+                    const float* p = base + (long)gr * s_row + (long)gk * s_k;
+                    if (vec && gk + 3 < k_end) v = *reinterpret_cast<const f32x4*>(p);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (gk + j < k_end) v[j] = p[(long)j * s_k];
+                    }
+                }
+            } else {
+                if (gk < k_end) {
+                    const float* p = base + (long)gr * s_row + (long)gk * s_k;
+                    if (vec && gr + 3 < nrows) v = *reinterpret_cast<const f32x4*>(p);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (gr + j < nrows) v[j] = p[(long)j * s_row];
+                    }
+                }
+            }
+            r[e] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float* lds, int tid) const {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int idx = tid + e * 256;
+            if (KFAST) { int row = idx >> 3, k = (idx & 7) * 4; *reinterpret_cast<f32x4*>(lds + row * LDK + k) = r[e]; }
+            else { int k = idx >> 4, row = (idx & 15) * 4; *reinterpret_cast<f32x4*>(lds + k * LDM + row) = r[e]; }
+        }
+    }
+    // element (row, k) of the staged tile
+    static __device__ __forceinline__ float at(const float* lds, int row, int k) {
+        return KFAST ? lds[row * LDK + k] : lds[k * LDM + row];
+    }
+};
+
+template <bool AK, bool BK_>
 __global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a) {
-    __shared__ float As[GBK][GBM + GPAD];
-    __shared__ float Bs[GBK][GBN + GPAD];
+    __shared__ __attribute__((aligned(16))) float As[GBM * LDK > GBK * LDM ? GBM * LDK : GBK * LDM];
+    __shared__ __attribute__((aligned(16))) float Bs[GBN * LDK > GBK * LDM ? GBN * LDK : GBK * LDM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
@@ -44,28 +99,28 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a) {
 #pragma unroll
         for (int y = 0; y < 2; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    TileIO<AK> ta;
+    TileIO<BK_> tb;
+    if (k_begin < k_end) {
+        ta.load(a.A, a.sam, a.sak, m0, a.M, k_begin, k_end, a.a_vec, tid);
+        tb.load(a.B, a.sbn, a.sbk, n0, a.N, k_begin, k_end, a.b_vec, tid);
+    }
     for (int k0 = k_begin; k0 < k_end; k0 += GBK) {
-        // stage A tile [GBK][GBM] and B tile [GBK][GBN]: 1024 elements each, 4 per thread
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            int idx = e * 256 + tid;
-            int kk, mm;
-            if (a.a_kfast) { kk = idx & 15; mm = idx >> 4; } else { mm = idx & 63; kk = idx >> 6; }
-            int gm = m0 + mm, gk = k0 + kk;
-            As[kk][mm] = (gm < a.M && gk < k_end) ? a.A[(long)gm * a.sam + (long)gk * a.sak] : 0.f;
-            int kb, nn;
-            if (a.b_kfast) { kb = idx & 15; nn = idx >> 4; } else { nn = idx & 63; kb = idx >> 6; }
-            int gn = n0 + nn, gkb = k0 + kb;
-            Bs[kb][nn] = (gn < a.N && gkb < k_end) ? a.B[(long)gkb * a.sbk + (long)gn * a.sbn] : 0.f;
-        }
+        __syncthreads();                    // previous tile fully consumed
+        ta.store(As, tid);
+        tb.store(Bs, tid);
         __syncthreads();
+        if (k0 + GBK < k_end) {             // prefetch the next tile while this one is multiplied
+            ta.load(a.A, a.sam, a.sak, m0, a.M, k0 + GBK, k_end, a.a_vec, tid);
+            tb.load(a.B, a.sbn, a.sbk, n0, a.N, k0 + GBK, k_end, a.b_vec, tid);
+        }
 #pragma unroll
         for (int ks = 0; ks < GBK; ks += 4) {
             float af[2], bf[2];
 #pragma unroll
-            for (int y = 0; y < 2; ++y) af[y] = As[ks + g][wm + y * 16 + li];
+            for (int y = 0; y < 2; ++y) af[y] = TileIO<AK>::at(As, wm + y * 16 + li, ks + g);
 #pragma unroll
-            for (int x = 0; x < 2; ++x) bf[x] = Bs[ks + g][wn + x * 16 + li];
+            for (int x = 0; x < 2; ++x) bf[x] = TileIO<BK_>::at(Bs, wn + x * 16 + li, ks + g);
 #pragma unroll
             for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -73,7 +128,6 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a) {
                     // D[row = n_local][col = m_local] : A-operand = B tile (i = n), B-operand = A tile (j = m)
                     acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[x], af[y], acc[x][y], 0, 0, 0);
         }
-        __syncthreads();
     }
 
     const bool vec_ok = a.scn == 1 && (a.scm & 3) == 0 && ((((uintptr_t)a.C) & 15) == 0) && a.splitk == 1 && !a.C2;
@@ -85,12 +139,10 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a) {
             const int nb = n0 + wn + x * 16 + 4 * g;
             if (m >= a.M || nb >= a.N) continue;
             f32x4 v = acc[x][y];
-            if (a.splitk == 1 || blockIdx.z == 0) {
-                if (a.bias) {
+            if (a.bias && (a.splitk == 1 || blockIdx.z == 0)) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (nb + r < a.N) v[r] += a.bias[nb + r];
-                }
+                for (int r = 0; r < 4; ++r)
+                    if (nb + r < a.N) v[r] += a.bias[nb + r];
             }
             if (a.act == 1) {
 #pragma unroll
@@ -135,13 +187,20 @@ int rv_gemm(const float* A, long sam, long sak, const float* B, long sbk, long s
     a.A = A; a.sam = sam; a.sak = sak; a.B = B; a.sbk = sbk; a.sbn = sbn; a.C = C; a.scm = scm; a.scn = scn;
     a.C2 = C2; a.sc2m = sc2m; a.sc2n = sc2n; a.bias = bias; a.M = M; a.N = N; a.K = K; a.act = act;
     a.accumulate = accumulate; a.splitk = splitk;
-    a.a_kfast = (sak <= sam); a.b_kfast = (sbk <= sbn);
+    const bool a_kfast = (sak <= sam), b_kfast = (sbk <= sbn);
+    // 16-byte loads need a unit stride along the fast dimension, a 16-byte multiple along the slow one and an
+    // aligned base; K-split offsets are multiples of GBK so they preserve alignment
+    a.a_vec = ((a_kfast ? sak : sam) == 1) && (((a_kfast ? sam : sak) & 3) == 0) && ((((uintptr_t)A) & 15) == 0);
+    a.b_vec = ((b_kfast ? sbk : sbn) == 1) && (((b_kfast ? sbn : sbk) & 3) == 0) && ((((uintptr_t)B) & 15) == 0);
     if (splitk > 1) {
         hipLaunchKernelGGL(zero_strided_k, dim3(cdiv((long)M * N, 256)), dim3(256), 0, st, C, scm, scn, M, N);
         RV_LAUNCH_CHECK("rv_gemm(zero)");
     }
     dim3 grid(cdiv(N, GBN), cdiv(M, GBM), splitk);
-    hipLaunchKernelGGL(gemm_mfma_k, grid, dim3(256), 0, st, a);
+    if (a_kfast && b_kfast) hipLaunchKernelGGL((gemm_mfma_k<true, true>), grid, dim3(256), 0, st, a);
+    else if (a_kfast && !b_kfast) hipLaunchKernelGGL((gemm_mfma_k<true, false>), grid, dim3(256), 0, st, a);
+    else if (!a_kfast && b_kfast) hipLaunchKernelGGL((gemm_mfma_k<false, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_mfma_k<false, false>), grid, dim3(256), 0, st, a);
     RV_LAUNCH_CHECK("rv_gemm");
     return RV_OK;
 }
