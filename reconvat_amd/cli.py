@@ -1,0 +1,161 @@
+"""Shared body of the two drop-in training entry points (train_UNet_Onset_VAT.py / train_UNet_VAT.py).
+
+Keeps the reference CLI (`python train_UNet_Onset_VAT.py with key=value ...`, keys and defaults of
+train_UNet_Onset_VAT.py:28-78 / train_UNet_VAT.py:26-79) and loop semantics (:128-154): epochs of
+`iteration` optimiser steps through train_VAT_model, a checkpoint every `saving_freq` epochs
+(model-{ep}.pt + last-optimizer-state.pt), scalar logging of every loss key per epoch.
+MI355X-side additions: one process per GPU under torch.distributed.run (data-parallel, ONE flat RCCL
+gradient all-reduce per step), the fused FlatAdam, optional whole-step hipGraph replay (`graph=True`) and
+`train_on=Synthetic`.
+"""
+import json
+import os
+from datetime import datetime
+
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader
+
+from . import UNet_Onset, UNet
+from .dataset import prepare_VAT_dataset
+from .train import FlatAdam, TrainStep, train_VAT_model, cycle
+
+ds_ksize, ds_stride = (2, 2), (2, 2)
+mode = 'imagewise'
+logging_freq = 100
+saving_freq = 200
+
+
+def base_config(o, onset_script):
+    """Config scope shared by both scripts; `o` holds CLI overrides (needed for the derived entries)."""
+    c = dict(
+        root='runs', device='cuda:0', log=True, w_size=31, spec='Mel', resume_iteration=None,
+        train_on='MAPS' if onset_script else 'Wind', n_heads=4, position=True, iteration=10, VAT_start=0, alpha=1,
+        VAT=True, XI=1e-6, eps=2, small=False, supersmall=False, onset_stack=True,
+        KL_Div=False, reconstruction=False, batch_size=8,
+        train_batch_size=8 if onset_script else 1, sequence_length=327680, epoches=20000,
+        step_size_up=100, max_lr=1e-4, learning_rate=1e-3, learning_rate_decay_steps=1000,
+        learning_rate_decay_rate=0.98, leave_one_out=None, clip_gradient_norm=3, refresh=False,
+        # MI355X-side extras (not in the reference)
+        graph=False, fused_optimizer=True, saving_freq=saving_freq,
+    )
+    c.update(o)
+    if torch.cuda.is_available() and torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory < 10e9:
+        if 'batch_size' not in o:
+            c['batch_size'] //= 2
+        if 'sequence_length' not in o:
+            c['sequence_length'] //= 2
+        print(f"Reducing batch size to {c['batch_size']} and sequence_length to {c['sequence_length']} to save memory")
+    c.setdefault('validation_length', c['sequence_length'])
+    if 'validation_length' not in o:
+        c['validation_length'] = c['sequence_length']
+    stamp = datetime.now().strftime('%y%m%d-%H%M%S')
+    if 'logdir' not in o:
+        if onset_script:
+            c['logdir'] = (f"{c['root']}/Unet_Onset-recons={c['reconstruction']}-XI={c['XI']}-eps={c['eps']}-alpha={c['alpha']}"
+                           f"-train_on=small_{c['small']}_{c['train_on']}-w_size={c['w_size']}-n_heads={c['n_heads']}"
+                           f"-lr={c['learning_rate']}-" + stamp)
+        else:
+            c['logdir'] = (f"{c['root']}/Unet-recons={c['reconstruction']}-XI={c['XI']}-eps={c['eps']}-alpha={c['alpha']}"
+                           f"-train_on=small_{c['small']}_{c['train_on']}-w_size={c['w_size']}-n_heads={c['n_heads']}"
+                           f"-lr={c['learning_rate']}-" + stamp)
+    return c
+
+
+class ScalarLog:
+    """TensorBoard SummaryWriter when available, else one JSON line per (tag, step)."""
+
+    def __init__(self, logdir):
+        os.makedirs(logdir, exist_ok=True)
+        try:
+            from torch.utils.tensorboard import SummaryWriter
+            self.tb = SummaryWriter(logdir)
+        except Exception:  # noqa: BLE001 -- tensorboard is optional
+            self.tb = None
+        self.f = open(os.path.join(logdir, 'scalars.jsonl'), 'a')
+
+    def add_scalar(self, tag, value, global_step):
+        if self.tb is not None:
+            self.tb.add_scalar(tag, value, global_step=global_step)
+        self.f.write(json.dumps({'tag': tag, 'value': value, 'step': global_step}) + '\n')
+        self.f.flush()
+
+
+def run_training(onset_script, spec, resume_iteration, train_on, batch_size, sequence_length, small, supersmall,
+                 train_batch_size, learning_rate, learning_rate_decay_steps, learning_rate_decay_rate, alpha,
+                 clip_gradient_norm, validation_length, refresh, device, epoches, logdir, log, iteration, VAT_start, VAT,
+                 XI, eps, reconstruction, graph, fused_optimizer, saving_freq, **_unused):
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1:
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        device = f'cuda:{local}'
+        torch.cuda.set_device(local)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device(device))
+    elif str(device).startswith('cuda'):
+        torch.cuda.set_device(torch.device(device))
+
+    l_set, ul_set, val_set, _full = prepare_VAT_dataset(sequence_length=sequence_length, validation_length=validation_length,
+                                                        refresh=refresh, device=device, small=small, supersmall=supersmall,
+                                                        dataset=train_on, rank=rank)
+    ul_loader = DataLoader(ul_set, batch_size, shuffle=True, drop_last=True) if VAT else None
+    l_loader = DataLoader(l_set, train_batch_size, shuffle=True, drop_last=True)
+
+    cls = UNet_Onset if onset_script else UNet
+    torch.manual_seed(0)                                   # identical initial weights on every rank
+    model = cls(ds_ksize, ds_stride, log=log, reconstruction=reconstruction, mode=mode, spec=spec, device=device, XI=XI, eps=eps)
+    if resume_iteration is not None:
+        sd = torch.load(os.path.join(logdir, f'model-{resume_iteration}.pt'), map_location='cpu')
+        model.load_state_dict(sd)
+    model.to(device)
+    torch.manual_seed(1 + rank)
+    scheduler = None
+    if fused_optimizer:
+        optimizer = FlatAdam(model.parameters(), lr=learning_rate, step_size=learning_rate_decay_steps,
+                             gamma=learning_rate_decay_rate, data_parallel=world > 1)
+    else:
+        optimizer = torch.optim.Adam(model.parameters(), learning_rate)
+        scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=learning_rate_decay_steps, gamma=learning_rate_decay_rate)
+    if resume_iteration is not None:
+        optimizer.load_state_dict(torch.load(os.path.join(logdir, 'last-optimizer-state.pt'), map_location=device))
+    n_params = sum(p.numel() for p in model.parameters())
+    if rank == 0:
+        print(f'{cls.__name__}: {n_params} parameters, world size {world}, device {device}')
+    writer = ScalarLog(logdir) if rank == 0 else None
+
+    step_runner = None
+    for ep in range(1, epoches + 1):
+        use_vat = VAT and ep >= VAT_start
+        if graph and fused_optimizer:
+            # whole-step hipGraph replay on static buffers (same loop semantics as train_VAT_model)
+            model.train()
+            li, ui = cycle(l_loader), (cycle(ul_loader) if use_vat else None)
+            total = 0.0
+            for _ in range(iteration):
+                bl = next(li)
+                bul = next(ui) if use_vat else None
+                if step_runner is None or step_runner.VAT != use_vat:
+                    step_runner = TrainStep(model, optimizer, bl, bul, alpha=alpha, VAT=use_vat, clip=clip_gradient_norm, graph=True)
+                else:
+                    step_runner.load(bl, bul)
+                total += float(step_runner())
+            losses = step_runner.losses
+            if rank == 0:
+                print(f'Train Epoch: {ep}\tLoss: {total / iteration:.6f}')
+        else:
+            _, losses, optimizer = train_VAT_model(model, iteration, ep, l_loader, ul_loader if VAT else None, optimizer,
+                                                   scheduler, clip_gradient_norm, alpha, VAT, VAT_start)
+        if rank == 0:
+            for key, value in losses.items():
+                writer.add_scalar(key, float(value), ep)
+            if ep % saving_freq == 0:
+                torch.save(model.state_dict(), os.path.join(logdir, f'model-{ep}.pt'))
+                torch.save(optimizer.state_dict(), os.path.join(logdir, 'last-optimizer-state.pt'))
+    if rank == 0:
+        torch.save(model.state_dict(), os.path.join(logdir, 'model-final.pt'))
+        print('Training finished. (Full-song MAPS evaluation needs mir_eval, which is outside the MI355X hot path: '
+              'load model-final.pt into the reference\'s evaluate.py for note/frame F1.)')
+    if world > 1:
+        dist.destroy_process_group()
+    return model

@@ -76,7 +76,7 @@ class FlatAdam:
     Parameters that never receive a gradient keep a zero gradient and zero moments -> they do not move,
     which is what torch.optim.Adam does by skipping them (6 such tensors in UNet_Onset)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, step_size=1000, gamma=0.98):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, step_size=1000, gamma=0.98, data_parallel=False):
         self.params = [p for p in params if p.requires_grad]
         assert self.params, 'no trainable parameters'
         dev = self.params[0].device
@@ -101,6 +101,7 @@ class FlatAdam:
         self.n = n
         self.lr, self.betas, self.eps, self.step_size, self.gamma = lr, betas, eps, step_size, gamma
         self.grad_scale = 1.0
+        self.data_parallel = data_parallel      # all-reduce the flat bucket inside step()
         ops.invalidate_weight_cache()
 
     def zero_grad(self, set_to_none=False):
@@ -110,6 +111,8 @@ class FlatAdam:
                 p.grad = self.flat_grad[off:off + p.numel()].view_as(p.data)
 
     def step(self):
+        if self.data_parallel:
+            allreduce_gradients(self)
         call('rv_adam_step', ptr(self.flat_param), ptr(self.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n,
              ptr(self.step_count), self.lr, self.step_size, self.gamma, self.betas[0], self.betas[1], self.eps,
              self.grad_scale, stream())
@@ -197,7 +200,8 @@ class TrainStep:
         else:
             self.model.train()
             self._fwd_bwd()
-        allreduce_gradients(self.opt)
+        if not self.opt.data_parallel:
+            allreduce_gradients(self.opt)
         self.opt.step()
         if self.clip:
             self.opt.clip_grad_norm_(self.clip)

@@ -1,0 +1,104 @@
+"""CPU tests of the host-side logic around the hot path: CLI parsing (sacred-compatible `with k=v`), config
+scope, loss weighting, dataset crop rule, state_dict surface, data-parallel bucket (gloo, world size 2)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cli_parsing_and_config_scope():
+    from reconvat_amd.sacred_lite import parse_cli, Experiment, ConfigError
+    from reconvat_amd.cli import base_config
+    o = parse_cli(['with', 'train_on=MAPS', 'small=True', 'supersmall=True', 'VAT=False', 'reconstruction=False',
+                   'device=cpu', 'XI=1e-6', 'eps=2', 'root=my_runs'])
+    assert o == {'train_on': 'MAPS', 'small': True, 'supersmall': True, 'VAT': False, 'reconstruction': False,
+                 'device': 'cpu', 'XI': 1e-6, 'eps': 2, 'root': 'my_runs'}
+    for onset in (True, False):                      # BASELINE.json config 1 uses supersmall on train_UNet_VAT.py
+        ex = Experiment('t')
+        ex.config(lambda ov, onset=onset: base_config(ov, onset))
+        cfg = ex.build_config(o)
+        assert cfg['batch_size'] == 8 and cfg['sequence_length'] == 327680 and cfg['learning_rate'] == 1e-3
+        assert cfg['train_batch_size'] == (8 if onset else 1)
+        assert cfg['logdir'].startswith('my_runs/Unet')          # derived entry sees the override
+        assert cfg['validation_length'] == cfg['sequence_length']
+        with pytest.raises(ConfigError):
+            ex.build_config({'no_such_key': 1})
+    assert base_config({}, True)['train_on'] == 'MAPS' and base_config({}, False)['train_on'] == 'Wind'
+
+
+def test_weighted_loss_rule():
+    from reconvat_amd.train import weighted_loss
+    losses = {'loss/train_frame': torch.tensor(1.0), 'loss/train_LDS_l_frame': torch.tensor(2.0),
+              'loss/train_LDS_ul_onset': torch.tensor(4.0), 'loss/train_r_norm_l': torch.tensor(0.5)}
+    assert float(weighted_loss(losses, alpha=1)) == 1.0 + 1.0 + 2.0 + 0.5
+    assert float(weighted_loss(losses, alpha=3)) == 1.0 + 3.0 + 6.0 + 0.5
+
+
+def test_dataset_crop_rule(tmp_path):
+    """PianoRollAudioDataset.__getitem__ (reference model/dataset.py:35-69): RandomState(42) crop, label decode."""
+    from reconvat_amd.dataset import CachedFolder
+    rng = np.random.RandomState(0)
+    audio = torch.from_numpy(rng.randint(-2000, 2000, size=60000).astype(np.int16))
+    label = torch.from_numpy(rng.randint(0, 4, size=(60000 // 512 + 1, 88)).astype(np.uint8))
+    os.makedirs(tmp_path / 'g')
+    torch.save(dict(path='x.flac', audio=audio, label=label, velocity=label.clone()), tmp_path / 'g' / 'x.pt')
+    ds = CachedFolder(str(tmp_path), ('g',), sequence_length=16384, seed=42)
+    item = ds[0]
+    step_begin = np.random.RandomState(42).randint(60000 - 16384) // 512
+    assert item['start_idx'] == step_begin * 512
+    assert item['audio'].shape == (16384,) and item['frame'].shape == (32, 88)
+    assert torch.equal(item['audio'], audio[step_begin * 512: step_begin * 512 + 16384].float() / 32768.0)
+    lab = label[step_begin:step_begin + 32]
+    assert torch.equal(item['onset'], (lab == 3).float()) and torch.equal(item['frame'], (lab > 1).float())
+    assert torch.equal(item['offset'], (lab == 1).float())
+
+
+def test_state_dict_surface_matches_reference_keys():
+    import reconvat_amd as ra
+    from oracle import fixture as fx
+    for kind, cls in (('onset', ra.UNet_Onset), ('frame', ra.UNet)):
+        for recon in (True, False):
+            m = cls((2, 2), (2, 2), log=True, reconstruction=recon, mode='imagewise', spec='Mel', XI=1e-6, eps=2)
+            sd = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+            want = dict(fx.param_shapes(kind, recon))
+            want.update({'spectrogram.mel_basis': (229, 1025), 'spectrogram.stft.wsin': (1025, 1, 2048),
+                         'spectrogram.stft.wcos': (1025, 1, 2048), 'spectrogram.stft.window_mask': (1, 2048, 1)})
+            assert sd == want
+            m.load_state_dict(fx.fixture_params(kind, recon))          # strict
+    m = ra.UNet_Onset((2, 2), (2, 2), log=True, reconstruction=True, mode='imagewise', spec='Mel')
+    assert sum(p.numel() for p in m.parameters()) == 3639256         # flat gradient bucket size
+
+
+DP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from reconvat_amd.train import allreduce_gradients
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:' + sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+class Bucket:                      # the flat-bucket contract FlatAdam exposes
+    pass
+b = Bucket(); rank = dist.get_rank()
+b.flat_grad = torch.arange(10, dtype=torch.float32) * (rank + 1)
+b.grad_scale = 1.0
+allreduce_gradients(b)
+assert torch.equal(b.flat_grad, torch.arange(10, dtype=torch.float32) * 3), b.flat_grad
+assert b.grad_scale == 0.5
+dist.barrier(); dist.destroy_process_group()
+print('ok', rank)
+'''
+
+
+def test_data_parallel_bucket_gloo(tmp_path):
+    """World size 2 over gloo on CPU: ONE all-reduce(sum) of the flat bucket, mean folded into grad_scale."""
+    script = tmp_path / 'w.py'
+    script.write_text(DP_WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
