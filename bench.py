@@ -73,7 +73,7 @@ def measure_conv_phase(step_fn, device):
     groups = {}
     for name, a in records:
         if name == 'rv_conv_fwd':
-            sig = (name, a[0]) + tuple(a[2:7]) + tuple(a[8:12])
+            sig = (name, a[0]) + tuple(a[2:7]) + tuple(a[8:12]) + (a[15],)
         else:
             sig = (name, a[0]) + tuple(a[2:6]) + tuple(a[7:12])
         g = groups.setdefault(sig, {'count': 0, 'name': name, 'args': a})

@@ -40,14 +40,15 @@ int rv_melspec_lognorm_fwd(const float* audio, long audio_stride, int B, int nsa
  *   value(tap,k,n) = w[k*s_k + n*s_n + (flip ? taps-1-tap : tap)];  scatter_cmid>0: 2x2/s2 scatter GEMM.
  * rv_conv_fwd mode: 0 = 3x3 s1 p1, 1 = 1x1, 2 = 2x2/s2 gather (down fwd, up dgrad), 3 = 2x2/s2 scatter
  *   (ConvTranspose2d(k=2,s=2)(x, output_size=...) fwd, down dgrad).  Forward AND input-gradient of
- *   every layer are instances of it (the packing decides which).
+ *   every layer are instances of it (the packing decides which).  algo: 0 default, 1 LDS-free direct kernel,
+ *   2 LDS/DMA-pipelined kernel (3x3 only) -- the host autotunes 1 vs 2 per layer shape.
  * rv_conv_wgrad: G[tap][a][b] = sum_p U[f(p,tap)][a]*V[p][b] (+ column sums of V for the bias), written
  *   to dw[a*s_a + b*s_b + tap'] / dbias[b]; mode 0 = 3x3, 1 = 1x1, 2 = 2x2/s2. */
 long rv_packed_weight_floats(int taps, int kdim, int ndim);
 int rv_pack_weights(const float* w, float* out, int taps, int kdim, int ndim, long s_k, long s_n, int flip,
                     int scatter_cmid, int force_plain, void* stream);
 int rv_conv_fwd(int mode, const float* in, int in_ld, int B, int H, int W, int Cin, float* out, int out_ld, int Ho,
-                int Wo, int Cout, const float* wpack, const float* bias, int accumulate, void* stream);
+                int Wo, int Cout, const float* wpack, const float* bias, int accumulate, int algo, void* stream);
 long rv_conv_wgrad_workspace_bytes(int taps, int B, int Hv, int Ca, int Cb);
 int rv_conv_wgrad(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, const float* V, int v_ld, int Hv, int Wv,
                   int Cb, int B, float* dw, long s_a, long s_b, int flip, float* dbias, int accumulate, void* workspace,

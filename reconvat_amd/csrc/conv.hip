@@ -24,6 +24,7 @@
 // Weight gradients are pixel-reduction GEMMs (wgrad_mfma): per-wave partial sums are written to a
 // workspace and folded by a deterministic second pass (no atomics).
 #include "common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------
 // weight packing
@@ -223,6 +224,173 @@ __global__ __launch_bounds__(256) void conv_mfma_k(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// LDS-resident, DMA-pipelined 3x3 (stride 1, pad 1) implicit GEMM: forward and input-gradient of every
+// 3x3 Conv2d / ConvTranspose2d with Cin % 8 == 0.
+//
+// A persistent workgroup walks a run of vertically adjacent bands (TH output rows x full width) for NT
+// n-tiles of output channels.  Unit of work = (band, 4R-channel chunk of Cin): its TH+2 input rows (one
+// pixel of zero halo left/right) and its 9*NT packed weight fragments sit in LDS, so the tap loop is
+// ds_read_b128 + MFMA only and every input element is fetched once per band instead of once per tap.
+// Units are DOUBLE-BUFFERED in LDS and filled by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip,
+// no ds_write pass): unit u+1 is in flight while unit u is multiplied; one s_waitcnt vmcnt(0) + barrier
+// per unit.  M-tiles are 16 consecutive pixels of the flattened band (no waste on the odd widths);
+// tile t belongs to wave t % 4.  Accumulator layout / epilogue as conv_mfma_k.
+// ------------------------------------------------------------------------------------------
+struct ConvLdsArgs {
+    ConvArgs c;
+    int TH, nbands, total_bands, bands_per_wg;
+};
+
+__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
+    // LDS destination = wave-uniform base + lane*16 bytes (hardware adds the lane offset)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int R, int NT, int MTW>
+__global__ __launch_bounds__(256) void conv3x3_lds_k(ConvLdsArgs aa) {
+    typedef typename VecR<R>::T vec;
+    constexpr int KC = 4 * R;                    // channels per chunk
+    constexpr int Q = R;                         // float4 per staged pixel (KC/4)
+    constexpr int PPI = 64 / Q;                  // pixels per DMA wave-instruction
+    constexpr int LPF = 16 * R;                  // lanes (float4) per weight fragment
+    constexpr int FPI = 64 / LPF;                // fragments per DMA wave-instruction
+    constexpr int WFLOATS = 9 * NT * 64 * R;
+    const ConvArgs& a = aa.c;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int W = a.W, H = a.H, W2 = W + 2, TH = aa.TH;
+    const int nrow = TH + 2;
+    const int xfloats = nrow * W2 * KC;
+    const int nt0 = blockIdx.y * NT;
+    float* xs0 = smem;                                   // [2][nrow][W2][KC]
+    float* ws0 = smem + 2 * xfloats;                     // [2][9][NT][64][R]
+    const int band_lo = blockIdx.x * aa.bands_per_wg;
+    const int band_hi = min(band_lo + aa.bands_per_wg, aa.total_bands);
+    if (band_lo >= band_hi) return;
+    const int nchunk = a.nchunk;
+    const int nunits = (band_hi - band_lo) * nchunk;
+    const int ipr = (W + PPI - 1) / PPI;                 // DMA instructions per input row
+
+    auto stage = [&](int u) {
+        const int band = band_lo + u / nchunk, c = u - (u / nchunk) * nchunk;
+        const int b = band / aa.nbands, y0 = (band - b * aa.nbands) * TH;
+        float* xb = xs0 + (u & 1) * xfloats;
+        const float* src0 = a.in + (long)b * H * W * a.in_ld + c * KC;
+        const int nx = nrow * ipr;
+        for (int i = wave; i < nx; i += 4) {
+            const int row = i / ipr, k = i - row * ipr;
+            const int gy = y0 - 1 + row;
+            const int px = k * PPI + lane / Q, q = lane - (lane / Q) * Q;
+            float* ldst = xb + (row * W2 + 1 + k * PPI) * KC;            // wave-uniform
+            if (px < W) {
+                if (gy >= 0 && gy < H) glds16(src0 + ((long)gy * W + px) * a.in_ld + q * 4, ldst);
+                else *reinterpret_cast<f32x4*>(ldst + lane * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (nchunk > 1 || u == 0) {
+            float* wb = ws0 + ((nchunk > 1) ? (u & 1) : 0) * WFLOATS;
+            constexpr int NW = (9 * NT + FPI - 1) / FPI;
+            for (int i = wave; i < NW; i += 4) {
+                const int f = i * FPI + lane / LPF, o = lane - (lane / LPF) * LPF;
+                if (f < 9 * NT) {
+                    const int tap = f / NT, n = f - tap * NT;
+                    glds16(a.wpack + (((long)tap * nchunk + c) * a.ntile_n + nt0 + n) * 64 * R + o * 4, wb + i * 256);
+                }
+            }
+        }
+    };
+
+    // halo columns of both buffers are zero for the whole kernel (the DMA never touches them)
+    for (int k = tid; k < 2 * nrow * 2 * KC; k += 256) {
+        const int buf = k / (nrow * 2 * KC), rem = k - buf * (nrow * 2 * KC);
+        const int row = rem / (2 * KC), rem2 = rem - row * (2 * KC);
+        const int side = rem2 / KC, ch = rem2 - side * KC;
+        xs0[buf * xfloats + (row * W2 + (side ? W + 1 : 0)) * KC + ch] = 0.f;
+    }
+
+    f32x4 acc[MTW][NT];
+    int lbase[MTW];
+    bool pv[MTW];
+    stage(0);
+    for (int u = 0; u < nunits; ++u) {
+        const int band = band_lo + u / nchunk, c = u - (u / nchunk) * nchunk;
+        const int b = band / aa.nbands, y0 = (band - b * aa.nbands) * TH;
+        const int th = min(TH, H - y0);
+        const int npx = th * W;
+        const int ntile = (npx + 15) >> 4;
+        if (c == 0) {
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int t = wave + 4 * m;
+                const int p = t * 16 + j;
+                pv[m] = t < ntile && p < npx;
+                const int pp = pv[m] ? p : 0;
+                const int ty = pp / W, tx = pp - ty * W;
+                lbase[m] = (ty * W2 + tx) * KC + g * R;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of unit u has landed
+        __syncthreads();                                    // ... and everyone's; unit u-1's buffer is free
+        if (u + 1 < nunits) stage(u + 1);                   // DMA runs under the MFMAs below
+        const float* xs = xs0 + (u & 1) * xfloats;
+        const float* ws = ws0 + ((nchunk > 1) ? (u & 1) : 0) * WFLOATS;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tap = ky * 3 + kx;
+                vec wf[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) wf[n] = *reinterpret_cast<const vec*>(ws + ((tap * NT + n) * 64 + lane) * R);
+                const int toff = (ky * W2 + kx) * KC;
+                vec xf[MTW];
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) xf[m] = *reinterpret_cast<const vec*>(xs + lbase[m] + toff);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int m = 0; m < MTW; ++m)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][r], xf[m][r], acc[m][n], 0, 0, 0);
+            }
+        if (c != nchunk - 1) continue;
+        // epilogue of this band
+        const long pix0 = ((long)b * H + y0) * W;
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            if (!pv[m]) continue;
+            const long opix = pix0 + (wave + 4 * m) * 16 + j;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int co0 = (nt0 + n) * 16 + 4 * g;
+                if (co0 >= a.Cout) continue;
+                float* o = a.out + opix * a.out_ld + co0;
+                f32x4 v = acc[m][n];
+                if (a.bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co0 + r < a.Cout) v[r] += a.bias[co0 + r];
+                }
+                if (a.vec_store && co0 + 3 < a.Cout) {
+                    if (a.accumulate) { f32x4 old = *reinterpret_cast<f32x4*>(o); v += old; }
+                    *reinterpret_cast<f32x4*>(o) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co0 + r < a.Cout) o[r] = a.accumulate ? o[r] + v[r] : v[r];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // small-channel convolution on the VALU (Cin==1, or Cout<=2): pure bandwidth kernels
 // ------------------------------------------------------------------------------------------
 struct SmallArgs {
@@ -235,16 +403,22 @@ struct SmallArgs {
     int accumulate;
 };
 
+// COUT >= 4: four output channels per thread (COUT/4 threads per pixel) so that a wave's stores are
+// contiguous 16-byte pieces; COUT < 4: one thread per pixel.
 template <int CIN, int COUT, int KH, int KW, int S, int P>
 __global__ __launch_bounds__(256) void conv_small_k(SmallArgs a) {
-    long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int CPT = COUT >= 4 ? 4 : COUT;        // output channels per thread
+    constexpr int TPP = COUT / CPT;                  // threads per pixel
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long p = t / TPP;
+    const int c0 = (int)(t - p * TPP) * CPT;
     if (p >= a.npix) return;
     int b = (int)(p / ((long)a.Ho * a.Wo));
     int rem = (int)(p - (long)b * a.Ho * a.Wo);
     int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-    float acc[COUT];
+    float acc[CPT];
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) acc[co] = a.bias ? a.bias[co] : 0.f;
+    for (int co = 0; co < CPT; ++co) acc[co] = a.bias ? a.bias[c0 + co] : 0.f;
 #pragma unroll
     for (int ky = 0; ky < KH; ++ky)
 #pragma unroll
@@ -252,7 +426,7 @@ __global__ __launch_bounds__(256) void conv_small_k(SmallArgs a) {
             int iy = oy * S - P + ky, ix = ox * S - P + kx;
             if ((unsigned)iy >= (unsigned)a.H || (unsigned)ix >= (unsigned)a.W) continue;
             const float* src = a.in + (((long)b * a.H + iy) * a.W + ix) * a.in_ld;
-            const float* w = a.wplain + (ky * KW + kx) * CIN * COUT;
+            const float* w = a.wplain + (ky * KW + kx) * CIN * COUT + c0;
             float xin[CIN];
             if constexpr (CIN % 4 == 0) {
 #pragma unroll
@@ -267,11 +441,19 @@ __global__ __launch_bounds__(256) void conv_small_k(SmallArgs a) {
 #pragma unroll
             for (int c = 0; c < CIN; ++c)
 #pragma unroll
-                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(xin[c], w[c * COUT + co], acc[co]);
+                for (int co = 0; co < CPT; ++co) acc[co] = fmaf(xin[c], w[c * COUT + co], acc[co]);
         }
-    float* o = a.out + p * a.out_ld;
+    float* o = a.out + p * a.out_ld + c0;
+    if constexpr (CPT == 4) {
+        f32x4 v = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+        if ((a.out_ld & 3) == 0) {
+            if (a.accumulate) { f32x4 old = *reinterpret_cast<f32x4*>(o); v += old; }
+            *reinterpret_cast<f32x4*>(o) = v;
+            return;
+        }
+    }
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) o[co] = a.accumulate ? o[co] + acc[co] : acc[co];
+    for (int co = 0; co < CPT; ++co) o[co] = a.accumulate ? o[co] + acc[co] : acc[co];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -605,9 +787,107 @@ static void choose_tiles(long ntiles, int ntile_n, int* NT, int* MT) {
     *NT = best_nt; *MT = best_mt;
 }
 
+// LDS-pipelined 3x3 launch: pick (NT, MTW, TH) so that two units fit LDS and the persistent grid covers the chip
+static size_t conv3x3_lds_bytes(int R, int NT, int TH, int W, int nchunk) {
+    return ((size_t)2 * (TH + 2) * (W + 2) * 4 * R + (size_t)(nchunk > 1 ? 2 : 1) * 9 * NT * 64 * R) * sizeof(float);
+}
+
+template <int R>
+static int launch_conv3x3_lds_r(const ConvArgs& a, int NT, int MTW, int TH, int wgs_per_cu, hipStream_t st) {
+    ConvLdsArgs aa;
+    aa.c = a; aa.TH = TH; aa.nbands = cdiv(a.H, TH);
+    aa.total_bands = a.B * aa.nbands;
+    const int nsplit = a.ntile_n / NT;
+    int wgs = (256 * wgs_per_cu) / nsplit;
+    if (wgs < 1) wgs = 1;
+    if (wgs > aa.total_bands) wgs = aa.total_bands;
+    aa.bands_per_wg = cdiv(aa.total_bands, wgs);
+    wgs = cdiv(aa.total_bands, aa.bands_per_wg);
+    const size_t lds = conv3x3_lds_bytes(R, NT, TH, a.W, a.nchunk);
+    dim3 grid(wgs, nsplit), blk(256);
+#define RV_L3(nt, mt)                                                                              \
+    if (NT == nt && MTW == mt) {                                                                  \
+        auto kern = conv3x3_lds_k<R, nt, mt>;                                                     \
+        static bool attr_done = false;                                                            \
+        if (!attr_done) {                                                                         \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_done = true;                                                                     \
+        }                                                                                         \
+        hipLaunchKernelGGL(kern, grid, blk, lds, st, aa);                                         \
+        return RV_OK;                                                                             \
+    }
+    RV_L3(1, 1) RV_L3(1, 2) RV_L3(1, 4) RV_L3(1, 8)
+    RV_L3(2, 1) RV_L3(2, 2) RV_L3(2, 4) RV_L3(2, 8)
+    RV_L3(3, 1) RV_L3(3, 2) RV_L3(3, 4) RV_L3(3, 8)
+    RV_L3(4, 1) RV_L3(4, 2) RV_L3(4, 4) RV_L3(4, 8)
+#undef RV_L3
+    return RV_EUNSUPPORTED;
+}
+
+static int launch_conv3x3_lds(const ConvArgs& a, int R, hipStream_t st) {
+    static const int mts[4] = {8, 4, 2, 1};
+    // search (NT, MTW): prefer large tiles, but need >= ~1.5 units per workgroup slot on the chip
+    int best_nt = 0, best_mt = 0, best_th = 0, best_wpc = 1;
+    long best_score = -1;
+    for (int nt = 4; nt >= 1; --nt) {
+        if (a.ntile_n % nt) continue;
+        for (int k = 0; k < 4; ++k) {
+            const int mt = mts[k];
+            if (nt * mt > 16 && !(nt <= 2 && mt == 8)) continue;          // accumulator budget
+            int th = (mt * 64) / a.W;
+            if (th > a.H) th = a.H;
+            if (th < 1) continue;
+            const size_t lds = conv3x3_lds_bytes(R, nt, th, a.W, a.nchunk);
+            if (lds > 150 * 1024) continue;
+            const int wpc = lds <= 76 * 1024 ? 2 : 1;                      // workgroups per CU
+            const long bands = (long)a.B * cdiv(a.H, th) * (a.ntile_n / nt);
+            const long slots = 256L * wpc;
+            // efficiency model: work per slot in whole bands (tail effect) x register-level reuse
+            const long rounds = (bands + slots - 1) / slots;
+            const long fill = (bands * 100) / (rounds * slots);            // 0..100
+            const long reuse = (long)(nt * mt * 100) / (nt + mt);
+            const long score = fill * (50 + reuse);
+            if (score > best_score) { best_score = score; best_nt = nt; best_mt = mt; best_th = th; best_wpc = wpc; }
+        }
+    }
+    if (!best_nt) return RV_EUNSUPPORTED;
+    return R == 4 ? launch_conv3x3_lds_r<4>(a, best_nt, best_mt, best_th, best_wpc, st)
+                  : launch_conv3x3_lds_r<2>(a, best_nt, best_mt, best_th, best_wpc, st);
+}
+
 static int frag_R(int kdim) { return (kdim % 16 == 0) ? 4 : ((kdim % 8 == 0) ? 2 : 0); }
 
+// ---- profiling aid: raw f32 MFMA issue rate (NACC independent accumulators per wave) -------------------------
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_peak_k(float* out, int iters, float seed) {
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float a0 = seed + threadIdx.x, b0 = seed * 0.5f + threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0 + r, b0 + i, acc[i], 0, 0, 0);
+    }
+    f32x4 s = acc[0];
+#pragma unroll
+    for (int i = 1; i < NACC; ++i) s += acc[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
 extern "C" {
+
+// profiling aid: nacc in {2,4,8}; returns 0.  FLOPs = blocks*4 waves*iters*4*nacc*2048
+int rv_debug_mfma_peak(float* out, int blocks, int iters, int nacc, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (nacc == 2) hipLaunchKernelGGL(mfma_peak_k<2>, dim3(blocks), dim3(256), 0, st, out, iters, 1.0f);
+    else if (nacc == 4) hipLaunchKernelGGL(mfma_peak_k<4>, dim3(blocks), dim3(256), 0, st, out, iters, 1.0f);
+    else hipLaunchKernelGGL(mfma_peak_k<8>, dim3(blocks), dim3(256), 0, st, out, iters, 1.0f);
+    RV_LAUNCH_CHECK("rv_debug_mfma_peak");
+    return RV_OK;
+}
 
 // Size (floats) of the packed fragment buffer for a logical Wm[taps][kdim][ndim].
 long rv_packed_weight_floats(int taps, int kdim, int ndim) {
@@ -643,10 +923,11 @@ int rv_pack_weights(const float* w, float* out, int taps, int kdim, int ndim, lo
 }
 
 // mode: 0 = 3x3 s1 p1, 1 = 1x1, 2 = 2x2 s2 gather (down fwd / up dgrad), 3 = 2x2 s2 scatter (up fwd / down dgrad)
+// algo: 0 = default, 1 = direct (LDS-free) kernel, 2 = LDS/DMA-pipelined kernel (mode 0 only)
 // in  : [B,H,W,*] pixel stride in_ld, Cin channels read from the pointer
 // out : [B,Ho,Wo,*] pixel stride out_ld, Cout channels written
 int rv_conv_fwd(int mode, const float* in, int in_ld, int B, int H, int W, int Cin, float* out, int out_ld, int Ho,
-                int Wo, int Cout, const float* wpack, const float* bias, int accumulate, void* stream) {
+                int Wo, int Cout, const float* wpack, const float* bias, int accumulate, int algo, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     RV_CHECK_ARG(mode >= 0 && mode <= 3, "rv_conv_fwd: bad mode %d", mode);
     if (mode == 0 || mode == 1) RV_CHECK_ARG(Ho == H && Wo == W, "rv_conv_fwd: same-size conv needs Ho==H, Wo==W");
@@ -660,7 +941,8 @@ int rv_conv_fwd(int mode, const float* in, int in_ld, int B, int H, int W, int C
         SmallArgs s;
         s.in = in; s.in_ld = in_ld; s.H = H; s.W = W; s.out = out; s.out_ld = out_ld; s.Ho = Ho; s.Wo = Wo;
         s.B = B; s.wplain = wpack; s.bias = bias; s.npix = (long)B * Ho * Wo; s.accumulate = accumulate;
-        dim3 grid(cdiv(s.npix, 256)), blk(256);
+        const int tpp = Cout >= 4 ? Cout / 4 : 1;
+        dim3 grid(cdiv(s.npix * tpp, 256)), blk(256);
 #define RV_SMALL(ci, co, kh, kw, ss, pp)                                                          \
     if (Cin == ci && Cout == co) {                                                               \
         hipLaunchKernelGGL((conv_small_k<ci, co, kh, kw, ss, pp>), grid, blk, 0, st, s);         \
@@ -694,6 +976,12 @@ int rv_conv_fwd(int mode, const float* in, int in_ld, int B, int H, int W, int C
         a.Ph = Ho; a.Pw = Wo;
     }
     a.npix = (long)B * a.Ph * a.Pw;
+    // algo: 0 = library default, 1 = LDS-free direct kernel, 2 = LDS/DMA-pipelined kernel (3x3 only; falls back
+    // to the direct kernel when the shape does not fit).  The host autotunes 1 vs 2 per layer shape.
+    if (mode == 0 && algo != 1) {
+        int rc3 = launch_conv3x3_lds(a, R, st);
+        if (rc3 == RV_OK) { RV_LAUNCH_CHECK("rv_conv_fwd(lds)"); return RV_OK; }
+    }
     int NT, MT;
     choose_tiles((a.npix + 15) / 16, a.ntile_n, &NT, &MT);
     int rc = RV_EUNSUPPORTED;

@@ -101,21 +101,53 @@ _FWD_MODE = {'c3': 0, 't3': 0, 'c1': 1, 'down': 2, 'up': 3}
 _DGRAD_MODE = {'c3': 0, 't3': 0, 'c1': 1, 'down': 3, 'up': 2}
 
 
+_algo_cache = {}
+AUTOTUNE = True
+
+
+def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias):
+    """rv_conv_fwd with a per-shape choice between the LDS-free and the LDS/DMA-pipelined 3x3 kernel.  The first
+    eager call of a shape times both (HIP events on the launch stream) and caches the winner; under hipGraph
+    capture an untuned shape uses the library default."""
+    args = (mode, ptr(x), ild, bb, h, wd, cin, ptr(out), old, ho, wo, cout, ptr(wpack), ptr(bias), 0)
+    algo = 0
+    if mode == 0 and AUTOTUNE:
+        key = (bb, h, wd, cin, cout, ild, old)
+        algo = _algo_cache.get(key, -1)
+        if algo < 0:
+            if torch.cuda.is_current_stream_capturing():
+                algo = 0
+            else:
+                best, algo = None, 0
+                st = torch.cuda.current_stream()
+                for cand in (1, 2):
+                    call('rv_conv_fwd', *args, cand, st.cuda_stream)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(st)
+                    for _ in range(3):
+                        call('rv_conv_fwd', *args, cand, st.cuda_stream)
+                    e1.record(st)
+                    e1.synchronize()
+                    t = e0.elapsed_time(e1)
+                    if best is None or t < best:
+                        best, algo = t, cand
+                _algo_cache[key] = algo
+    call('rv_conv_fwd', *args, algo, stream())
+
+
 def conv_forward_into(kind, x, w, b, out):
     """out (NHWC view) = conv(x) ; shapes are taken from the views."""
     need_gpu(x, w, out)
     bb, h, wd, cin, ild = _geom(x)
     _, ho, wo, cout, old = _geom(out)
-    call('rv_conv_fwd', _FWD_MODE[kind], ptr(x), ild, bb, h, wd, cin, ptr(out), old, ho, wo, cout,
-         ptr(_pack(kind, w, 'fwd')), ptr(b), 0, stream())
+    _conv_call(_FWD_MODE[kind], x, ild, bb, h, wd, cin, out, old, ho, wo, cout, _pack(kind, w, 'fwd'), b)
 
 
 def conv_dgrad_into(kind, dy, w, dx):
     """dx (NHWC view) = input gradient of the conv given dy (NHWC view)."""
     bb, h, wd, c, ild = _geom(dy)
     _, ho, wo, co, old = _geom(dx)
-    call('rv_conv_fwd', _DGRAD_MODE[kind], ptr(dy), ild, bb, h, wd, c, ptr(dx), old, ho, wo, co,
-         ptr(_pack(kind, w, 'dgrad')), None, 0, stream())
+    _conv_call(_DGRAD_MODE[kind], dy, ild, bb, h, wd, c, dx, old, ho, wo, co, _pack(kind, w, 'dgrad'), None)
 
 
 def conv_wgrad(kind, x, dy, w, want_bias=True):
