@@ -60,7 +60,8 @@ int rv_bn_lrelu_fwd(const float* z, int z_ld, long P, int C, const float* gamma,
                     float* running_var, long* num_batches_tracked, float momentum, float eps, int training, float slope,
                     const float* res, int res_ld, float* y, int y_ld, float* coef, void* workspace, void* stream);
 int rv_bn_lrelu_bwd(const float* dy, int dy_ld, const float* z, int z_ld, long P, int C, const float* coef, float slope,
-                    int frozen, float* dz, int dz_ld, float* dgamma, float* dbeta, void* workspace, void* stream);
+                    int frozen, float* dz, int dz_ld, float* dgamma, float* dbeta, int param_accumulate, void* workspace,
+                    void* stream);
 
 /* ---- linear layers (nn.Linear / torch.sigmoid call sites, model/UNet_onset.py:50-52,62-64,275,
  * 292-293,307-313,324,330): C[m*scm+n*scn] (+)= act(sum_k A[m*sam+k*sak]*B[k*sbk+n*sbn] + bias[n]) */

@@ -26,6 +26,7 @@ struct BnArgs {
     int frozen;              // eval-mode statistics: no batch-mean terms in the backward
     float* dgamma; float* dbeta;
     int accumulate;
+    int param_accumulate;    // dgamma/dbeta are added into the destination instead of overwriting it
 };
 
 // thread t -> channel quad t % (C/4), pixel lane t / (C/4); 16-byte loads, BN_PIX_PER_THREAD pixels each.
@@ -178,8 +179,9 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
     }
     if (BWD && blockIdx.x == 0 && a.dgamma) {
         for (int cc = threadIdx.x; cc < a.C; cc += blockDim.x) {
-            a.dgamma[cc] = (float)a.sums[a.C + cc];
-            a.dbeta[cc] = (float)a.sums[cc];
+            const float dg = (float)a.sums[a.C + cc], db = (float)a.sums[cc];
+            a.dgamma[cc] = a.param_accumulate ? a.dgamma[cc] + dg : dg;
+            a.dbeta[cc] = a.param_accumulate ? a.dbeta[cc] + db : db;
         }
     }
 }
@@ -223,13 +225,15 @@ int rv_bn_lrelu_fwd(const float* z, int z_ld, long P, int C, const float* gamma,
 }
 
 // dz (and dgamma/dbeta when non-null) from dy; z and coef are the forward's.  frozen != 0: eval-mode BN.
+// param_accumulate != 0: dgamma/dbeta are added into their destinations (gradient accumulation).
 int rv_bn_lrelu_bwd(const float* dy, int dy_ld, const float* z, int z_ld, long P, int C, const float* coef, float slope,
-                    int frozen, float* dz, int dz_ld, float* dgamma, float* dbeta, void* workspace, void* stream) {
+                    int frozen, float* dz, int dz_ld, float* dgamma, float* dbeta, int param_accumulate, void* workspace,
+                    void* stream) {
     hipStream_t st = (hipStream_t)stream;
     RV_CHECK_ARG(C % 4 == 0 && C <= 128, "rv_bn_lrelu_bwd: C=%d must be a multiple of 4 and <= 128", C);
     BnArgs a = {};
     a.z = z; a.z_ld = z_ld; a.dy = dy; a.dy_ld = dy_ld; a.P = P; a.C = C; a.sums = (double*)workspace;
-    a.coef = coef; a.slope = slope; a.frozen = frozen; a.out = dz; a.out_ld = dz_ld; a.dgamma = dgamma; a.dbeta = dbeta;
+    a.coef = coef; a.slope = slope; a.frozen = frozen; a.out = dz; a.out_ld = dz_ld; a.dgamma = dgamma; a.dbeta = dbeta; a.param_accumulate = param_accumulate;
     if (!frozen || dgamma) {
         (void)hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, st);
         const int PL = 256 / (C / 4);

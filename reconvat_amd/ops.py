@@ -16,6 +16,27 @@ BN_MOMENTUM = 0.1       # model/UNet_onset.py:183
 BN_EPS = 1e-5
 
 _EPOCH = [0]
+_DIRECT = [False]
+
+
+class direct_param_grads:
+    """Context manager: while active, conv / BatchNorm backward kernels ACCUMULATE their parameter gradients
+    straight into the pre-allocated ``param.grad`` buffers (FlatAdam's flat gradient bucket) and hand autograd
+    ``None`` for them -- this removes one add kernel per parameter per graph.  Only for loops that consume
+    ``param.grad`` (TrainStep); ``torch.autograd.grad(..., params)`` would not see these gradients."""
+
+    def __enter__(self):
+        self.prev = _DIRECT[0]
+        _DIRECT[0] = True
+
+    def __exit__(self, *exc):
+        _DIRECT[0] = self.prev
+
+
+def _grad_buf(t):
+    if _DIRECT[0] and t is not None and t.requires_grad and t.grad is not None:
+        return t.grad
+    return None
 
 
 def invalidate_weight_cache():
@@ -150,12 +171,16 @@ def conv_dgrad_into(kind, dy, w, dx):
     _conv_call(_DGRAD_MODE[kind], dy, ild, bb, h, wd, c, dx, old, ho, wo, co, _pack(kind, w, 'dgrad'), None)
 
 
-def conv_wgrad(kind, x, dy, w, want_bias=True):
-    """(dw, db) in the PyTorch layouts of `w` / bias."""
+def conv_wgrad(kind, x, dy, w, want_bias=True, dw_acc=None, db_acc=None):
+    """(dw, db) in the PyTorch layouts of `w` / bias; with dw_acc/db_acc the results are ADDED into those buffers."""
     bb, h, wd, cin, xld = _geom(x)
     _, ho, wo, cout, yld = _geom(dy)
-    dw = torch.empty_like(w)
-    db = torch.empty(cout, device=w.device, dtype=torch.float32) if want_bias else None
+    acc = 1 if dw_acc is not None else 0
+    dw = dw_acc if acc else torch.empty_like(w)
+    if not want_bias:
+        db = None
+    else:
+        db = db_acc if acc else torch.empty(cout, device=w.device, dtype=torch.float32)
     lib = _lib.load()
     if kind == 'up':
         # G[tap][a=co][b=ci] = sum_p dY[2p+tap][co] * X[p][ci]  -> dWt[ci][co][tap]
@@ -177,10 +202,10 @@ def conv_wgrad(kind, x, dy, w, want_bias=True):
     nbytes = lib.rv_conv_wgrad_workspace_bytes(taps, bb, hv, ca, cb)
     ws = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
     call('rv_conv_wgrad', mode, ptr(u), uld, hu, wu, ca, ptr(v), vld, hv, wv, cb, bb, ptr(dw), s_a, s_b, flip,
-         bias_ptr, 0, ptr(ws), nbytes, stream())
+         bias_ptr, acc, ptr(ws), nbytes, stream())
     if kind == 'up' and want_bias:
-        call('rv_colsum', ptr(dy), yld, bb * ho * wo, cout, ptr(db), 0, stream())
-    return dw, db
+        call('rv_colsum', ptr(dy), yld, bb * ho * wo, cout, ptr(db), acc, stream())
+    return (None, None) if acc else (dw, db)
 
 
 def _out_hw(kind, h, w, size):
@@ -204,6 +229,7 @@ class ConvFn(Function):
         ctx.kind = kind
         ctx.xshape = tuple(x.shape)
         ctx.save_for_backward(x if ctx.needs_input_grad[1] else None, w)
+        ctx.params = (w, b)          # parameter objects (for direct gradient accumulation)
         return y
 
     @staticmethod
@@ -215,7 +241,12 @@ class ConvFn(Function):
             dx = torch.empty(ctx.xshape, device=dy.device, dtype=torch.float32)
             conv_dgrad_into(ctx.kind, dy, w, dx)
         if ctx.needs_input_grad[1]:
-            dw, db = conv_wgrad(ctx.kind, x, dy, w, ctx.needs_input_grad[2])
+            pw, pb = ctx.params
+            gw, gb = _grad_buf(pw), _grad_buf(pb)
+            if gw is not None and (gb is not None or not ctx.needs_input_grad[2]):
+                conv_wgrad(ctx.kind, x, dy, w, ctx.needs_input_grad[2], gw, gb)
+            else:
+                dw, db = conv_wgrad(ctx.kind, x, dy, w, ctx.needs_input_grad[2])
         return dx, dw, db, None, None
 
 
@@ -237,6 +268,7 @@ class UpCatFn(Function):
         ctx.shapes = (tuple(x.shape), tuple(s.shape))
         need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[4]
         ctx.save_for_backward(x if need_w else None, s if need_w else None, w_up, w_skip)
+        ctx.params = (w_up, b_up, w_skip, b_skip)
         return cat
 
     @staticmethod
@@ -252,10 +284,19 @@ class UpCatFn(Function):
         if ctx.needs_input_grad[3]:
             ds = torch.empty(ctx.shapes[1], device=dcat.device, dtype=torch.float32)
             conv_dgrad_into('c3', d_sk, w_skip, ds)
+        pwu, pbu, pws, pbs = ctx.params
         if ctx.needs_input_grad[1]:
-            dwu, dbu = conv_wgrad('up', x, d_up, w_up, True)
+            gw, gb = _grad_buf(pwu), _grad_buf(pbu)
+            if gw is not None and gb is not None:
+                conv_wgrad('up', x, d_up, w_up, True, gw, gb)
+            else:
+                dwu, dbu = conv_wgrad('up', x, d_up, w_up, True)
         if ctx.needs_input_grad[4]:
-            dws, dbs = conv_wgrad('c3', s, d_sk, w_skip, True)
+            gw, gb = _grad_buf(pws), _grad_buf(pbs)
+            if gw is not None and gb is not None:
+                conv_wgrad('c3', s, d_sk, w_skip, True, gw, gb)
+            else:
+                dws, dbs = conv_wgrad('c3', s, d_sk, w_skip, True)
         return dx, dwu, dbu, ds, dws, dbs, None
 
 
@@ -279,6 +320,7 @@ class BnActFn(Function):
              BN_MOMENTUM, BN_EPS, 1 if training else 0, slope, ptr(res), rld, ptr(y), c, ptr(coef), ptr(ws), stream())
         ctx.training = training
         ctx.slope = slope
+        ctx.params = (gamma, beta)
         ctx.save_for_backward(z, coef)
         return y
 
@@ -290,11 +332,19 @@ class BnActFn(Function):
         p = bb * h * wd
         need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dz = torch.empty_like(z, memory_format=torch.contiguous_format)
-        dg = torch.empty(c, device=z.device, dtype=torch.float32) if need_w else None
-        db = torch.empty(c, device=z.device, dtype=torch.float32) if need_w else None
+        pg, pb = ctx.params
+        gg, gb = (_grad_buf(pg), _grad_buf(pb)) if need_w else (None, None)
+        direct = gg is not None and gb is not None
+        if direct:
+            dg, db = gg, gb
+        else:
+            dg = torch.empty(c, device=z.device, dtype=torch.float32) if need_w else None
+            db = torch.empty(c, device=z.device, dtype=torch.float32) if need_w else None
         ws = torch.empty(2 * c, device=z.device, dtype=torch.float64)
         call('rv_bn_lrelu_bwd', ptr(dy), c, ptr(z), zld, p, c, ptr(coef), ctx.slope, 0 if ctx.training else 1,
-             ptr(dz), c, ptr(dg), ptr(db), ptr(ws), stream())
+             ptr(dz), c, ptr(dg), ptr(db), 1 if direct else 0, ptr(ws), stream())
+        if direct:
+            dg = db = None
         dres = dy if ctx.needs_input_grad[6] else None
         return (dz if ctx.needs_input_grad[0] else None), dg, db, None, None, None, dres, None, None
 

@@ -264,6 +264,30 @@ def test_backward_vs_oracle(dev, kind):
             assert rel_err(b, p64[k]) < 1e-4, k
 
 
+def test_direct_grad_accumulation(dev):
+    """ops.direct_param_grads() (kernels accumulate conv/BN parameter gradients straight into the flat bucket)
+    gives the same bucket as ordinary autograd accumulation."""
+    import reconvat_amd as ra
+    from reconvat_amd import ops
+    bl, bul = _batches(dev)
+    grads = []
+    for direct in (False, True):
+        m = build('onset', True, dev)
+        opt = ra.FlatAdam(m.parameters(), lr=1e-3)
+        opt.zero_grad()
+        if direct:
+            with ops.direct_param_grads():
+                _, losses, _ = m.run_on_batch(bl, None, False)
+                ra.weighted_loss(losses, 1.0).backward()
+        else:
+            _, losses, _ = m.run_on_batch(bl, None, False)
+            ra.weighted_loss(losses, 1.0).backward()
+        grads.append(opt.flat_grad.clone())
+    assert float(grads[0].abs().max()) > 0
+    err = (grads[0] - grads[1]).abs().max().item()
+    assert err <= 1e-5 * grads[0].abs().max().item(), err
+
+
 def test_graph_capture_matches_eager(dev):
     """The hipGraph-replayed step computes the same losses as eager launches on the same inputs."""
     import reconvat_amd as ra
