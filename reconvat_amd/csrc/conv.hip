@@ -479,8 +479,11 @@ struct WgradArgs {
 template <int KH, int KW, int S, int P, int TA, int TB>
 __global__ __launch_bounds__(256) void wgrad_mfma_k(WgradArgs a) {
     constexpr int TAPS = KH * KW, CA = TA * 16, CB = TB * 16;
+    constexpr int C4A = CA / 4, C4B = CB / 4;
+    constexpr int NSLOT = (S == 1) ? KH + 1 : 2 * KH;      // input-row ring: one slot ahead of the rows in use
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
     const int ga = blockIdx.y / a.ngb, gb = blockIdx.y - ga * a.ngb;
     const int a0 = ga * CA, b0 = gb * CB;
@@ -488,10 +491,10 @@ __global__ __launch_bounds__(256) void wgrad_mfma_k(WgradArgs a) {
     const int row0 = blockIdx.x * a.rows_per_wave;          // rows per WORKGROUP here
     const int row1 = min(row0 + a.rows_per_wave, nrows);
     const int Wv4 = (a.Wv + 3) & ~3;
-    const int UP = S * (Wv4 - 1) + KW + (S == 1 ? 0 : 0);    // pixels per staged input row (incl. zero padding)
-    float* ubuf = smem;                                      // [KH][UP][CA]
-    float* vbuf = smem + KH * UP * CA;                       // [Wv4][CB]
-    const int stage_floats = KH * UP * CA + Wv4 * CB;
+    const int UP = S * (Wv4 - 1) + KW;                       // pixels per staged input row (incl. zero padding)
+    float* ubuf = smem;                                      // [NSLOT][UP][CA]
+    float* vbuf = smem + NSLOT * UP * CA;                    // [2][Wv4][CB]
+    const int stage_floats = NSLOT * UP * CA + 2 * Wv4 * CB;
 
     f32x4 acc[TAPS][TA][TB];
     f32x4 accb[TB];
@@ -505,58 +508,77 @@ __global__ __launch_bounds__(256) void wgrad_mfma_k(WgradArgs a) {
     for (int y = 0; y < TB; ++y) accb[y] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bool do_bias = a.want_bias && ga == 0;
 
-    for (int k = tid; k < stage_floats; k += 256) smem[k] = 0.f;   // padding stays zero for the whole kernel
+    for (int k = tid; k < stage_floats; k += 256) smem[k] = 0.f;   // padding / unused channels stay zero
     __syncthreads();
 
-    // channel validity of this workgroup's float4 columns
     const int ca_valid = min(CA, a.Ca - a0), cb_valid = min(CB, a.Cb - b0);
+    const int npxu = min(a.Wu, UP - P);
 
-    auto load_urow = [&](int b, int r, int slot) {
-        float* dst = ubuf + slot * UP * CA + P * CA;
+    // LDS-DMA of one input row (image b, row r) into ring slot `slot`; rows outside the image are zero-filled
+    auto dma_urow = [&](int b, int r, int slot) {
+        constexpr int PPI = 64 / C4A;
+        float* dst0 = ubuf + slot * UP * CA + P * CA;
         const bool inside = r >= 0 && r < a.Hu;
         const float* src = a.U + ((long)b * a.Hu + (inside ? r : 0)) * a.Wu * a.u_ld + a0;
-        constexpr int C4 = CA / 4;
-        const int npx = min(a.Wu, UP - P);
-        for (int idx = tid; idx < npx * C4; idx += 256) {
-            int px = idx / C4, c4 = (idx - px * C4) * 4;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (inside && c4 < ca_valid) v = *reinterpret_cast<const f32x4*>(src + (long)px * a.u_ld + c4);
-            *reinterpret_cast<f32x4*>(dst + px * CA + c4) = v;
+        const int px_l = lane / C4A, c4 = (lane - px_l * C4A) * 4;
+        for (int k = wave; k * PPI < npxu; k += 4) {
+            const int px = k * PPI + px_l;
+            float* ldst = dst0 + k * PPI * CA;                           // wave-uniform
+            if (px < npxu && c4 < ca_valid) {
+                if (inside) glds16(src + (long)px * a.u_ld + c4, ldst);
+                else *reinterpret_cast<f32x4*>(ldst + lane * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
         }
     };
-    auto load_vrow = [&](int b, int y) {
+    auto dma_vrow = [&](int b, int y, int vb) {
+        constexpr int PPI = 64 / C4B;
+        float* dst0 = vbuf + vb * Wv4 * CB;
         const float* src = a.V + ((long)b * a.Hv + y) * a.Wv * a.v_ld + b0;
-        constexpr int C4 = CB / 4;
-        for (int idx = tid; idx < a.Wv * C4; idx += 256) {
-            int px = idx / C4, c4 = (idx - px * C4) * 4;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (c4 < cb_valid) v = *reinterpret_cast<const f32x4*>(src + (long)px * a.v_ld + c4);
-            *reinterpret_cast<f32x4*>(vbuf + px * CB + c4) = v;
+        const int px_l = lane / C4B, c4 = (lane - px_l * C4B) * 4;
+        for (int k = wave; k * PPI < a.Wv; k += 4) {
+            const int px = k * PPI + px_l;
+            if (px < a.Wv && c4 < cb_valid) glds16(src + (long)px * a.v_ld + c4, dst0 + k * PPI * CB);
         }
+    };
+    auto slot_of_row = [&](int y, int ky) -> int {
+        if (S == 1) return (y - P + ky + 4 * NSLOT) % NSLOT;
+        return (y & 1) * KH + ky;
+    };
+    auto stage_full = [&](int b, int y, int vb) {
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) dma_urow(b, y * S - P + ky, slot_of_row(y, ky));
+        dma_vrow(b, y, vb);
+    };
+    auto stage_next = [&](int b, int y, int vb) {            // rows of (b, y) not already resident for (b, y-1)
+        if (S == 1) dma_urow(b, y - P + KH - 1, slot_of_row(y, KH - 1));
+        else {
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky) dma_urow(b, y * S - P + ky, slot_of_row(y, ky));
+        }
+        dma_vrow(b, y, vb);
     };
 
-    int prev_b = -1, prev_y = -2;
+    bool prefetched = false;
     for (int row = row0; row < row1; ++row) {
         const int b = row / a.Hv, y = row - b * a.Hv;
-        __syncthreads();                                      // everyone is done with the previous row's buffers
-        const bool slide = (S == 1) && (b == prev_b) && (y == prev_y + 1);
-#pragma unroll
-        for (int ky = 0; ky < KH; ++ky) {
-            const int r = y * S - P + ky;
-            const int slot = (S == 1) ? ((r + KH) % KH) : ky;
-            if (!slide || ky == KH - 1) load_urow(b, r, slot);
+        const int vb = row & 1;
+        if (!prefetched) {
+            __syncthreads();                                  // nobody still reads the ring
+            stage_full(b, y, vb);
         }
-        load_vrow(b, y);
-        prev_b = b; prev_y = y;
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                      // row (b, y) is resident for every wave
+        prefetched = (row + 1 < row1) && (y + 1 < a.Hv);
+        if (prefetched) stage_next(b, y + 1, vb ^ 1);         // DMA under the MFMAs below
         int slot_of[KH];
 #pragma unroll
-        for (int ky = 0; ky < KH; ++ky) slot_of[ky] = (S == 1) ? ((y - P + ky + KH) % KH) : ky;
+        for (int ky = 0; ky < KH; ++ky) slot_of[ky] = slot_of_row(y, ky);
+        const float* vrow = vbuf + vb * Wv4 * CB;
         for (int x0 = wave * 4; x0 < Wv4; x0 += 16) {
             const int x = x0 + g;
             float vf[TB];
 #pragma unroll
-            for (int tb = 0; tb < TB; ++tb) vf[tb] = vbuf[x * CB + tb * 16 + i];
+            for (int tb = 0; tb < TB; ++tb) vf[tb] = vrow[x * CB + tb * 16 + i];
 #pragma unroll
             for (int ky = 0; ky < KH; ++ky) {
                 const float* ur = ubuf + slot_of[ky] * UP * CA + (S * x) * CA + i;
@@ -580,7 +602,6 @@ __global__ __launch_bounds__(256) void wgrad_mfma_k(WgradArgs a) {
         }
     }
     // fold the four waves through LDS (wave w > 0 publishes, wave 0 accumulates)
-    constexpr int NACC = (TAPS * TA * TB + TB) * 4;
     for (int w = 1; w < 4; ++w) {
         __syncthreads();
         if (wave == w) {
@@ -615,7 +636,6 @@ __global__ __launch_bounds__(256) void wgrad_mfma_k(WgradArgs a) {
                 for (int r = 0; r < 4; ++r) accb[tb][r] += smem[(q++) * 64 + lane];
         }
     }
-    static_assert(NACC > 0, "");
     if (wave != 0) return;
     // D[row = a_local = 4g+r][col = b_local = i]
     float* dst = a.part + (long)blockIdx.x * a.pstride;
@@ -1063,7 +1083,8 @@ int rv_conv_wgrad(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, co
         const int KH = mode == 0 ? 3 : (mode == 1 ? 1 : 2), SS = mode == 2 ? 2 : 1;
         const int Wv4 = (Wv + 3) & ~3;
         const int UP = SS * (Wv4 - 1) + KH;
-        size_t lds = ((size_t)KH * UP * TA * 16 + (size_t)Wv4 * TB * 16) * sizeof(float);
+        const int nslot = SS == 1 ? KH + 1 : 2 * KH;
+        size_t lds = ((size_t)nslot * UP * TA * 16 + (size_t)2 * Wv4 * TB * 16) * sizeof(float);
         const size_t fold = (size_t)((mode == 0 ? 9 : (mode == 1 ? 1 : 4)) * TA * TB + TB) * 4 * 64 * sizeof(float);
         if (lds < fold) lds = fold;
         RV_CHECK_ARG(lds <= 160 * 1024, "rv_conv_wgrad: row of %d pixels x %d channels does not fit LDS", Wv, TA * 16);
