@@ -844,15 +844,17 @@ static int launch_conv3x3_lds_r(const ConvArgs& a, int NT, int MTW, int TH, int 
     return RV_EUNSUPPORTED;
 }
 
-static int launch_conv3x3_lds(const ConvArgs& a, int R, hipStream_t st) {
+static int launch_conv3x3_lds(const ConvArgs& a, int R, hipStream_t st, int force_nt = 0, int force_mt = 0) {
     static const int mts[4] = {8, 4, 2, 1};
     // search (NT, MTW): prefer large tiles, but need >= ~1.5 units per workgroup slot on the chip
     int best_nt = 0, best_mt = 0, best_th = 0, best_wpc = 1;
     long best_score = -1;
     for (int nt = 4; nt >= 1; --nt) {
         if (a.ntile_n % nt) continue;
+        if (force_nt && nt != force_nt) continue;
         for (int k = 0; k < 4; ++k) {
             const int mt = mts[k];
+            if (force_mt && mt != force_mt) continue;
             if (nt * mt > 16 && !(nt <= 2 && mt == 8)) continue;          // accumulator budget
             int th = (mt * 64) / a.W;
             if (th > a.H) th = a.H;
@@ -996,14 +998,24 @@ int rv_conv_fwd(int mode, const float* in, int in_ld, int B, int H, int W, int C
         a.Ph = Ho; a.Pw = Wo;
     }
     a.npix = (long)B * a.Ph * a.Pw;
-    // algo: 0 = library default, 1 = LDS-free direct kernel, 2 = LDS/DMA-pipelined kernel (3x3 only; falls back
-    // to the direct kernel when the shape does not fit).  The host autotunes 1 vs 2 per layer shape.
-    if (mode == 0 && algo != 1) {
-        int rc3 = launch_conv3x3_lds(a, R, st);
+    // algo: 0 = library default, 1 = LDS-free direct kernel, 2 = LDS/DMA-pipelined kernel (3x3 only),
+    // 0x100|NT<<4|MT = direct kernel with that register tile, 0x200|NT<<4|MTW = LDS kernel with that tile.
+    // Forced tiles that do not fit the shape return RV_EUNSUPPORTED (the host autotuner skips them).
+    const int fam = algo >> 8, f_nt = (algo >> 4) & 15, f_mt = algo & 15;
+    if (mode == 0 && algo != 1 && fam != 1) {
+        int rc3 = (fam == 2) ? launch_conv3x3_lds(a, R, st, f_nt, f_mt) : launch_conv3x3_lds(a, R, st);
         if (rc3 == RV_OK) { RV_LAUNCH_CHECK("rv_conv_fwd(lds)"); return RV_OK; }
+        if (fam == 2) { rv_set_error("rv_conv_fwd: forced LDS tile NT=%d MTW=%d does not fit", f_nt, f_mt); return RV_EUNSUPPORTED; }
     }
     int NT, MT;
     choose_tiles((a.npix + 15) / 16, a.ntile_n, &NT, &MT);
+    if (fam == 1) {
+        if (f_nt < 1 || a.ntile_n % f_nt || !(f_mt == 1 || f_mt == 2 || f_mt == 4) || f_nt > 4) {
+            rv_set_error("rv_conv_fwd: forced direct tile NT=%d MT=%d invalid", f_nt, f_mt);
+            return RV_EUNSUPPORTED;
+        }
+        NT = f_nt; MT = f_mt;
+    }
     int rc = RV_EUNSUPPORTED;
     if (R == 4) {
         if (mode == 0) rc = launch_conv_rt<3, 3, 1, 1, 4, false>(a, NT, MT, st);

@@ -141,12 +141,21 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
             else:
                 best, algo = None, 0
                 st = torch.cuda.current_stream()
-                for cand in (1, 2):
-                    call('rv_conv_fwd', *args, cand, st.cuda_stream)
+                lib = _lib.load()
+                ntile_n = (cout + 15) // 16
+                cands = [1, 2]
+                for nt in (1, 2, 3, 4):
+                    if ntile_n % nt:
+                        continue
+                    cands += [0x100 | nt << 4 | mt for mt in (1, 2, 4)]
+                    cands += [0x200 | nt << 4 | mt for mt in (1, 2, 4, 8)]
+                for cand in cands:
+                    if lib.rv_conv_fwd(*args, cand, st.cuda_stream) != 0:
+                        continue                                   # tile does not fit this shape
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(st)
                     for _ in range(3):
-                        call('rv_conv_fwd', *args, cand, st.cuda_stream)
+                        lib.rv_conv_fwd(*args, cand, st.cuda_stream)
                     e1.record(st)
                     e1.synchronize()
                     t = e0.elapsed_time(e1)
