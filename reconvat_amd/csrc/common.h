@@ -61,3 +61,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
     const int q = n >> 3, r = n & 7, x = bid & 7, k = bid >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
+
+// Division by a launch-constant via multiply-high (n < 2^31, d >= 1): q = (umulhi(n, mul) + n) >> shift.
+struct FastDiv {
+    unsigned mul, shift, d;
+};
+static inline FastDiv fastdiv_make(unsigned d) {
+    FastDiv f;
+    f.d = d;
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    f.shift = s;
+    f.mul = (unsigned)((((1ull << s) - d) << 32) / d + 1);
+    return f;
+}
+__device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv& f) {
+    return (unsigned)(((unsigned long long)__umulhi(n, f.mul) + n) >> f.shift);
+}

@@ -90,6 +90,7 @@ struct ConvArgs {
     long npix;        // B*Ph*Pw
     int vec_store;    // out pointer/ld allow 16-byte stores
     int accumulate;   // out += result
+    FastDiv fd_pw, fd_plane, fd_w;   // divide by Pw, by Ph*Pw and by the input width W
 };
 
 template <int R> struct VecR;
@@ -113,11 +114,11 @@ __global__ __launch_bounds__(256) void conv_mfma_k(ConvArgs a) {
     for (int m = 0; m < MT; ++m) {
         long p = (tile0 + m) * 16 + j;
         pv[m] = p < a.npix;
-        long pp = pv[m] ? p : 0;
-        int b = (int)(pp / ((long)a.Ph * a.Pw));
-        int rem = (int)(pp - (long)b * a.Ph * a.Pw);
-        py[m] = rem / a.Pw;
-        px[m] = rem - py[m] * a.Pw;
+        const unsigned pp = pv[m] ? (unsigned)p : 0u;
+        const int b = (int)fastdiv(pp, a.fd_plane);
+        const unsigned rem = pp - (unsigned)b * (unsigned)(a.Ph * a.Pw);
+        py[m] = (int)fastdiv(rem, a.fd_pw);
+        px[m] = (int)rem - py[m] * a.Pw;
         pb[m] = b;
         ibase[m] = (((long)b * a.H + py[m] * S - P) * a.W + px[m] * S - P) * a.in_ld + g * R;
     }
@@ -181,6 +182,14 @@ __global__ __launch_bounds__(256) void conv_mfma_k(ConvArgs a) {
     }
 
     // epilogue: lane holds channels co0..co0+3 of pixel j of every (m, n) tile
+    f32x4 bv[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int ncol = (nt0 + n) * 16 + 4 * g;
+        const int cb = SCATTER ? ncol % a.Cout : ncol;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[n][r] = (a.bias && cb + r < a.Cout) ? a.bias[cb + r] : 0.f;
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         if (!pv[m]) continue;
@@ -202,12 +211,7 @@ __global__ __launch_bounds__(256) void conv_mfma_k(ConvArgs a) {
             }
             if (!inside || co0 >= a.Cout) continue;
             float* o = a.out + opix * a.out_ld + co0;
-            f32x4 v = acc[m][n];
-            if (a.bias) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (co0 + r < a.Cout) v[r] += a.bias[co0 + r];
-            }
+            f32x4 v = acc[m][n] + bv[n];
             if (a.vec_store && co0 + 3 < a.Cout) {
                 if (a.accumulate) {
                     f32x4 old = *reinterpret_cast<f32x4*>(o);
@@ -314,6 +318,13 @@ __global__ __launch_bounds__(256) void conv3x3_lds_k(ConvLdsArgs aa) {
     f32x4 acc[MTW][NT];
     int lbase[MTW];
     bool pv[MTW];
+    f32x4 bv[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int cb = (nt0 + n) * 16 + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[n][r] = (a.bias && cb + r < a.Cout) ? a.bias[cb + r] : 0.f;
+    }
     stage(0);
     for (int u = 0; u < nunits; ++u) {
         const int band = band_lo + u / nchunk, c = u - (u / nchunk) * nchunk;
@@ -327,8 +338,8 @@ __global__ __launch_bounds__(256) void conv3x3_lds_k(ConvLdsArgs aa) {
                 const int t = wave + 4 * m;
                 const int p = t * 16 + j;
                 pv[m] = t < ntile && p < npx;
-                const int pp = pv[m] ? p : 0;
-                const int ty = pp / W, tx = pp - ty * W;
+                const unsigned pp = pv[m] ? (unsigned)p : 0u;
+                const int ty = (int)fastdiv(pp, a.fd_w), tx = (int)pp - ty * W;
                 lbase[m] = (ty * W2 + tx) * KC + g * R;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -371,12 +382,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_k(ConvLdsArgs aa) {
                 const int co0 = (nt0 + n) * 16 + 4 * g;
                 if (co0 >= a.Cout) continue;
                 float* o = a.out + opix * a.out_ld + co0;
-                f32x4 v = acc[m][n];
-                if (a.bias) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (co0 + r < a.Cout) v[r] += a.bias[co0 + r];
-                }
+                f32x4 v = acc[m][n] + bv[n];
                 if (a.vec_store && co0 + 3 < a.Cout) {
                     if (a.accumulate) { f32x4 old = *reinterpret_cast<f32x4*>(o); v += old; }
                     *reinterpret_cast<f32x4*>(o) = v;
@@ -998,6 +1004,8 @@ int rv_conv_fwd(int mode, const float* in, int in_ld, int B, int H, int W, int C
         a.Ph = Ho; a.Pw = Wo;
     }
     a.npix = (long)B * a.Ph * a.Pw;
+    a.fd_pw = fastdiv_make((unsigned)a.Pw); a.fd_plane = fastdiv_make((unsigned)(a.Ph * a.Pw)); a.fd_w = fastdiv_make((unsigned)W);
+    RV_CHECK_ARG(a.npix < (1L << 31), "rv_conv_fwd: more than 2^31 pixels");
     // algo: 0 = library default, 1 = LDS-free direct kernel, 2 = LDS/DMA-pipelined kernel (3x3 only),
     // 0x100|NT<<4|MT = direct kernel with that register tile, 0x200|NT<<4|MTW = LDS kernel with that tile.
     // Forced tiles that do not fit the shape return RV_EUNSUPPORTED (the host autotuner skips them).
