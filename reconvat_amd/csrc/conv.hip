@@ -1054,7 +1054,9 @@ static WgradPlan wgrad_plan(int taps, int B, int Hv, int Ca, int Cb) {
     }
     p.TA = Ca > 16 ? 2 : 1; p.TB = Cb > 16 ? 2 : 1;
     p.nga = cdiv(Ca, p.TA * 16); p.ngb = cdiv(Cb, p.TB * 16);
-    int want = 768 / (p.nga * p.ngb);        // workgroups along the row axis: ~3 per CU overall
+    static int want_total = 0;
+    if (!want_total) { const char* e = getenv("RV_WGRAD_WGS"); want_total = e ? atoi(e) : 256; }
+    int want = want_total / (p.nga * p.ngb);        // one resident workgroup per CU (register-limited): exactly one block wave, no tail
     if (want < 4) want = 4;
     if (want > nrows) want = nrows;
     p.rows_per_wave = cdiv(nrows, want);     // rows per WORKGROUP for the LDS-staged kernel
