@@ -55,7 +55,9 @@ int rv_conv_wgrad(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, co
                   long workspace_bytes, void* stream);
 
 /* ---- BatchNorm2d(momentum=0.1) + leaky_relu (+ residual) (model/UNet_onset.py:183,196-199,221-223) --
- * coef [4C] = mean, invstd, scale, shift (saved for backward); workspace: 2*C doubles. */
+ * coef [4C] = mean, invstd, scale, shift (saved for backward).  workspace: rv_bn_workspace_bytes(C) bytes that are
+ * ALL-ZERO on entry (fp64 per-channel sums accumulate there); the host carves them from one arena cleared per step. */
+long rv_bn_workspace_bytes(int C);
 int rv_bn_lrelu_fwd(const float* z, int z_ld, long P, int C, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, long* num_batches_tracked, float momentum, float eps, int training, float slope,
                     const float* res, int res_ld, float* y, int y_ld, float* coef, void* workspace, void* stream);

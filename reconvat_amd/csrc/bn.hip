@@ -6,8 +6,9 @@
 // partials over <= 16 pixels, fp64 across threads/blocks) so that var = E[x^2] - mean^2 is safe.
 //
 //   stats    : sum / sum-of-squares per channel                    (reads z)
-//   finalize : mean, invstd, scale/shift, running stats, num_batches_tracked
-//   apply    : y = lrelu(z*scale + shift) (+ residual)             (reads z [,res], writes y)
+//   apply    : y = lrelu(z*scale + shift) (+ residual)             (reads z [,res], writes y); every thread
+//              derives its 4 channels' scale/shift from the fp64 sums, block 0 also does the "finalize" work
+//              (coefficients for backward, running statistics, num_batches_tracked)
 //   bwd_red  : sum(dzh), sum(dzh*xhat)  with dzh = dy * lrelu'(zh) (reads dy, z)
 //   bwd_apply: dz = scale * (dzh - mean(dzh) - xhat*mean(dzh*xhat)) (reads dy, z, writes dz)
 #include "common.h"
@@ -27,6 +28,12 @@ struct BnArgs {
     float* dgamma; float* dbeta;
     int accumulate;
     int param_accumulate;    // dgamma/dbeta are added into the destination instead of overwriting it
+    // forward finalize (fused into the apply kernel)
+    const float* gamma; const float* beta;
+    float* running_mean; float* running_var; long* nbt;
+    float* coef_out;         // [4C] written by block 0 (saved for backward)
+    float momentum, eps;
+    int training;
 };
 
 // thread t -> channel quad t % (C/4), pixel lane t / (C/4); 16-byte loads, BN_PIX_PER_THREAD pixels each.
@@ -84,39 +91,19 @@ __global__ __launch_bounds__(256) void bn_reduce_k(BnArgs a) {
     }
 }
 
-struct BnFinalArgs {
-    const double* sums; long P; int C;
-    const float* gamma; const float* beta;
-    float* running_mean; float* running_var; long* nbt;
-    float* coef;      // [4C] out: mean, invstd, scale, shift
-    float momentum, eps;
-    int training;
-};
-
-__global__ void bn_finalize_k(BnFinalArgs a) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && a.training && a.nbt) *a.nbt += 1;
-    if (c >= a.C) return;
-    float mean, invstd;
+// batch (training) or running (eval) mean / inverse std of channel c -- identical arithmetic in every thread
+__device__ __forceinline__ void bn_coef(const BnArgs& a, int c, float& mean, float& invstd) {
     if (a.training) {
-        double n = (double)a.P;
-        double m = a.sums[c] / n;
+        const double n = (double)a.P;
+        const double m = a.sums[c] / n;
         double var = a.sums[a.C + c] / n - m * m;
         if (var < 0.0) var = 0.0;
         mean = (float)m;
         invstd = (float)(1.0 / sqrt(var + (double)a.eps));
-        double unb = n > 1.0 ? var * n / (n - 1.0) : var;
-        a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
-        a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
     } else {
         mean = a.running_mean[c];
         invstd = 1.0f / sqrtf(a.running_var[c] + a.eps);
     }
-    float scale = a.gamma[c] * invstd;
-    a.coef[c] = mean;
-    a.coef[a.C + c] = invstd;
-    a.coef[2 * a.C + c] = scale;
-    a.coef[3 * a.C + c] = a.beta[c] - mean * scale;
 }
 
 // elementwise, 4 channels per thread (C % 4 == 0).  The grid is a multiple of 3 workgroups, so the
@@ -132,9 +119,9 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
     int c = (int)(idx % C4) * 4;
     f32x4 mean, invstd, scale, shift, k1, k2;
     auto fetch = [&](int cc) {
-        scale = *reinterpret_cast<const f32x4*>(a.coef + 2 * C + cc);
-        shift = *reinterpret_cast<const f32x4*>(a.coef + 3 * C + cc);
         if (BWD) {
+            scale = *reinterpret_cast<const f32x4*>(a.coef + 2 * C + cc);
+            shift = *reinterpret_cast<const f32x4*>(a.coef + 3 * C + cc);
             mean = *reinterpret_cast<const f32x4*>(a.coef + cc);
             invstd = *reinterpret_cast<const f32x4*>(a.coef + C + cc);
             const double invn = 1.0 / (double)a.P;
@@ -142,6 +129,14 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
             for (int q = 0; q < 4; ++q) {
                 k1[q] = a.frozen ? 0.f : (float)(a.sums[cc + q] * invn);
                 k2[q] = a.frozen ? 0.f : (float)(a.sums[C + cc + q] * invn);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float m_, is_;
+                bn_coef(a, cc + q, m_, is_);
+                scale[q] = a.gamma[cc + q] * is_;
+                shift[q] = a.beta[cc + q] - m_ * scale[q];
             }
         }
     };
@@ -177,12 +172,35 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
         }
         *reinterpret_cast<f32x4*>(dst) = o;
     }
-    if (BWD && blockIdx.x == 0 && a.dgamma) {
+    if (blockIdx.x == 0) {
         for (int cc = threadIdx.x; cc < a.C; cc += blockDim.x) {
-            const float dg = (float)a.sums[a.C + cc], db = (float)a.sums[cc];
-            a.dgamma[cc] = a.param_accumulate ? a.dgamma[cc] + dg : dg;
-            a.dbeta[cc] = a.param_accumulate ? a.dbeta[cc] + db : db;
+            if (BWD) {
+                if (a.dgamma) {
+                    const float dg = (float)a.sums[a.C + cc], db = (float)a.sums[cc];
+                    a.dgamma[cc] = a.param_accumulate ? a.dgamma[cc] + dg : dg;
+                    a.dbeta[cc] = a.param_accumulate ? a.dbeta[cc] + db : db;
+                }
+            } else {
+                // finalize: coefficients for the backward pass, running statistics, num_batches_tracked
+                float m_, is_;
+                bn_coef(a, cc, m_, is_);
+                const float sc = a.gamma[cc] * is_;
+                a.coef_out[cc] = m_;
+                a.coef_out[a.C + cc] = is_;
+                a.coef_out[2 * a.C + cc] = sc;
+                a.coef_out[3 * a.C + cc] = a.beta[cc] - m_ * sc;
+                if (a.training) {
+                    const double n = (double)a.P;
+                    const double mm = a.sums[cc] / n;
+                    double var = a.sums[a.C + cc] / n - mm * mm;
+                    if (var < 0.0) var = 0.0;
+                    const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+                    a.running_mean[cc] = (1.f - a.momentum) * a.running_mean[cc] + a.momentum * m_;
+                    a.running_var[cc] = (1.f - a.momentum) * a.running_var[cc] + a.momentum * (float)unb;
+                }
+            }
         }
+        if (!BWD && threadIdx.x == 0 && a.training && a.nbt) *a.nbt += 1;
     }
 }
 
@@ -195,7 +213,12 @@ static int bn_apply_blocks(long total) {
 
 extern "C" {
 
-// workspace: 2*C doubles (sums).  coef: [4C] floats (mean, invstd, scale, shift) -- saved for backward.
+// Bytes of workspace the BN entry points need: 2*C fp64 sums.  CONTRACT: the workspace must be ALL-ZERO on entry (the
+// host hands out slices of one arena that is cleared once per step -- a per-call memset costs a launch, and a
+// last-workgroup self-clean costs ~4 ns of serialized atomics per workgroup); it holds the sums on exit.
+long rv_bn_workspace_bytes(int C) { return (long)(2 * C) * 8; }
+
+// coef: [4C] floats (mean, invstd, scale, shift) -- saved for backward.
 // training != 0: batch statistics, running stats / num_batches_tracked updated in place.
 // y = leaky_relu(bn(z), slope) (+ res).  slope = 1 -> no activation.
 int rv_bn_lrelu_fwd(const float* z, int z_ld, long P, int C, const float* gamma, const float* beta, float* running_mean,
@@ -206,19 +229,14 @@ int rv_bn_lrelu_fwd(const float* z, int z_ld, long P, int C, const float* gamma,
     RV_CHECK_ARG((z_ld % 4) == 0 && (y_ld % 4) == 0 && (!res || (res_ld % 4) == 0), "rv_bn_lrelu_fwd: strides must be multiples of 4");
     BnArgs a = {};
     a.z = z; a.z_ld = z_ld; a.P = P; a.C = C; a.sums = (double*)workspace; a.slope = slope;
+    a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var; a.nbt = num_batches_tracked;
+    a.coef_out = coef; a.momentum = momentum; a.eps = eps; a.training = training;
     if (training) {
-        (void)hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, st);
         const int PL = 256 / (C / 4);
         hipLaunchKernelGGL(bn_reduce_k<false>, dim3(cdiv(P, (long)PL * BN_PIX_PER_THREAD)), dim3(256), 0, st, a);
         RV_LAUNCH_CHECK("rv_bn_lrelu_fwd(stats)");
     }
-    BnFinalArgs f;
-    f.sums = (const double*)workspace; f.P = P; f.C = C; f.gamma = gamma; f.beta = beta;
-    f.running_mean = running_mean; f.running_var = running_var; f.nbt = num_batches_tracked;
-    f.coef = coef; f.momentum = momentum; f.eps = eps; f.training = training;
-    hipLaunchKernelGGL(bn_finalize_k, dim3(cdiv(C, 64)), dim3(64), 0, st, f);
-    RV_LAUNCH_CHECK("rv_bn_lrelu_fwd(finalize)");
-    a.coef = coef; a.out = y; a.out_ld = y_ld; a.res = res; a.res_ld = res_ld;
+    a.out = y; a.out_ld = y_ld; a.res = res; a.res_ld = res_ld;
     hipLaunchKernelGGL(bn_apply_k<false>, dim3(bn_apply_blocks(P * (C / 4))), dim3(256), 0, st, a);
     RV_LAUNCH_CHECK("rv_bn_lrelu_fwd(apply)");
     return RV_OK;
@@ -235,7 +253,6 @@ int rv_bn_lrelu_bwd(const float* dy, int dy_ld, const float* z, int z_ld, long P
     a.z = z; a.z_ld = z_ld; a.dy = dy; a.dy_ld = dy_ld; a.P = P; a.C = C; a.sums = (double*)workspace;
     a.coef = coef; a.slope = slope; a.frozen = frozen; a.out = dz; a.out_ld = dz_ld; a.dgamma = dgamma; a.dbeta = dbeta; a.param_accumulate = param_accumulate;
     if (!frozen || dgamma) {
-        (void)hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, st);
         const int PL = 256 / (C / 4);
         hipLaunchKernelGGL(bn_reduce_k<true>, dim3(cdiv(P, (long)PL * BN_PIX_PER_THREAD)), dim3(256), 0, st, a);
         RV_LAUNCH_CHECK("rv_bn_lrelu_bwd(reduce)");

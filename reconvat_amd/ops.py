@@ -19,6 +19,39 @@ _EPOCH = [0]
 _DIRECT = [False]
 
 
+class ZeroArena:
+    """Bump allocator over ONE device buffer that is cleared once per training step: reduction kernels that need
+    zero-initialised scratch (BatchNorm sums) take slices instead of issuing a memset per call.  Armed by
+    TrainStep (also under hipGraph capture: the clear is the first node and the slice order is deterministic);
+    unarmed, `take` falls back to torch.zeros."""
+
+    def __init__(self):
+        self.buf = None
+        self.off = 0
+        self.armed = False
+
+    def begin_step(self, device, nbytes=4 << 20):
+        if self.buf is None or self.buf.device != device or self.buf.numel() * 8 < nbytes:
+            self.buf = torch.zeros(nbytes // 8, device=device, dtype=torch.float64)
+        else:
+            self.buf.zero_()
+        self.off = 0
+        self.armed = True
+
+    def end_step(self):
+        self.armed = False
+
+    def take(self, n_doubles, device):
+        if self.armed and self.buf.device == device and self.off + n_doubles <= self.buf.numel():
+            out = self.buf[self.off:self.off + n_doubles]
+            self.off += (n_doubles + 1) & ~1
+            return out
+        return torch.zeros(n_doubles, device=device, dtype=torch.float64)
+
+
+ARENA = ZeroArena()
+
+
 class direct_param_grads:
     """Context manager: while active, conv / BatchNorm backward kernels ACCUMULATE their parameter gradients
     straight into the pre-allocated ``param.grad`` buffers (FlatAdam's flat gradient bucket) and hand autograd
@@ -323,10 +356,12 @@ class BnActFn(Function):
         p = bb * h * wd
         y = torch.empty_like(z, memory_format=torch.contiguous_format)
         coef = torch.empty(4 * c, device=z.device, dtype=torch.float32)
-        ws = torch.empty(2 * c, device=z.device, dtype=torch.float64)
+        # zero-initialised fp64 sums: one slice for the forward statistics, one for the backward reduction
+        ws = (ARENA.take(2 * c, z.device), ARENA.take(2 * c, z.device) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None)
         rld = _geom(res)[4] if res is not None else 0
         call('rv_bn_lrelu_fwd', ptr(z), zld, p, c, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(nbt),
-             BN_MOMENTUM, BN_EPS, 1 if training else 0, slope, ptr(res), rld, ptr(y), c, ptr(coef), ptr(ws), stream())
+             BN_MOMENTUM, BN_EPS, 1 if training else 0, slope, ptr(res), rld, ptr(y), c, ptr(coef), ptr(ws[0]), stream())
+        ctx.ws = ws
         ctx.training = training
         ctx.slope = slope
         ctx.params = (gamma, beta)
@@ -349,9 +384,9 @@ class BnActFn(Function):
         else:
             dg = torch.empty(c, device=z.device, dtype=torch.float32) if need_w else None
             db = torch.empty(c, device=z.device, dtype=torch.float32) if need_w else None
-        ws = torch.empty(2 * c, device=z.device, dtype=torch.float64)
         call('rv_bn_lrelu_bwd', ptr(dy), c, ptr(z), zld, p, c, ptr(coef), ctx.slope, 0 if ctx.training else 1,
-             ptr(dz), c, ptr(dg), ptr(db), 1 if direct else 0, ptr(ws), stream())
+             ptr(dz), c, ptr(dg), ptr(db), 1 if direct else 0,
+             ptr(ctx.ws[1] if ctx.ws[1] is not None else ARENA.take(2 * c, z.device)), stream())
         if direct:
             dg = db = None
         dres = dy if ctx.needs_input_grad[6] else None

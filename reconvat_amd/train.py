@@ -163,10 +163,12 @@ class TrainStep:
 
     def _fwd_bwd(self):
         self.opt.zero_grad()
+        ops.ARENA.begin_step(self.opt.flat_grad.device)
         with ops.direct_param_grads():      # conv grads accumulate straight into the flat bucket
             _, losses, _ = self.model.run_on_batch(self.batch, self.batch_ul, self.VAT)
             loss = weighted_loss(losses, self.alpha)
             loss.backward()
+        ops.ARENA.end_step()
         self.losses = {k: v.detach() for k, v in losses.items()}
         self.loss = loss.detach()
 
