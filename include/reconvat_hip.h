@@ -55,12 +55,15 @@ int rv_conv_wgrad(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, co
                   long workspace_bytes, void* stream);
 
 /* ---- BatchNorm2d(momentum=0.1) + leaky_relu (+ residual) (model/UNet_onset.py:183,196-199,221-223) --
- * coef [4C] = mean, invstd, scale, shift (saved for backward).  workspace: rv_bn_workspace_bytes(C) bytes that are
+ * coef [5C] = mean, invstd, scale, shift, unbiased batch variance (saved for backward).  training: 0 eval, 1 train,
+ * 2 train without touching the running statistics (rv_bn_running_update applies that update later, in sequence).  workspace: rv_bn_workspace_bytes(C) bytes that are
  * ALL-ZERO on entry (fp64 per-channel sums accumulate there); the host carves them from one arena cleared per step. */
 long rv_bn_workspace_bytes(int C);
 int rv_bn_lrelu_fwd(const float* z, int z_ld, long P, int C, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, long* num_batches_tracked, float momentum, float eps, int training, float slope,
                     const float* res, int res_ld, float* y, int y_ld, float* coef, void* workspace, void* stream);
+int rv_bn_running_update(float* running_mean, float* running_var, long* num_batches_tracked, const float* coef, int C,
+                         float momentum, void* stream);
 int rv_bn_lrelu_bwd(const float* dy, int dy_ld, const float* z, int z_ld, long P, int C, const float* coef, float slope,
                     int frozen, float* dz, int dz_ld, float* dgamma, float* dbeta, int param_accumulate, void* workspace,
                     void* stream);

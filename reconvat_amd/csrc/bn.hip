@@ -194,13 +194,16 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
                     const double mm = a.sums[cc] / n;
                     double var = a.sums[a.C + cc] / n - mm * mm;
                     if (var < 0.0) var = 0.0;
-                    const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
-                    a.running_mean[cc] = (1.f - a.momentum) * a.running_mean[cc] + a.momentum * m_;
-                    a.running_var[cc] = (1.f - a.momentum) * a.running_var[cc] + a.momentum * (float)unb;
+                    const float unb = (float)(n > 1.0 ? var * n / (n - 1.0) : var);
+                    a.coef_out[4 * a.C + cc] = unb;            // kept for a deferred running-stat update
+                    if (a.training == 1) {
+                        a.running_mean[cc] = (1.f - a.momentum) * a.running_mean[cc] + a.momentum * m_;
+                        a.running_var[cc] = (1.f - a.momentum) * a.running_var[cc] + a.momentum * unb;
+                    }
                 }
             }
         }
-        if (!BWD && threadIdx.x == 0 && a.training && a.nbt) *a.nbt += 1;
+        if (!BWD && threadIdx.x == 0 && a.training == 1 && a.nbt) *a.nbt += 1;
     }
 }
 
@@ -218,8 +221,10 @@ extern "C" {
 // last-workgroup self-clean costs ~4 ns of serialized atomics per workgroup); it holds the sums on exit.
 long rv_bn_workspace_bytes(int C) { return (long)(2 * C) * 8; }
 
-// coef: [4C] floats (mean, invstd, scale, shift) -- saved for backward.
-// training != 0: batch statistics, running stats / num_batches_tracked updated in place.
+// coef: [5C] floats (mean, invstd, scale, shift, unbiased batch variance) -- saved for backward.
+// training == 1: batch statistics, running stats / num_batches_tracked updated in place;
+// training == 2: batch statistics, running stats untouched (apply them later with rv_bn_running_update);
+// training == 0: running statistics (eval mode).
 // y = leaky_relu(bn(z), slope) (+ res).  slope = 1 -> no activation.
 int rv_bn_lrelu_fwd(const float* z, int z_ld, long P, int C, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, long* num_batches_tracked, float momentum, float eps, int training, float slope,
@@ -259,6 +264,25 @@ int rv_bn_lrelu_bwd(const float* dy, int dy_ld, const float* z, int z_ld, long P
     }
     hipLaunchKernelGGL(bn_apply_k<true>, dim3(bn_apply_blocks(P * (C / 4))), dim3(256), 0, st, a);
     RV_LAUNCH_CHECK("rv_bn_lrelu_bwd(apply)");
+    return RV_OK;
+}
+
+// running_mean/var <- (1-m)*running + m*batch (batch mean / unbiased variance taken from a forward's coef), and
+// num_batches_tracked += 1: the update a training == 2 forward skipped, applied where the caller needs it in the
+// sequence of updates (nn.BatchNorm2d semantics are order-dependent).
+__global__ void bn_running_update_k(float* rm, float* rv, long* nbt, const float* coef, int C, float momentum) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    rm[c] = (1.f - momentum) * rm[c] + momentum * coef[c];
+    rv[c] = (1.f - momentum) * rv[c] + momentum * coef[4 * C + c];
+}
+
+int rv_bn_running_update(float* running_mean, float* running_var, long* num_batches_tracked, const float* coef, int C,
+                         float momentum, void* stream) {
+    hipLaunchKernelGGL(bn_running_update_k, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, running_mean, running_var,
+                       num_batches_tracked, coef, C, momentum);
+    RV_LAUNCH_CHECK("rv_bn_running_update");
     return RV_OK;
 }
 

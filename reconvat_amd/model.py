@@ -265,11 +265,16 @@ class UNet_VAT(nn.Module):
         out = model.transcriber(x, detach) if detach else model.transcriber(x)
         return out[:-1]            # (frame[, onset]) without the attention map
 
-    def forward(self, model, x):
+    def forward(self, model, x, refs=None):
+        """`refs`: the transcriber's outputs on `x` if the caller already has them (run_on_batch reuses its main
+        forward pass, which is the same function of the same weights; see _Base._vat_reusing_forward)."""
         if self.nan_flag is None or self.nan_flag.device != x.device:
             self.nan_flag = torch.zeros(1, dtype=torch.int32, device=x.device)
-        with torch.no_grad():
-            refs = self._outputs(model, x)
+        if refs is None:
+            with torch.no_grad():
+                refs = self._outputs(model, x)
+        else:
+            refs = tuple(r.detach() for r in refs)
         d = (self.noise(x) if self.noise is not None else torch.randn_like(x)).requires_grad_(True)
         g = None
         for it in range(self.n_power):
@@ -315,6 +320,27 @@ class _Base(nn.Module):
             spec = torch.log(spec + 1e-5)
         return self.normalize.transform(spec).transpose(-1, -2).unsqueeze(1).contiguous()
 
+    def _vat_reusing_forward(self, spec):
+        """Labelled-branch VAT + the main transcriber forward with ONE transcriber pass less than the reference.
+
+        The reference evaluates transcriber(spec) twice with identical weights: once under no_grad as the VAT
+        target (model/UNet_onset.py:117-118) and once as the main forward (:383).  Train-mode BatchNorm makes both
+        passes bit-identical functions of the batch, so the main (grad-enabled) pass is run first and its
+        detached outputs serve as the VAT target.  The only state the skipped pass would have touched are the
+        BatchNorm running statistics: the main pass runs with deferred updates, which are replayed at the two
+        positions of the reference's update sequence (before and after the two perturbed VAT passes)."""
+        if self.training:
+            with ops.deferred_bn_updates() as pending:
+                out = self.transcriber(spec)
+            pending.apply()                                   # position of the no_grad reference pass
+        else:
+            pending = None
+            out = self.transcriber(spec)
+        lds, r_adv, r_norm = self.vat_loss(self, spec, refs=out[:-1])
+        if pending is not None:
+            pending.apply()                                   # position of the main forward pass
+        return out, lds, r_adv, r_norm
+
     def load_my_state_dict(self, state_dict):
         own_state = self.state_dict()
         for name, param in state_dict.items():
@@ -338,8 +364,8 @@ class UNet_Onset(_Base):
         if reconstruction:
             self.reconstructor = Roll2Spec(ds_ksize, ds_stride)
 
-    def forward(self, x):
-        pianoroll, onset, a = self.transcriber(x)
+    def forward(self, x, _first=None):
+        pianoroll, onset, a = self.transcriber(x) if _first is None else _first
         if self.reconstruction:
             reconstruction, _ = self.reconstructor(pianoroll)
             pianoroll2, onset2, _ = self.transcriber(reconstruction)
@@ -362,8 +388,9 @@ class UNet_Onset(_Base):
             lds_ul = {'frame': torch.tensor(0.), 'onset': torch.tensor(0.)}
             r_norm_ul = torch.tensor(0.)
         spec = self._front(audio_label, audio_label.shape[-1])
+        first = None
         if VAT:
-            lds_l, r_adv, r_norm_l = self.vat_loss(self, spec)
+            first, lds_l, r_adv, r_norm_l = self._vat_reusing_forward(spec)
             r_adv = r_adv.squeeze(1)
             r_norm_l = abs_mean(r_norm_l)
         else:
@@ -372,7 +399,7 @@ class UNet_Onset(_Base):
             r_norm_l = torch.tensor(0.)
         tag = 'train' if self.training else 'test'
         if self.reconstruction:
-            reconstrut, pianoroll, onset, pianoroll2, onset2, a = self(spec)
+            reconstrut, pianoroll, onset, pianoroll2, onset2, a = self(spec, first)
             predictions = {'frame': pianoroll, 'onset': onset, 'frame2': pianoroll2, 'onset2': onset2, 'attention': a,
                            'r_adv': r_adv, 'reconstruction': reconstrut}
             if not self.training:
@@ -386,7 +413,7 @@ class UNet_Onset(_Base):
                 f'loss/{tag}_onset2': bce_mean(predictions['onset2'], onset_label),
             }
         else:
-            frame_pred, onset, a = self(spec)
+            frame_pred, onset, a = self(spec, first)
             predictions = {'onset': onset, 'frame': frame_pred, 'r_adv': r_adv, 'attention': a}
             if not self.training:
                 predictions['frame'] = frame_pred.reshape(*frame_label.shape)
@@ -411,8 +438,8 @@ class UNet(_Base):
         if reconstruction:
             self.reconstructor = Roll2Spec(ds_ksize, ds_stride)
 
-    def forward(self, x):
-        pianoroll, a = self.transcriber(x)
+    def forward(self, x, _first=None):
+        pianoroll, a = self.transcriber(x) if _first is None else _first
         if self.reconstruction:
             reconstruction, _ = self.reconstructor(pianoroll)
             pianoroll2, _ = self.transcriber(reconstruction)
@@ -432,8 +459,9 @@ class UNet(_Base):
             lds_ul = torch.tensor(0.)
             r_norm_ul = torch.tensor(0.)
         spec = self._front(audio_label, audio_label.shape[-1])
+        first = None
         if VAT:
-            lds_l, r_adv, r_norm_l = self.vat_loss(self, spec)
+            first, lds_l, r_adv, r_norm_l = self._vat_reusing_forward(spec)
             r_adv = r_adv.squeeze(1)
             r_norm_l = abs_mean(r_norm_l)
         else:
@@ -442,7 +470,7 @@ class UNet(_Base):
             r_norm_l = torch.tensor(0.)
         tag = 'train' if self.training else 'test'
         if self.reconstruction:
-            reconstrut, pianoroll, pianoroll2, a = self(spec)
+            reconstrut, pianoroll, pianoroll2, a = self(spec, first)
             if not self.training:
                 pianoroll = pianoroll.reshape(*frame_label.shape)
                 pianoroll2 = pianoroll2.reshape(*frame_label.shape)
@@ -454,7 +482,7 @@ class UNet(_Base):
                 f'loss/{tag}_frame2': bce_mean(predictions['frame2'], frame_label),
             }
         else:
-            frame_pred, a = self(spec)
+            frame_pred, a = self(spec, first)
             if not self.training:
                 frame_pred = frame_pred.reshape(*frame_label.shape)
             predictions = {'onset': frame_pred, 'frame': frame_pred, 'r_adv': r_adv, 'attention': a}

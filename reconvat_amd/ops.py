@@ -51,6 +51,28 @@ class ZeroArena:
 
 ARENA = ZeroArena()
 
+_BN_DEFER = [None]
+
+
+class deferred_bn_updates:
+    """Inside this context train-mode BatchNorm forwards use batch statistics but do NOT touch running_mean /
+    running_var / num_batches_tracked; the skipped updates are collected and can be replayed (any number of
+    times, at the point of the reference's update sequence where they belong) with ``apply()``."""
+
+    def __enter__(self):
+        self.prev = _BN_DEFER[0]
+        self.items = []
+        _BN_DEFER[0] = self.items
+        return self
+
+    def __exit__(self, *exc):
+        _BN_DEFER[0] = self.prev
+
+    def apply(self):
+        for rm, rv, nbt, coef, c in self.items:
+            call('rv_bn_running_update', ptr(rm), ptr(rv), ptr(nbt), ptr(coef), c, BN_MOMENTUM, stream())
+
+
 
 class direct_param_grads:
     """Context manager: while active, conv / BatchNorm backward kernels ACCUMULATE their parameter gradients
@@ -355,12 +377,16 @@ class BnActFn(Function):
         bb, h, wd, c, zld = _geom(z)
         p = bb * h * wd
         y = torch.empty_like(z, memory_format=torch.contiguous_format)
-        coef = torch.empty(4 * c, device=z.device, dtype=torch.float32)
+        coef = torch.empty(5 * c, device=z.device, dtype=torch.float32)
+        mode = 1 if training else 0
+        if training and _BN_DEFER[0] is not None:
+            mode = 2
+            _BN_DEFER[0].append((running_mean, running_var, nbt, coef, c))
         # zero-initialised fp64 sums: one slice for the forward statistics, one for the backward reduction
         ws = (ARENA.take(2 * c, z.device), ARENA.take(2 * c, z.device) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None)
         rld = _geom(res)[4] if res is not None else 0
         call('rv_bn_lrelu_fwd', ptr(z), zld, p, c, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(nbt),
-             BN_MOMENTUM, BN_EPS, 1 if training else 0, slope, ptr(res), rld, ptr(y), c, ptr(coef), ptr(ws[0]), stream())
+             BN_MOMENTUM, BN_EPS, mode, slope, ptr(res), rld, ptr(y), c, ptr(coef), ptr(ws[0]), stream())
         ctx.ws = ws
         ctx.training = training
         ctx.slope = slope

@@ -264,6 +264,44 @@ def test_backward_vs_oracle(dev, kind):
             assert rel_err(b, p64[k]) < 1e-4, k
 
 
+def test_vat_forward_reuse_keeps_bn_bookkeeping(dev):
+    """run_on_batch reuses the main transcriber pass as the VAT target (one pass less than the reference) and
+    replays the skipped BatchNorm running-stat updates in sequence: num_batches_tracked and the running
+    statistics must match the oracle, which executes the reference's full sequence of 5+3 transcriber passes."""
+    from oracle import fixture as fx, model as om
+    bl, bul = _batches(dev)
+    n_ul, n_l = fx.fixture_noise((2, 1, 64, 229), 'd0_ul'), fx.fixture_noise((2, 1, 64, 229), 'd0_l')
+    m = build('onset', True, dev)
+    seq = [n_ul.to(dev), n_l.to(dev)]
+    m.vat_loss.noise = lambda t: seq.pop(0).clone()
+    m.run_on_batch(bl, bul, True)
+    params = fx.fixture_params('onset', True)
+    cpu = lambda b: {k: v.cpu() for k, v in b.items()}
+    om.run_on_batch_onset(params, True, cpu(bl), cpu(bul), True, True, d0_l=n_l, d0_ul=n_ul)
+    sd = m.state_dict()
+    for k, v in sd.items():
+        if k.endswith('num_batches_tracked'):
+            assert int(v) == int(params[k]), k            # transcriber BNs: 8 passes, reconstructor BNs: 1
+        elif k.endswith(('running_mean', 'running_var')):
+            # the adversarial passes see slightly different r_adv (chaotic direction) -> loose but meaningful bound
+            assert rel_err(v, params[k]) < 5e-2, (k, rel_err(v, params[k]))
+    assert int(sd['transcriber.Unet1_encoder.block1.bn1.num_batches_tracked']) == 8
+    # exact check on the GPU itself: the reference's pass sequence (separate no_grad target pass) vs the reuse path
+    m2 = build('onset', True, dev)
+    seq2 = [n_ul.to(dev), n_l.to(dev)]
+    m2.vat_loss.noise = lambda t: seq2.pop(0).clone()
+
+    def naive(spec, m2=m2):
+        lds, r_adv, r_norm = m2.vat_loss(m2, spec)
+        return m2.transcriber(spec), lds, r_adv, r_norm
+    m2._vat_reusing_forward = naive
+    _, l2, _ = m2.run_on_batch(bl, bul, True)
+    sd2 = m2.state_dict()
+    for k, v in sd.items():
+        if k.endswith(('running_mean', 'running_var', 'num_batches_tracked')):
+            assert rel_err(v.float(), sd2[k].float()) < 1e-5, k
+
+
 def test_direct_grad_accumulation(dev):
     """ops.direct_param_grads() (kernels accumulate conv/BN parameter gradients straight into the flat bucket)
     gives the same bucket as ordinary autograd accumulation."""
