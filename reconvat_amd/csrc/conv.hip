@@ -251,8 +251,9 @@ __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int R, int NT, int MTW>
-__global__ __launch_bounds__(256) void conv3x3_lds_k(ConvLdsArgs aa) {
+template <int R, int NT, int MTW, int NW>
+__global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
+    constexpr int NTHR = NW * 64;
     typedef typename VecR<R>::T vec;
     constexpr int KC = 4 * R;                    // channels per chunk
     constexpr int Q = R;                         // float4 per staged pixel (KC/4)
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_k(ConvLdsArgs aa) {
         float* xb = xs0 + (u & 1) * xfloats;
         const float* src0 = a.in + (long)b * H * W * a.in_ld + c * KC;
         const int nx = nrow * ipr;
-        for (int i = wave; i < nx; i += 4) {
+        for (int i = wave; i < nx; i += NW) {
             const int row = i / ipr, k = i - row * ipr;
             const int gy = y0 - 1 + row;
             const int px = k * PPI + lane / Q, q = lane - (lane / Q) * Q;
@@ -296,8 +297,8 @@ __global__ __launch_bounds__(256) void conv3x3_lds_k(ConvLdsArgs aa) {
         }
         if (nchunk > 1 || u == 0) {
             float* wb = ws0 + ((nchunk > 1) ? (u & 1) : 0) * WFLOATS;
-            constexpr int NW = (9 * NT + FPI - 1) / FPI;
-            for (int i = wave; i < NW; i += 4) {
+            constexpr int NWF = (9 * NT + FPI - 1) / FPI;
+            for (int i = wave; i < NWF; i += NW) {
                 const int f = i * FPI + lane / LPF, o = lane - (lane / LPF) * LPF;
                 if (f < 9 * NT) {
                     const int tap = f / NT, n = f - tap * NT;
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_k(ConvLdsArgs aa) {
     };
 
     // halo columns of both buffers are zero for the whole kernel (the DMA never touches them)
-    for (int k = tid; k < 2 * nrow * 2 * KC; k += 256) {
+    for (int k = tid; k < 2 * nrow * 2 * KC; k += NTHR) {
         const int buf = k / (nrow * 2 * KC), rem = k - buf * (nrow * 2 * KC);
         const int row = rem / (2 * KC), rem2 = rem - row * (2 * KC);
         const int side = rem2 / KC, ch = rem2 - side * KC;
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_k(ConvLdsArgs aa) {
         if (c == 0) {
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
-                const int t = wave + 4 * m;
+                const int t = wave + NW * m;
                 const int p = t * 16 + j;
                 pv[m] = t < ntile && p < npx;
                 const unsigned pp = pv[m] ? (unsigned)p : 0u;
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_k(ConvLdsArgs aa) {
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
             if (!pv[m]) continue;
-            const long opix = pix0 + (wave + 4 * m) * 16 + j;
+            const long opix = pix0 + (wave + NW * m) * 16 + j;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const int co0 = (nt0 + n) * 16 + 4 * g;
@@ -818,7 +819,7 @@ static size_t conv3x3_lds_bytes(int R, int NT, int TH, int W, int nchunk) {
     return ((size_t)2 * (TH + 2) * (W + 2) * 4 * R + (size_t)(nchunk > 1 ? 2 : 1) * 9 * NT * 64 * R) * sizeof(float);
 }
 
-template <int R>
+template <int R, int NW>
 static int launch_conv3x3_lds_r(const ConvArgs& a, int NT, int MTW, int TH, int wgs_per_cu, hipStream_t st) {
     ConvLdsArgs aa;
     aa.c = a; aa.TH = TH; aa.nbands = cdiv(a.H, TH);
@@ -830,10 +831,10 @@ static int launch_conv3x3_lds_r(const ConvArgs& a, int NT, int MTW, int TH, int 
     aa.bands_per_wg = cdiv(aa.total_bands, wgs);
     wgs = cdiv(aa.total_bands, aa.bands_per_wg);
     const size_t lds = conv3x3_lds_bytes(R, NT, TH, a.W, a.nchunk);
-    dim3 grid(wgs, nsplit), blk(256);
+    dim3 grid(wgs, nsplit), blk(NW * 64);
 #define RV_L3(nt, mt)                                                                              \
     if (NT == nt && MTW == mt) {                                                                  \
-        auto kern = conv3x3_lds_k<R, nt, mt>;                                                     \
+        auto kern = conv3x3_lds_k<R, nt, mt, NW>;                                                 \
         static bool attr_done = false;                                                            \
         if (!attr_done) {                                                                         \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -844,13 +845,13 @@ static int launch_conv3x3_lds_r(const ConvArgs& a, int NT, int MTW, int TH, int 
     }
     RV_L3(1, 1) RV_L3(1, 2) RV_L3(1, 4) RV_L3(1, 8)
     RV_L3(2, 1) RV_L3(2, 2) RV_L3(2, 4) RV_L3(2, 8)
-    RV_L3(3, 1) RV_L3(3, 2) RV_L3(3, 4) RV_L3(3, 8)
-    RV_L3(4, 1) RV_L3(4, 2) RV_L3(4, 4) RV_L3(4, 8)
+    RV_L3(3, 1) RV_L3(3, 2) RV_L3(3, 4)
+    RV_L3(4, 1) RV_L3(4, 2) RV_L3(4, 4)
 #undef RV_L3
     return RV_EUNSUPPORTED;
 }
 
-static int launch_conv3x3_lds(const ConvArgs& a, int R, hipStream_t st, int force_nt = 0, int force_mt = 0) {
+static int launch_conv3x3_lds(const ConvArgs& a, int R, hipStream_t st, int force_nt = 0, int force_mt = 0, int nw = 4) {
     static const int mts[4] = {8, 4, 2, 1};
     // search (NT, MTW): prefer large tiles, but need >= ~1.5 units per workgroup slot on the chip
     int best_nt = 0, best_mt = 0, best_th = 0, best_wpc = 1;
@@ -861,13 +862,13 @@ static int launch_conv3x3_lds(const ConvArgs& a, int R, hipStream_t st, int forc
         for (int k = 0; k < 4; ++k) {
             const int mt = mts[k];
             if (force_mt && mt != force_mt) continue;
-            if (nt * mt > 16 && !(nt <= 2 && mt == 8)) continue;          // accumulator budget
-            int th = (mt * 64) / a.W;
+            if (nt * mt > 16) continue;                                   // accumulator budget
+            int th = (mt * 16 * nw) / a.W;                                // nw waves x mt tiles x 16 pixels per band
             if (th > a.H) th = a.H;
             if (th < 1) continue;
             const size_t lds = conv3x3_lds_bytes(R, nt, th, a.W, a.nchunk);
             if (lds > 150 * 1024) continue;
-            const int wpc = lds <= 76 * 1024 ? 2 : 1;                      // workgroups per CU
+            const int wpc = (lds <= 76 * 1024 && nw == 4) ? 2 : 1;         // workgroups per CU
             const long bands = (long)a.B * cdiv(a.H, th) * (a.ntile_n / nt);
             const long slots = 256L * wpc;
             // efficiency model: work per slot in whole bands (tail effect) x register-level reuse
@@ -879,8 +880,11 @@ static int launch_conv3x3_lds(const ConvArgs& a, int R, hipStream_t st, int forc
         }
     }
     if (!best_nt) return RV_EUNSUPPORTED;
-    return R == 4 ? launch_conv3x3_lds_r<4>(a, best_nt, best_mt, best_th, best_wpc, st)
-                  : launch_conv3x3_lds_r<2>(a, best_nt, best_mt, best_th, best_wpc, st);
+    if (nw == 8)
+        return R == 4 ? launch_conv3x3_lds_r<4, 8>(a, best_nt, best_mt, best_th, best_wpc, st)
+                      : launch_conv3x3_lds_r<2, 8>(a, best_nt, best_mt, best_th, best_wpc, st);
+    return R == 4 ? launch_conv3x3_lds_r<4, 4>(a, best_nt, best_mt, best_th, best_wpc, st)
+                  : launch_conv3x3_lds_r<2, 4>(a, best_nt, best_mt, best_th, best_wpc, st);
 }
 
 static int frag_R(int kdim) { return (kdim % 16 == 0) ? 4 : ((kdim % 8 == 0) ? 2 : 0); }
@@ -1007,13 +1011,14 @@ int rv_conv_fwd(int mode, const float* in, int in_ld, int B, int H, int W, int C
     a.fd_pw = fastdiv_make((unsigned)a.Pw); a.fd_plane = fastdiv_make((unsigned)(a.Ph * a.Pw)); a.fd_w = fastdiv_make((unsigned)W);
     RV_CHECK_ARG(a.npix < (1L << 31), "rv_conv_fwd: more than 2^31 pixels");
     // algo: 0 = library default, 1 = LDS-free direct kernel, 2 = LDS/DMA-pipelined kernel (3x3 only),
-    // 0x100|NT<<4|MT = direct kernel with that register tile, 0x200|NT<<4|MTW = LDS kernel with that tile.
+    // 0x100|NT<<4|MT = direct kernel with that register tile, 0x200|NT<<4|MTW = LDS kernel with that tile (4 waves),
+    // 0x300|NT<<4|MTW = LDS kernel with 8 waves per workgroup (two per SIMD).
     // Forced tiles that do not fit the shape return RV_EUNSUPPORTED (the host autotuner skips them).
     const int fam = algo >> 8, f_nt = (algo >> 4) & 15, f_mt = algo & 15;
     if (mode == 0 && algo != 1 && fam != 1) {
-        int rc3 = (fam == 2) ? launch_conv3x3_lds(a, R, st, f_nt, f_mt) : launch_conv3x3_lds(a, R, st);
+        int rc3 = (fam == 2 || fam == 3) ? launch_conv3x3_lds(a, R, st, f_nt, f_mt, fam == 3 ? 8 : 4) : launch_conv3x3_lds(a, R, st);
         if (rc3 == RV_OK) { RV_LAUNCH_CHECK("rv_conv_fwd(lds)"); return RV_OK; }
-        if (fam == 2) { rv_set_error("rv_conv_fwd: forced LDS tile NT=%d MTW=%d does not fit", f_nt, f_mt); return RV_EUNSUPPORTED; }
+        if (fam == 2 || fam == 3) { rv_set_error("rv_conv_fwd: forced LDS tile NT=%d MTW=%d does not fit", f_nt, f_mt); return RV_EUNSUPPORTED; }
     }
     int NT, MT;
     choose_tiles((a.npix + 15) / 16, a.ntile_n, &NT, &MT);
