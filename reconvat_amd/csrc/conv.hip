@@ -483,9 +483,16 @@ struct WgradArgs {
 // A/B fragments with ds_read_b32 (lane (i, g): channel i of pixel x0+g, which is what the f32 MFMA wants).
 // Accumulators stay in registers across all rows; at the end the four waves are folded through LDS and
 // ONE partial per workgroup goes to the workspace (deterministic second pass: wgrad_reduce_k).
-template <int KH, int KW, int S, int P, int TA, int TB>
-__global__ __launch_bounds__(256) void wgrad_mfma_k(WgradArgs a) {
+template <int KH, int KW, int S, int P, int TA, int TB, int NW>
+__global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
     constexpr int TAPS = KH * KW, CA = TA * 16, CB = TB * 16;
+    // 8-wave workgroups put two waves on every SIMD.  With the full 32x32 channel group the accumulators of one
+    // wave would not leave room for a second one, so there the waves are split 4 (x groups) x 2 (halves of the
+    // a-tiles); otherwise all NW waves are x groups.
+    constexpr int NH = (NW == 8 && TA == 2 && TB == 2) ? 2 : 1;
+    constexpr int TAW = TA / NH;             // a-tiles owned by one wave
+    constexpr int NXG = NW / NH;             // x groups
+    constexpr int NTHR = NW * 64;
     constexpr int C4A = CA / 4, C4B = CB / 4;
     constexpr int NSLOT = (S == 1) ? KH + 1 : 2 * KH;      // input-row ring: one slot ahead of the rows in use
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -503,19 +510,20 @@ __global__ __launch_bounds__(256) void wgrad_mfma_k(WgradArgs a) {
     float* vbuf = smem + NSLOT * UP * CA;                    // [2][Wv4][CB]
     const int stage_floats = NSLOT * UP * CA + 2 * Wv4 * CB;
 
-    f32x4 acc[TAPS][TA][TB];
+    const int xg = wave % NXG, hp = wave / NXG;
+    f32x4 acc[TAPS][TAW][TB];
     f32x4 accb[TB];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-        for (int x = 0; x < TA; ++x)
+        for (int x = 0; x < TAW; ++x)
 #pragma unroll
             for (int y = 0; y < TB; ++y) acc[t][x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int y = 0; y < TB; ++y) accb[y] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = a.want_bias && ga == 0;
+    const bool do_bias = a.want_bias && ga == 0 && hp == 0;
 
-    for (int k = tid; k < stage_floats; k += 256) smem[k] = 0.f;   // padding / unused channels stay zero
+    for (int k = tid; k < stage_floats; k += NTHR) smem[k] = 0.f;   // padding / unused channels stay zero
     __syncthreads();
 
     const int ca_valid = min(CA, a.Ca - a0), cb_valid = min(CB, a.Cb - b0);
@@ -528,7 +536,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_k(WgradArgs a) {
         const bool inside = r >= 0 && r < a.Hu;
         const float* src = a.U + ((long)b * a.Hu + (inside ? r : 0)) * a.Wu * a.u_ld + a0;
         const int px_l = lane / C4A, c4 = (lane - px_l * C4A) * 4;
-        for (int k = wave; k * PPI < npxu; k += 4) {
+        for (int k = wave; k * PPI < npxu; k += NW) {
             const int px = k * PPI + px_l;
             float* ldst = dst0 + k * PPI * CA;                           // wave-uniform
             if (px < npxu && c4 < ca_valid) {
@@ -542,7 +550,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_k(WgradArgs a) {
         float* dst0 = vbuf + vb * Wv4 * CB;
         const float* src = a.V + ((long)b * a.Hv + y) * a.Wv * a.v_ld + b0;
         const int px_l = lane / C4B, c4 = (lane - px_l * C4B) * 4;
-        for (int k = wave; k * PPI < a.Wv; k += 4) {
+        for (int k = wave; k * PPI < a.Wv; k += NW) {
             const int px = k * PPI + px_l;
             if (px < a.Wv && c4 < cb_valid) glds16(src + (long)px * a.v_ld + c4, dst0 + k * PPI * CB);
         }
@@ -581,7 +589,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_k(WgradArgs a) {
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky) slot_of[ky] = slot_of_row(y, ky);
         const float* vrow = vbuf + vb * Wv4 * CB;
-        for (int x0 = wave * 4; x0 < Wv4; x0 += 16) {
+        for (int x0 = xg * 4; x0 < Wv4; x0 += 4 * NXG) {
             const int x = x0 + g;
             float vf[TB];
 #pragma unroll
@@ -592,8 +600,8 @@ __global__ __launch_bounds__(256) void wgrad_mfma_k(WgradArgs a) {
 #pragma unroll
                 for (int kx = 0; kx < KW; ++kx) {
 #pragma unroll
-                    for (int ta = 0; ta < TA; ++ta) {
-                        const float uf = ur[kx * CA + ta * 16];
+                    for (int ta = 0; ta < TAW; ++ta) {
+                        const float uf = ur[kx * CA + (hp * TAW + ta) * 16];
 #pragma unroll
                         for (int tb = 0; tb < TB; ++tb)
                             acc[ky * KW + kx][ta][tb] =
@@ -608,54 +616,56 @@ __global__ __launch_bounds__(256) void wgrad_mfma_k(WgradArgs a) {
             }
         }
     }
-    // fold the four waves through LDS (wave w > 0 publishes, wave 0 accumulates)
-    for (int w = 1; w < 4; ++w) {
+    // fold the x groups through LDS (x group w > 0 publishes, x group 0 of the same half accumulates)
+    constexpr int NACC = (TAPS * TAW * TB + TB) * 4;
+    float* fold = smem + hp * NACC * 64;
+    for (int w = 1; w < NXG; ++w) {
         __syncthreads();
-        if (wave == w) {
+        if (xg == w) {
             int q = 0;
 #pragma unroll
             for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-                for (int ta = 0; ta < TA; ++ta)
+                for (int ta = 0; ta < TAW; ++ta)
 #pragma unroll
                     for (int tb = 0; tb < TB; ++tb)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) smem[(q++) * 64 + lane] = acc[t][ta][tb][r];
+                        for (int r = 0; r < 4; ++r) fold[(q++) * 64 + lane] = acc[t][ta][tb][r];
 #pragma unroll
             for (int tb = 0; tb < TB; ++tb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) smem[(q++) * 64 + lane] = accb[tb][r];
+                for (int r = 0; r < 4; ++r) fold[(q++) * 64 + lane] = accb[tb][r];
         }
         __syncthreads();
-        if (wave == 0) {
+        if (xg == 0) {
             int q = 0;
 #pragma unroll
             for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-                for (int ta = 0; ta < TA; ++ta)
+                for (int ta = 0; ta < TAW; ++ta)
 #pragma unroll
                     for (int tb = 0; tb < TB; ++tb)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[t][ta][tb][r] += smem[(q++) * 64 + lane];
+                        for (int r = 0; r < 4; ++r) acc[t][ta][tb][r] += fold[(q++) * 64 + lane];
 #pragma unroll
             for (int tb = 0; tb < TB; ++tb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) accb[tb][r] += smem[(q++) * 64 + lane];
+                for (int r = 0; r < 4; ++r) accb[tb][r] += fold[(q++) * 64 + lane];
         }
     }
-    if (wave != 0) return;
+    if (xg != 0) return;
     // D[row = a_local = 4g+r][col = b_local = i]
     float* dst = a.part + (long)blockIdx.x * a.pstride;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-        for (int ta = 0; ta < TA; ++ta)
+        for (int ta = 0; ta < TAW; ++ta)
 #pragma unroll
             for (int tb = 0; tb < TB; ++tb) {
                 const int bb = b0 + tb * 16 + i;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int aa = a0 + ta * 16 + 4 * g + r;
+                    const int aa = a0 + (hp * TAW + ta) * 16 + 4 * g + r;
                     if (aa < a.Ca && bb < a.Cb) dst[((long)t * a.Ca + aa) * a.Cb + bb] = acc[t][ta][tb][r];
                 }
             }
@@ -1112,15 +1122,24 @@ int rv_conv_wgrad(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, co
         const int UP = SS * (Wv4 - 1) + KH;
         const int nslot = SS == 1 ? KH + 1 : 2 * KH;
         size_t lds = ((size_t)nslot * UP * TA * 16 + (size_t)2 * Wv4 * TB * 16) * sizeof(float);
-        const size_t fold = (size_t)((mode == 0 ? 9 : (mode == 1 ? 1 : 4)) * TA * TB + TB) * 4 * 64 * sizeof(float);
+        static int nw = 0;
+        if (!nw) { const char* e = getenv("RV_WGRAD_NW"); nw = (e && atoi(e) == 4) ? 4 : 8; }
+        const size_t fold = (size_t)((mode == 0 ? 9 : (mode == 1 ? 1 : 4)) * TA * TB + 2 * TB) * 4 * 64 * sizeof(float);
         if (lds < fold) lds = fold;
         RV_CHECK_ARG(lds <= 160 * 1024, "rv_conv_wgrad: row of %d pixels x %d channels does not fit LDS", Wv, TA * 16);
 #define RV_WG1(kh, kw, ss, pp, ta, tb)                                                            \
     do {                                                                                         \
-        auto kern = wgrad_mfma_k<kh, kw, ss, pp, ta, tb>;                                        \
-        if (lds > 64 * 1024)                                                                     \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, grid, blk, lds, st, a);                                         \
+        if (nw == 8) {                                                                           \
+            auto kern = wgrad_mfma_k<kh, kw, ss, pp, ta, tb, 8>;                                 \
+            if (lds > 64 * 1024)                                                                 \
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);                               \
+        } else {                                                                                 \
+            auto kern = wgrad_mfma_k<kh, kw, ss, pp, ta, tb, 4>;                                 \
+            if (lds > 64 * 1024)                                                                 \
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL(kern, grid, blk, lds, st, a);                                     \
+        }                                                                                        \
     } while (0)
 #define RV_WG(kh, kw, ss, pp)                                                                     \
     do {                                                                                         \
