@@ -872,7 +872,7 @@ static int launch_conv3x3_lds(const ConvArgs& a, int R, hipStream_t st, int forc
         for (int k = 0; k < 4; ++k) {
             const int mt = mts[k];
             if (force_mt && mt != force_mt) continue;
-            if (nt * mt > 16) continue;                                   // accumulator budget
+            if (nt * mt > 16 || (nw == 16 && nt * mt > 8)) continue;      // accumulator budget (<= 128 registers per wave at 16 waves)
             int th = (mt * 16 * nw) / a.W;                                // nw waves x mt tiles x 16 pixels per band
             if (th > a.H) th = a.H;
             if (th < 1) continue;
@@ -890,6 +890,9 @@ static int launch_conv3x3_lds(const ConvArgs& a, int R, hipStream_t st, int forc
         }
     }
     if (!best_nt) return RV_EUNSUPPORTED;
+    if (nw == 16)
+        return R == 4 ? launch_conv3x3_lds_r<4, 16>(a, best_nt, best_mt, best_th, best_wpc, st)
+                      : launch_conv3x3_lds_r<2, 16>(a, best_nt, best_mt, best_th, best_wpc, st);
     if (nw == 8)
         return R == 4 ? launch_conv3x3_lds_r<4, 8>(a, best_nt, best_mt, best_th, best_wpc, st)
                       : launch_conv3x3_lds_r<2, 8>(a, best_nt, best_mt, best_th, best_wpc, st);
@@ -1022,13 +1025,13 @@ int rv_conv_fwd(int mode, const float* in, int in_ld, int B, int H, int W, int C
     RV_CHECK_ARG(a.npix < (1L << 31), "rv_conv_fwd: more than 2^31 pixels");
     // algo: 0 = library default, 1 = LDS-free direct kernel, 2 = LDS/DMA-pipelined kernel (3x3 only),
     // 0x100|NT<<4|MT = direct kernel with that register tile, 0x200|NT<<4|MTW = LDS kernel with that tile (4 waves),
-    // 0x300|NT<<4|MTW = LDS kernel with 8 waves per workgroup (two per SIMD).
+    // 0x300|NT<<4|MTW = LDS kernel with 8 waves per workgroup (two per SIMD), 0x400|... = 16 waves (four per SIMD).
     // Forced tiles that do not fit the shape return RV_EUNSUPPORTED (the host autotuner skips them).
     const int fam = algo >> 8, f_nt = (algo >> 4) & 15, f_mt = algo & 15;
     if (mode == 0 && algo != 1 && fam != 1) {
-        int rc3 = (fam == 2 || fam == 3) ? launch_conv3x3_lds(a, R, st, f_nt, f_mt, fam == 3 ? 8 : 4) : launch_conv3x3_lds(a, R, st);
+        int rc3 = (fam >= 2 && fam <= 4) ? launch_conv3x3_lds(a, R, st, f_nt, f_mt, fam == 4 ? 16 : (fam == 3 ? 8 : 4)) : launch_conv3x3_lds(a, R, st);
         if (rc3 == RV_OK) { RV_LAUNCH_CHECK("rv_conv_fwd(lds)"); return RV_OK; }
-        if (fam == 2 || fam == 3) { rv_set_error("rv_conv_fwd: forced LDS tile NT=%d MTW=%d does not fit", f_nt, f_mt); return RV_EUNSUPPORTED; }
+        if (fam >= 2 && fam <= 4) { rv_set_error("rv_conv_fwd: forced LDS tile NT=%d MTW=%d does not fit", f_nt, f_mt); return RV_EUNSUPPORTED; }
     }
     int NT, MT;
     choose_tiles((a.npix + 15) / 16, a.ntile_n, &NT, &MT);
