@@ -411,56 +411,79 @@ struct SmallArgs {
 };
 
 // COUT >= 4: four output channels per thread (COUT/4 threads per pixel) so that a wave's stores are
-// contiguous 16-byte pieces; COUT < 4: one thread per pixel.
+// contiguous 16-byte pieces; the thread's KH*KW*CIN*4 weights and its bias stay in registers while it
+// walks pixels with a grid stride (the stride is a multiple of COUT/4, so its channel quad never changes).
+// COUT < 4: one thread per pixel, weights through the scalar cache.
 template <int CIN, int COUT, int KH, int KW, int S, int P>
 __global__ __launch_bounds__(256) void conv_small_k(SmallArgs a) {
     constexpr int CPT = COUT >= 4 ? 4 : COUT;        // output channels per thread
     constexpr int TPP = COUT / CPT;                  // threads per pixel
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long p = t / TPP;
-    const int c0 = (int)(t - p * TPP) * CPT;
-    if (p >= a.npix) return;
-    int b = (int)(p / ((long)a.Ho * a.Wo));
-    int rem = (int)(p - (long)b * a.Ho * a.Wo);
-    int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-    float acc[CPT];
+    constexpr bool WREG = (TPP > 1) && (KH * KW * CIN * CPT <= 80);
+    const long tstride = (long)gridDim.x * blockDim.x;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c0 = (int)(t % TPP) * CPT;
+    float wreg[WREG ? KH * KW * CIN * CPT : 1];
+    if constexpr (WREG) {
 #pragma unroll
-    for (int co = 0; co < CPT; ++co) acc[co] = a.bias ? a.bias[c0 + co] : 0.f;
-#pragma unroll
-    for (int ky = 0; ky < KH; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < KW; ++kx) {
-            int iy = oy * S - P + ky, ix = ox * S - P + kx;
-            if ((unsigned)iy >= (unsigned)a.H || (unsigned)ix >= (unsigned)a.W) continue;
-            const float* src = a.in + (((long)b * a.H + iy) * a.W + ix) * a.in_ld;
-            const float* w = a.wplain + (ky * KW + kx) * CIN * COUT + c0;
-            float xin[CIN];
-            if constexpr (CIN % 4 == 0) {
-#pragma unroll
-                for (int c = 0; c < CIN; c += 4) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
-                    xin[c] = v[0]; xin[c + 1] = v[1]; xin[c + 2] = v[2]; xin[c + 3] = v[3];
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < CIN; ++c) xin[c] = src[c];
-            }
+        for (int tap = 0; tap < KH * KW; ++tap)
 #pragma unroll
             for (int c = 0; c < CIN; ++c)
 #pragma unroll
-                for (int co = 0; co < CPT; ++co) acc[co] = fmaf(xin[c], w[c * COUT + co], acc[co]);
+                for (int co = 0; co < CPT; ++co) wreg[(tap * CIN + c) * CPT + co] = a.wplain[(tap * CIN + c) * COUT + c0 + co];
+    }
+    float bias[CPT];
+#pragma unroll
+    for (int co = 0; co < CPT; ++co) bias[co] = a.bias ? a.bias[c0 + co] : 0.f;
+    for (; t < a.npix * TPP; t += tstride) {
+        const long p = t / TPP;
+        int b = (int)(p / ((long)a.Ho * a.Wo));
+        int rem = (int)(p - (long)b * a.Ho * a.Wo);
+        int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        float acc[CPT];
+#pragma unroll
+        for (int co = 0; co < CPT; ++co) acc[co] = bias[co];
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                int iy = oy * S - P + ky, ix = ox * S - P + kx;
+                if ((unsigned)iy >= (unsigned)a.H || (unsigned)ix >= (unsigned)a.W) continue;
+                const float* src = a.in + (((long)b * a.H + iy) * a.W + ix) * a.in_ld;
+                const float* w = a.wplain + (ky * KW + kx) * CIN * COUT + c0;
+                float xin[CIN];
+                if constexpr (CIN % 4 == 0) {
+#pragma unroll
+                    for (int c = 0; c < CIN; c += 4) {
+                        f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+                        xin[c] = v[0]; xin[c + 1] = v[1]; xin[c + 2] = v[2]; xin[c + 3] = v[3];
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CIN; ++c) xin[c] = src[c];
+                }
+#pragma unroll
+                for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                    for (int co = 0; co < CPT; ++co) {
+                        const float wv = WREG ? wreg[((ky * KW + kx) * CIN + c) * CPT + co] : w[c * COUT + co];
+                        acc[co] = fmaf(xin[c], wv, acc[co]);
+                    }
+            }
+        float* o = a.out + p * a.out_ld + c0;
+        bool done = false;
+        if constexpr (CPT == 4) {
+            f32x4 v = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+            if ((a.out_ld & 3) == 0) {
+                if (a.accumulate) { f32x4 old = *reinterpret_cast<f32x4*>(o); v += old; }
+                *reinterpret_cast<f32x4*>(o) = v;
+                done = true;
+            }
         }
-    float* o = a.out + p * a.out_ld + c0;
-    if constexpr (CPT == 4) {
-        f32x4 v = (f32x4){acc[0], acc[1], acc[2], acc[3]};
-        if ((a.out_ld & 3) == 0) {
-            if (a.accumulate) { f32x4 old = *reinterpret_cast<f32x4*>(o); v += old; }
-            *reinterpret_cast<f32x4*>(o) = v;
-            return;
+        if (!done) {
+#pragma unroll
+            for (int co = 0; co < CPT; ++co) o[co] = a.accumulate ? o[co] + acc[co] : acc[co];
         }
     }
-#pragma unroll
-    for (int co = 0; co < CPT; ++co) o[co] = a.accumulate ? o[co] + acc[co] : acc[co];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -987,7 +1010,9 @@ int rv_conv_fwd(int mode, const float* in, int in_ld, int B, int H, int W, int C
         s.in = in; s.in_ld = in_ld; s.H = H; s.W = W; s.out = out; s.out_ld = out_ld; s.Ho = Ho; s.Wo = Wo;
         s.B = B; s.wplain = wpack; s.bias = bias; s.npix = (long)B * Ho * Wo; s.accumulate = accumulate;
         const int tpp = Cout >= 4 ? Cout / 4 : 1;
-        dim3 grid(cdiv(s.npix * tpp, 256)), blk(256);
+        long nblk = cdiv(s.npix * tpp, 256);
+        if (nblk > 4096) nblk = 4096;            // grid stride (4096*256 is a multiple of every COUT/4)
+        dim3 grid((unsigned)nblk), blk(256);
 #define RV_SMALL(ci, co, kh, kw, ss, pp)                                                          \
     if (Cin == ci && Cout == co) {                                                               \
         hipLaunchKernelGGL((conv_small_k<ci, co, kh, kw, ss, pp>), grid, blk, 0, st, s);         \

@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_k(const float* g1, int ld1, c
     }
 }
 
-// column sums of a [M, N] matrix (bias gradients of the linear layers): out[n] (+)= sum_m x[m*ld + n]
+// column sums of a [M, N] matrix (bias gradients): out[n] (+)= sum_m x[m*ld + n]
+// generic version: 64 columns x 4 row lanes per workgroup
 __global__ __launch_bounds__(256) void colsum_k(const float* x, int ld, long M, int N, float* out, int rows_per_block) {
     __shared__ float sh[4][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -153,6 +154,33 @@ __global__ __launch_bounds__(256) void colsum_k(const float* x, int ld, long M, 
     sh[rl][threadIdx.x & 63] = s;
     __syncthreads();
     if (rl == 0 && col < N) atomicAdd(&out[col], (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]));
+}
+
+// narrow matrices (N % 4 == 0, N <= 256; the up-conv bias gradients over millions of pixels): 16-byte loads,
+// thread -> (column quad, row lane), 32 rows per thread, LDS fold, one atomic per column per workgroup
+__global__ __launch_bounds__(256) void colsum_vec_k(const float* x, int ld, long M, int N, float* out) {
+    __shared__ float sh[256 * 4];
+    const int C4 = N >> 2, PL = 256 / C4;
+    const int t = threadIdx.x;
+    const int c = (t % C4) * 4, pl = t / C4;
+    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (pl < PL) {
+        const long p0 = (long)blockIdx.x * PL * 32;
+#pragma unroll 4
+        for (int k = 0; k < 32; ++k) {
+            const long p = p0 + pl + (long)k * PL;
+            if (p >= M) break;
+            s += *reinterpret_cast<const f32x4*>(x + p * ld + c);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sh[pl * N + c + q] = s[q];
+    }
+    __syncthreads();
+    if (t < N) {
+        float d = 0.f;
+        for (int l = 0; l < PL; ++l) d += sh[l * N + t];
+        atomicAdd(&out[t], d);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -259,9 +287,14 @@ int rv_sigmoid_bwd(const float* g1, int ld1, const float* g2, int ld2, const flo
 int rv_colsum(const float* x, int ld, long M, int N, float* out, int accumulate, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * N, st);
-    int rpb = 256;
-    dim3 grid(cdiv(N, 64), cdiv(M, rpb));
-    hipLaunchKernelGGL(colsum_k, grid, dim3(256), 0, st, x, ld, M, N, out, rpb);
+    if ((N & 3) == 0 && N <= 256 && (ld & 3) == 0 && ((((uintptr_t)x) & 15) == 0) && M >= 4096) {
+        const int PL = 256 / (N / 4);
+        hipLaunchKernelGGL(colsum_vec_k, dim3(cdiv(M, (long)PL * 32)), dim3(256), 0, st, x, ld, M, N, out);
+    } else {
+        int rpb = 256;
+        dim3 grid(cdiv(N, 64), cdiv(M, rpb));
+        hipLaunchKernelGGL(colsum_k, grid, dim3(256), 0, st, x, ld, M, N, out, rpb);
+    }
     RV_LAUNCH_CHECK("rv_colsum");
     return RV_OK;
 }
