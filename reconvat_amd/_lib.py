@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libreconvat_hip.so')
+# RECONVAT_HIP_LIB: A/B another build of the same ABI (kernel experiments); default = the in-tree library
+LIB_PATH = os.environ.get('RECONVAT_HIP_LIB') or os.path.join(_HERE, 'libreconvat_hip.so')
 
 P = ctypes.c_void_p
 I = ctypes.c_int

@@ -240,15 +240,53 @@ __global__ __launch_bounds__(256) void conv_mfma_k(ConvArgs a) {
 // per unit.  M-tiles are 16 consecutive pixels of the flattened band (no waste on the odd widths);
 // tile t belongs to wave t % 4.  Accumulator layout / epilogue as conv_mfma_k.
 // ------------------------------------------------------------------------------------------
+// Timing experiments only (tools/bench_conv.py with RV_ABLATE=bits; results are wrong by design): compile with
+// -DRV_ABLATION to honour ConvLdsArgs::ablate.  Bits: 1 barrier, 2 staging, 4 MFMAs, 8 stores, 16 LDS reads,
+// 32/64/128 early returns (launch floor / prologue / before the first DMA).
+#ifdef RV_ABLATION
+#define ABL(aa) ((aa).ablate)
+#else
+#define ABL(aa) 0
+#endif
 struct ConvLdsArgs {
     ConvArgs c;
     int TH, nbands, total_bands, bands_per_wg;
+    int nbuf;          // LDS unit buffers (2 or 3): prefetch distance nbuf-1
+    int skew;          // nbuf == 3: half of the waves stage after their multiplies
+    int ablate;        // ABLATION (timing experiments only)
+    int nsplit, xcd;   // n-splits per band group; XCD-aware placement on/off
 };
 
 __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
     // LDS destination = wave-uniform base + lane*16 bytes (hardware adds the lane offset)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// wait until at most n of this wave's VMEM operations are outstanding (n wave-uniform; clamping down is safe)
+__device__ __forceinline__ void wait_vmcnt_le(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    }
+}
+
+// hand-issued LDS reads (see the tap loop of conv3x3_lds_k): the compiler does not track them, the caller waits
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
+}
+__device__ __forceinline__ void lds_read(f32x4& v, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void lds_read(f32x2& v, unsigned addr) {
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory");
 }
 
 template <int R, int NT, int MTW, int NW>
@@ -269,47 +307,108 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
     const int W = a.W, H = a.H, W2 = W + 2, TH = aa.TH;
     const int nrow = TH + 2;
     const int xfloats = nrow * W2 * KC;
-    const int nt0 = blockIdx.y * NT;
-    float* xs0 = smem;                                   // [2][nrow][W2][KC]
-    float* ws0 = smem + 2 * xfloats;                     // [2][9][NT][64][R]
-    const int band_lo = blockIdx.x * aa.bands_per_wg;
+    // XCD-aware placement (1-D grid): every XCD gets a contiguous run of (band group, n-split) pairs with the
+    // splits fastest, so the workgroups that re-read the same input rows -- the n-splits of one band group and
+    // the neighbouring band groups (halo rows) -- share one L2 instead of pulling the rows into several.
+    if (ABL(aa) & 32) return;
+    const int vid = aa.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int grp = vid / aa.nsplit, split = vid - grp * aa.nsplit;
+    const int nt0 = split * NT;
+    const int nbuf = aa.nbuf;
+    float* xs0 = smem;                                   // [nbuf][nrow][W2][KC]
+    float* ws0 = smem + nbuf * xfloats;                  // [nbuf][9][NT][64][R]
+    const int band_lo = grp * aa.bands_per_wg;
     const int band_hi = min(band_lo + aa.bands_per_wg, aa.total_bands);
     if (band_lo >= band_hi) return;
     const int nchunk = a.nchunk;
     const int nunits = (band_hi - band_lo) * nchunk;
     const int ipr = (W + PPI - 1) / PPI;                 // DMA instructions per input row
 
-    auto stage = [&](int u) {
-        const int band = band_lo + u / nchunk, c = u - (u / nchunk) * nchunk;
-        const int b = band / aa.nbands, y0 = (band - b * aa.nbands) * TH;
-        float* xb = xs0 + (u & 1) * xfloats;
-        const float* src0 = a.in + (long)b * H * W * a.in_ld + c * KC;
-        const int nx = nrow * ipr;
-        for (int i = wave; i < nx; i += NW) {
+    // ---- staging plan.  Staging is instruction-issue bound and does not hide under the other waves' MFMAs, so
+    // everything that does not depend on the unit is computed ONCE per wave: per DMA slot the lane's byte offset
+    // from the unit's first input row / from the chunk's first weight fragment, the LDS destination and the lane
+    // mask.  Per unit that leaves two scalar base pointers and one DMA instruction per slot. ----
+    constexpr int TXF = 4;                                // x slots planned in registers (any further: generic loop)
+    constexpr int NWF = (9 * NT + FPI - 1) / FPI;         // weight DMA instructions per unit (whole workgroup)
+    constexpr int TW = (NWF + NW - 1) / NW;               // ... per wave
+    const int nx = nrow * ipr;
+    int xs_row[TXF], xs_ldst[TXF];
+    unsigned xs_goff[TXF];
+    bool xs_lane[TXF];
+#pragma unroll
+    for (int t = 0; t < TXF; ++t) {
+        const int i = wave + NW * t;
+        const int row = i / ipr, k = i - row * ipr;
+        const int px = k * PPI + lane / Q, q = lane - (lane / Q) * Q;
+        xs_row[t] = row;
+        xs_ldst[t] = (row * W2 + 1 + k * PPI) * KC;
+        xs_goff[t] = (unsigned)((row * W + px) * a.in_ld + q * 4) * 4u;
+        xs_lane[t] = i < nx && px < W;
+    }
+    unsigned w_off[TW];
+    bool w_lane[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        const int i = wave + NW * t;
+        const int f = i * FPI + lane / LPF, o = lane - (lane / LPF) * LPF;
+        const int tap = f / NT, n = f - tap * NT;
+        w_lane[t] = i < NWF && f < 9 * NT;
+        w_off[t] = (unsigned)((tap * nchunk * a.ntile_n + nt0 + n) * 64 * R + o * 4) * 4u;
+    }
+    const int b_first = band_lo / aa.nbands, y_first = (band_lo - b_first * aa.nbands) * TH;
+    int sg_u = 0, sg_buf = 0, sg_b = b_first, sg_y0 = y_first, sg_c = 0;      // staging cursor (units in order)
+
+    // issues the DMA of the next unit; returns how many VMEM instructions this wave issued (wave-uniform)
+    auto stage = [&]() -> int {
+        int issued = 0;
+        float* xb = xs0 + sg_buf * xfloats;
+        const char* src = reinterpret_cast<const char*>(a.in + ((long)(sg_b * H + sg_y0 - 1) * W) * a.in_ld + sg_c * KC);
+#pragma unroll
+        for (int t = 0; t < TXF; ++t) {
+            if (wave + NW * t >= nx) break;
+            const int gy = sg_y0 - 1 + xs_row[t];
+            float* ldst = xb + xs_ldst[t];                               // wave-uniform
+            if (gy >= 0 && gy < H) {
+                if (xs_lane[t]) glds16(reinterpret_cast<const float*>(src + xs_goff[t]), ldst);
+                ++issued;
+            } else if (xs_lane[t]) {
+                *reinterpret_cast<f32x4*>(ldst + lane * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        for (int i = wave + NW * TXF; i < nx; i += NW) {                 // narrow workgroups on wide rows
             const int row = i / ipr, k = i - row * ipr;
-            const int gy = y0 - 1 + row;
+            const int gy = sg_y0 - 1 + row;
             const int px = k * PPI + lane / Q, q = lane - (lane / Q) * Q;
-            float* ldst = xb + (row * W2 + 1 + k * PPI) * KC;            // wave-uniform
-            if (px < W) {
-                if (gy >= 0 && gy < H) glds16(src0 + ((long)gy * W + px) * a.in_ld + q * 4, ldst);
-                else *reinterpret_cast<f32x4*>(ldst + lane * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            float* ldst = xb + (row * W2 + 1 + k * PPI) * KC;
+            if (gy >= 0 && gy < H) {
+                if (px < W) glds16(reinterpret_cast<const float*>(src) + ((long)row * W + px) * a.in_ld + q * 4, ldst);
+                ++issued;
+            } else if (px < W) {
+                *reinterpret_cast<f32x4*>(ldst + lane * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        if (nchunk > 1 || u == 0) {
-            float* wb = ws0 + ((nchunk > 1) ? (u & 1) : 0) * WFLOATS;
-            constexpr int NWF = (9 * NT + FPI - 1) / FPI;
-            for (int i = wave; i < NWF; i += NW) {
-                const int f = i * FPI + lane / LPF, o = lane - (lane / LPF) * LPF;
-                if (f < 9 * NT) {
-                    const int tap = f / NT, n = f - tap * NT;
-                    glds16(a.wpack + (((long)tap * nchunk + c) * a.ntile_n + nt0 + n) * 64 * R + o * 4, wb + i * 256);
-                }
+        if (nchunk > 1 || sg_u == 0) {
+            float* wb = ws0 + ((nchunk > 1) ? sg_buf : 0) * WFLOATS;
+            const char* wsrc = reinterpret_cast<const char*>(a.wpack + (long)sg_c * a.ntile_n * 64 * R);
+#pragma unroll
+            for (int t = 0; t < TW; ++t) {
+                if (wave + NW * t >= NWF) break;
+                if (w_lane[t]) glds16(reinterpret_cast<const float*>(wsrc + w_off[t]), wb + (wave + NW * t) * 256);
+                ++issued;
             }
         }
+        ++sg_u;
+        if (++sg_buf == nbuf) sg_buf = 0;
+        if (++sg_c == nchunk) {
+            sg_c = 0;
+            sg_y0 += TH;
+            if (sg_y0 >= H) { sg_y0 = 0; ++sg_b; }
+        }
+        return issued;
     };
 
     // halo columns of both buffers are zero for the whole kernel (the DMA never touches them)
-    for (int k = tid; k < 2 * nrow * 2 * KC; k += NTHR) {
+    for (int k = tid; k < nbuf * nrow * 2 * KC; k += NTHR) {
         const int buf = k / (nrow * 2 * KC), rem = k - buf * (nrow * 2 * KC);
         const int row = rem / (2 * KC), rem2 = rem - row * (2 * KC);
         const int side = rem2 / KC, ch = rem2 - side * KC;
@@ -326,10 +425,22 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[n][r] = (a.bias && cb + r < a.Cout) ? a.bias[cb + r] : 0.f;
     }
-    stage(0);
+    // units 0 .. nbuf-2 are in flight before the first multiply; `ahead` = VMEM instructions of this wave that
+    // belong to LATER units than the one about to be multiplied (they may stay outstanding: loads return in order)
+    if (ABL(aa) & 128) return;
+    stage();
+    int ahead = 0;
+    if (nbuf > 2 && nunits > 1) ahead = stage();
+    if (ABL(aa) & 64) return;
+    int cu_buf = 0, cu_b = b_first, cu_y0 = y_first, cu_c = 0;                // compute cursor
     for (int u = 0; u < nunits; ++u) {
-        const int band = band_lo + u / nchunk, c = u - (u / nchunk) * nchunk;
-        const int b = band / aa.nbands, y0 = (band - b * aa.nbands) * TH;
+        const int b = cu_b, y0 = cu_y0, c = cu_c, buf = cu_buf;
+        if (++cu_buf == nbuf) cu_buf = 0;
+        if (++cu_c == nchunk) {
+            cu_c = 0;
+            cu_y0 += TH;
+            if (cu_y0 >= H) { cu_y0 = 0; ++cu_b; }
+        }
         const int th = min(TH, H - y0);
         const int npx = th * W;
         const int ntile = (npx + 15) >> 4;
@@ -346,37 +457,56 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
                 for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of unit u has landed
-        __syncthreads();                                    // ... and everyone's; unit u-1's buffer is free
-        if (u + 1 < nunits) stage(u + 1);                   // DMA runs under the MFMAs below
-        const float* xs = xs0 + (u & 1) * xfloats;
-        const float* ws = ws0 + ((nchunk > 1) ? (u & 1) : 0) * WFLOATS;
+        wait_vmcnt_le(ahead);                               // this wave's share of unit u has landed
+        if (!(ABL(aa) & 1)) __syncthreads();              // ... and everyone's; unit u-1's buffer is free
+        // The waves that share a SIMD stage at opposite ends of the unit (prefetch distance 2 only), so one wave's
+        // address arithmetic / DMA issue overlaps the other's MFMAs instead of both idling the matrix pipe together.
+        const bool late = aa.skew && ((wave >> 2) & 1);
+        if (!late && !(ABL(aa) & 2)) ahead = (sg_u < nunits) ? stage() : 0;   // DMA runs under the MFMAs below
+        const float* xs = xs0 + buf * xfloats;
+        const float* ws = ws0 + ((nchunk > 1) ? buf : 0) * WFLOATS;
+        // Software-pipelined tap loop: the fragments of tap t+1 are in flight while tap t is multiplied.  The
+        // ds_reads and their s_waitcnt are issued by hand: with LDS-DMA pending the compiler's own wait-count
+        // model degrades every LDS wait to lgkmcnt(0), which would serialise the prefetch again.
+        vec wf[2][NT], xf[2][MTW];
+        const unsigned ws_a = lds_addr(ws) + lane * (R * 4);
+        unsigned xs_a[MTW];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int m = 0; m < MTW; ++m) xs_a[m] = lds_addr(xs) + lbase[m] * 4;
+        auto ldtap = [&](const int buf, const int tap) {
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int tap = ky * 3 + kx;
-                vec wf[NT];
+            for (int n = 0; n < NT; ++n) lds_read(wf[buf][n], ws_a + (tap * NT + n) * 64 * R * 4);
+            const int toff = ((tap / 3) * W2 + (tap % 3)) * KC * 4;
 #pragma unroll
-                for (int n = 0; n < NT; ++n) wf[n] = *reinterpret_cast<const vec*>(ws + ((tap * NT + n) * 64 + lane) * R);
-                const int toff = (ky * W2 + kx) * KC;
-                vec xf[MTW];
+            for (int m = 0; m < MTW; ++m) lds_read(xf[buf][m], xs_a[m] + toff);
+        };
+        ldtap(0, 0);
+        if (!(ABL(aa) & 4))
 #pragma unroll
-                for (int m = 0; m < MTW; ++m) xf[m] = *reinterpret_cast<const vec*>(xs + lbase[m] + toff);
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-#pragma unroll
-                    for (int n = 0; n < NT; ++n)
-#pragma unroll
-                        for (int m = 0; m < MTW; ++m)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][r], xf[m][r], acc[m][n], 0, 0, 0);
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) {
+                if (!(ABL(aa) & 16)) ldtap((tap + 1) & 1, tap + 1);
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NT + MTW) : "memory");   // tap's own fragments have landed
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tap & 1][n][r], xf[tap & 1][m][r], acc[m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (late && !(ABL(aa) & 2)) ahead = (sg_u < nunits) ? stage() : 0;
         if (c != nchunk - 1) continue;
         // epilogue of this band
         const long pix0 = ((long)b * H + y0) * W;
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
-            if (!pv[m]) continue;
+            if (!pv[m] || (ABL(aa) & 8)) continue;
             const long opix = pix0 + (wave + NW * m) * 16 + j;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -848,8 +978,8 @@ static void choose_tiles(long ntiles, int ntile_n, int* NT, int* MT) {
 }
 
 // LDS-pipelined 3x3 launch: pick (NT, MTW, TH) so that two units fit LDS and the persistent grid covers the chip
-static size_t conv3x3_lds_bytes(int R, int NT, int TH, int W, int nchunk) {
-    return ((size_t)2 * (TH + 2) * (W + 2) * 4 * R + (size_t)(nchunk > 1 ? 2 : 1) * 9 * NT * 64 * R) * sizeof(float);
+static size_t conv3x3_lds_bytes(int R, int NT, int TH, int W, int nchunk, int nbuf = 2) {
+    return ((size_t)nbuf * (TH + 2) * (W + 2) * 4 * R + (size_t)(nchunk > 1 ? nbuf : 1) * 9 * NT * 64 * R) * sizeof(float);
 }
 
 template <int R, int NW>
@@ -863,8 +993,18 @@ static int launch_conv3x3_lds_r(const ConvArgs& a, int NT, int MTW, int TH, int 
     if (wgs > aa.total_bands) wgs = aa.total_bands;
     aa.bands_per_wg = cdiv(aa.total_bands, wgs);
     wgs = cdiv(aa.total_bands, aa.bands_per_wg);
-    const size_t lds = conv3x3_lds_bytes(R, NT, TH, a.W, a.nchunk);
-    dim3 grid(wgs, nsplit), blk(NW * 64);
+    // RV_CONV_NBUF=3: a third unit buffer (prefetch distance 2) when it fits.  Measured neutral on MI355X (the
+    // kernel is not DMA-latency bound), so two buffers -- less LDS -- stay the default.
+    static const int nbuf_env = getenv("RV_CONV_NBUF") ? atoi(getenv("RV_CONV_NBUF")) : 0;
+    aa.nbuf = 2;
+    if (nbuf_env == 3 && conv3x3_lds_bytes(R, NT, TH, a.W, a.nchunk, 3) <= (size_t)(wgs_per_cu > 1 ? 76 : 150) * 1024) aa.nbuf = 3;
+    aa.ablate = getenv("RV_ABLATE") ? atoi(getenv("RV_ABLATE")) : 0;
+    static const int skew_env = getenv("RV_CONV_SKEW") ? atoi(getenv("RV_CONV_SKEW")) : 1;
+    aa.skew = (aa.nbuf == 3 && NW >= 8) ? skew_env : 0;
+    const size_t lds = conv3x3_lds_bytes(R, NT, TH, a.W, a.nchunk, aa.nbuf);
+    static const int xcd_env = getenv("RV_CONV_XCD") ? atoi(getenv("RV_CONV_XCD")) : 1;
+    aa.nsplit = nsplit; aa.xcd = xcd_env;
+    dim3 grid(wgs * nsplit), blk(NW * 64);
 #define RV_L3(nt, mt)                                                                              \
     if (NT == nt && MTW == mt) {                                                                  \
         auto kern = conv3x3_lds_k<R, nt, mt, NW>;                                                 \

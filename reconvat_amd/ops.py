@@ -5,6 +5,8 @@ numeric kernel is a hand-written HIP kernel (reconvat_amd/csrc).  There is no CP
 Internal activation layout is NHWC ([B, H=time, W=bins, C]); a tensor handed to a conv may be a channel
 slice (view) of a wider buffer -- the pixel stride is taken from ``stride(2)``.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -187,7 +189,9 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
     capture an untuned shape uses the library default."""
     args = (mode, ptr(x), ild, bb, h, wd, cin, ptr(out), old, ho, wo, cout, ptr(wpack), ptr(bias), 0)
     algo = 0
-    if mode == 0 and AUTOTUNE:
+    if mode == 0 and os.environ.get('RV_FORCE_ALGO'):      # kernel experiments (tools/bench_conv.py)
+        algo = int(os.environ['RV_FORCE_ALGO'], 0)
+    elif mode == 0 and AUTOTUNE:
         key = (bb, h, wd, cin, cout, ild, old)
         algo = _algo_cache.get(key, -1)
         if algo < 0:

@@ -31,6 +31,26 @@ def run():
         ops.conv_wgrad(kind, x, dy, wt, True)
 
 
+if os.environ.get('BURST'):
+    # short bursts after a pause: the clock state of a conv launch inside a real training step (mixed with
+    # bandwidth-bound kernels) rather than that of a sustained MFMA loop
+    import time
+    samples = []
+    for _ in range(8):
+        torch.cuda.synchronize()
+        time.sleep(0.02)
+        run(); run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            run()
+        e1.record()
+        e1.synchronize()
+        samples.append(e0.elapsed_time(e1) / 5)
+    ms = sorted(samples)[len(samples) // 2]
+    print(f'{what} {kind} {cin}->{cout} {h}x{w}: {ms * 1e3:.1f} us  {flops / ms / 1e9:.1f} TFLOP/s (bursts)')
+    sys.exit(0)
+
 for _ in range(3):
     run()
 torch.cuda.synchronize()

@@ -1,6 +1,6 @@
 """Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / average, like --stats.
 
-    python tools/rocpd_stats.py gpurun_out/prof1/r1_results.db [--steps N] > profiles/xyz.txt
+    python tools/rocpd_stats.py gpurun_out/prof1/r1_results.db [--steps N] [--tail-ms X] > profiles/xyz.txt
 """
 import re
 import sqlite3
@@ -16,10 +16,15 @@ def short(name):
 def main():
     db = sqlite3.connect(sys.argv[1])
     steps = int(sys.argv[sys.argv.index('--steps') + 1]) if '--steps' in sys.argv else None
+    where = ''
+    if '--tail-ms' in sys.argv:      # only the dispatches of the last X ms of the trace (the timed steps)
+        tail = float(sys.argv[sys.argv.index('--tail-ms') + 1])
+        end = db.execute('select max(end) from kernels').fetchone()[0]
+        where = f'where start >= {end - int(tail * 1e6)} '
     rows = db.execute('select name, count(*), sum(duration), avg(duration), min(duration), max(duration) '
-                      'from kernels group by name order by sum(duration) desc').fetchall()
+                      f'from kernels {where}group by name order by sum(duration) desc').fetchall()
     total = sum(r[2] for r in rows)
-    span = db.execute('select min(start), max(end) from kernels').fetchone()
+    span = db.execute(f'select min(start), max(end) from kernels {where}').fetchone()
     print(f'# kernels: {sum(r[1] for r in rows)} dispatches, {len(rows)} distinct, total kernel time {total / 1e6:.3f} ms, '
           f'trace span {(span[1] - span[0]) / 1e6:.3f} ms')
     if steps:
