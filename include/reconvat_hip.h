@@ -41,14 +41,18 @@ int rv_melspec_lognorm_fwd(const float* audio, long audio_stride, int B, int nsa
  * rv_conv_fwd mode: 0 = 3x3 s1 p1, 1 = 1x1, 2 = 2x2/s2 gather (down fwd, up dgrad), 3 = 2x2/s2 scatter
  *   (ConvTranspose2d(k=2,s=2)(x, output_size=...) fwd, down dgrad).  Forward AND input-gradient of
  *   every layer are instances of it (the packing decides which).  algo: 0 default, 1 LDS-free direct kernel,
- *   2 LDS/DMA-pipelined kernel (3x3 only) -- the host autotunes 1 vs 2 per layer shape.
+ *   2 LDS/DMA-pipelined kernel (3x3 only) -- the host autotunes 1 vs 2 per layer shape.  bn_sums (nullable,
+ *   [2*Cout] fp64, += ): per-channel sum / sum of squares of the written output, i.e. the batch statistics of the
+ *   BatchNorm2d that consumes it (conv -> bn call sites, model/UNet_onset.py:196-198,221-223), produced in the conv
+ *   epilogue; pass the same buffer to rv_bn_lrelu_fwd as `workspace` with sums_ready = 1.
  * rv_conv_wgrad: G[tap][a][b] = sum_p U[f(p,tap)][a]*V[p][b] (+ column sums of V for the bias), written
  *   to dw[a*s_a + b*s_b + tap'] / dbias[b]; mode 0 = 3x3, 1 = 1x1, 2 = 2x2/s2. */
 long rv_packed_weight_floats(int taps, int kdim, int ndim);
 int rv_pack_weights(const float* w, float* out, int taps, int kdim, int ndim, long s_k, long s_n, int flip,
                     int scatter_cmid, int force_plain, void* stream);
 int rv_conv_fwd(int mode, const float* in, int in_ld, int B, int H, int W, int Cin, float* out, int out_ld, int Ho,
-                int Wo, int Cout, const float* wpack, const float* bias, int accumulate, int algo, void* stream);
+                int Wo, int Cout, const float* wpack, const float* bias, int accumulate, int algo, double* bn_sums,
+                void* stream);
 long rv_conv_wgrad_workspace_bytes(int taps, int B, int Hv, int Ca, int Cb);
 int rv_conv_wgrad(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, const float* V, int v_ld, int Hv, int Wv,
                   int Cb, int B, float* dw, long s_a, long s_b, int flip, float* dbias, int accumulate, void* workspace,
@@ -57,11 +61,13 @@ int rv_conv_wgrad(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, co
 /* ---- BatchNorm2d(momentum=0.1) + leaky_relu (+ residual) (model/UNet_onset.py:183,196-199,221-223) --
  * coef [5C] = mean, invstd, scale, shift, unbiased batch variance (saved for backward).  training: 0 eval, 1 train,
  * 2 train without touching the running statistics (rv_bn_running_update applies that update later, in sequence).  workspace: rv_bn_workspace_bytes(C) bytes that are
- * ALL-ZERO on entry (fp64 per-channel sums accumulate there); the host carves them from one arena cleared per step. */
+ * ALL-ZERO on entry (fp64 per-channel sums accumulate there); the host carves them from one arena cleared per step.
+ * sums_ready != 0: the workspace already holds the sums of z (rv_conv_fwd's bn_sums) and the statistics pass is skipped. */
 long rv_bn_workspace_bytes(int C);
 int rv_bn_lrelu_fwd(const float* z, int z_ld, long P, int C, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, long* num_batches_tracked, float momentum, float eps, int training, float slope,
-                    const float* res, int res_ld, float* y, int y_ld, float* coef, void* workspace, void* stream);
+                    const float* res, int res_ld, float* y, int y_ld, float* coef, void* workspace, int sums_ready,
+                    void* stream);
 int rv_bn_running_update(float* running_mean, float* running_var, long* num_batches_tracked, const float* coef, int C,
                          float momentum, void* stream);
 int rv_bn_lrelu_bwd(const float* dy, int dy_ld, const float* z, int z_ld, long P, int C, const float* coef, float slope,

@@ -24,11 +24,11 @@ SIGNATURES = {
     'rv_melspec_lognorm_fwd': (I, [P, L, I, I, P, P, P, P, P, I, I, I, I, I, P, I, P, P]),
     'rv_packed_weight_floats': (L, [I, I, I]),
     'rv_pack_weights': (I, [P, P, I, I, I, L, L, I, I, I, P]),
-    'rv_conv_fwd': (I, [I, P, I, I, I, I, I, P, I, I, I, I, P, P, I, I, P]),
+    'rv_conv_fwd': (I, [I, P, I, I, I, I, I, P, I, I, I, I, P, P, I, I, P, P]),
     'rv_conv_wgrad_workspace_bytes': (L, [I, I, I, I, I]),
     'rv_conv_wgrad': (I, [I, P, I, I, I, I, P, I, I, I, I, I, P, L, L, I, P, I, P, L, P]),
     'rv_bn_workspace_bytes': (L, [I]),
-    'rv_bn_lrelu_fwd': (I, [P, I, L, I, P, P, P, P, P, F, F, I, F, P, I, P, I, P, P, P]),
+    'rv_bn_lrelu_fwd': (I, [P, I, L, I, P, P, P, P, P, F, F, I, F, P, I, P, I, P, P, I, P]),
     'rv_bn_running_update': (I, [P, P, P, P, I, F, P]),
     'rv_bn_lrelu_bwd': (I, [P, I, P, I, L, I, P, F, I, P, I, P, P, I, P, P]),
     'rv_gemm': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, I, I, I, I, I, I, P]),

@@ -214,6 +214,16 @@ static int bn_apply_blocks(long total) {
     return (int)b;
 }
 
+int rv_internal_bn_stats(const float* z, int z_ld, long P, int C, double* sums, hipStream_t st) {
+    RV_CHECK_ARG(C % 4 == 0 && C <= 128 && (z_ld % 4) == 0, "bn statistics: C=%d must be a multiple of 4 and <= 128", C);
+    BnArgs a = {};
+    a.z = z; a.z_ld = z_ld; a.P = P; a.C = C; a.sums = sums;
+    const int PL = 256 / (C / 4);
+    hipLaunchKernelGGL(bn_reduce_k<false>, dim3(cdiv(P, (long)PL * BN_PIX_PER_THREAD)), dim3(256), 0, st, a);
+    RV_LAUNCH_CHECK("bn statistics");
+    return RV_OK;
+}
+
 extern "C" {
 
 // Bytes of workspace the BN entry points need: 2*C fp64 sums.  CONTRACT: the workspace must be ALL-ZERO on entry (the
@@ -225,10 +235,12 @@ long rv_bn_workspace_bytes(int C) { return (long)(2 * C) * 8; }
 // training == 1: batch statistics, running stats / num_batches_tracked updated in place;
 // training == 2: batch statistics, running stats untouched (apply them later with rv_bn_running_update);
 // training == 0: running statistics (eval mode).
+// sums_ready != 0: the workspace already holds this tensor's sums (rv_conv_fwd(..., bn_sums = workspace) produced z).
 // y = leaky_relu(bn(z), slope) (+ res).  slope = 1 -> no activation.
 int rv_bn_lrelu_fwd(const float* z, int z_ld, long P, int C, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, long* num_batches_tracked, float momentum, float eps, int training, float slope,
-                    const float* res, int res_ld, float* y, int y_ld, float* coef, void* workspace, void* stream) {
+                    const float* res, int res_ld, float* y, int y_ld, float* coef, void* workspace, int sums_ready,
+                    void* stream) {
     hipStream_t st = (hipStream_t)stream;
     RV_CHECK_ARG(C % 4 == 0 && C <= 128, "rv_bn_lrelu_fwd: C=%d must be a multiple of 4 and <= 128", C);
     RV_CHECK_ARG((z_ld % 4) == 0 && (y_ld % 4) == 0 && (!res || (res_ld % 4) == 0), "rv_bn_lrelu_fwd: strides must be multiples of 4");
@@ -236,10 +248,9 @@ int rv_bn_lrelu_fwd(const float* z, int z_ld, long P, int C, const float* gamma,
     a.z = z; a.z_ld = z_ld; a.P = P; a.C = C; a.sums = (double*)workspace; a.slope = slope;
     a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var; a.nbt = num_batches_tracked;
     a.coef_out = coef; a.momentum = momentum; a.eps = eps; a.training = training;
-    if (training) {
-        const int PL = 256 / (C / 4);
-        hipLaunchKernelGGL(bn_reduce_k<false>, dim3(cdiv(P, (long)PL * BN_PIX_PER_THREAD)), dim3(256), 0, st, a);
-        RV_LAUNCH_CHECK("rv_bn_lrelu_fwd(stats)");
+    if (training && !sums_ready) {
+        const int rc = rv_internal_bn_stats(z, z_ld, P, C, a.sums, st);
+        if (rc != RV_OK) return rc;
     }
     a.out = y; a.out_ld = y_ld; a.res = res; a.res_ld = res_ld;
     hipLaunchKernelGGL(bn_apply_k<false>, dim3(bn_apply_blocks(P * (C / 4))), dim3(256), 0, st, a);

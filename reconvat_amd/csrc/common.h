@@ -78,3 +78,7 @@ static inline FastDiv fastdiv_make(unsigned d) {
 __device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv& f) {
     return (unsigned)(((unsigned long long)__umulhi(n, f.mul) + n) >> f.shift);
 }
+
+// bn.hip: sums[0..C) += sum_p z[p][c], sums[C..2C) += sum_p z[p][c]^2 (fp64) -- the BatchNorm2d batch statistics pass,
+// also used by rv_conv_fwd behind the conv kernels that do not produce the statistics in their epilogue.
+int rv_internal_bn_stats(const float* z, int z_ld, long P, int C, double* sums, hipStream_t st);

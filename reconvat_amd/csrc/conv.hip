@@ -91,6 +91,7 @@ struct ConvArgs {
     int vec_store;    // out pointer/ld allow 16-byte stores
     int accumulate;   // out += result
     FastDiv fd_pw, fd_plane, fd_w;   // divide by Pw, by Ph*Pw and by the input width W
+    double* bn_sums;  // optional [2*Cout] fp64: += per-channel sum / sum of squares of the values written to `out`
 };
 
 template <int R> struct VecR;
@@ -419,6 +420,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
     int lbase[MTW];
     bool pv[MTW];
     f32x4 bv[NT];
+    f32x4 st1[NT], st2[NT];                      // BatchNorm statistics of this thread's outputs (a.bn_sums)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) st1[n] = st2[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int cb = (nt0 + n) * 16 + 4 * g;
@@ -520,9 +524,49 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (co0 + r < a.Cout) o[r] = a.accumulate ? o[r] + v[r] : v[r];
+                        if (co0 + r < a.Cout) {
+                            if (a.accumulate) v[r] += o[r];
+                            o[r] = v[r];
+                        }
                 }
+                st1[n] += v;
+                st2[n] += v * v;
             }
+        }
+    }
+    // Fused BatchNorm statistics: the consumer's per-channel sum / sum of squares leave with the conv instead of
+    // costing another pass over the output.  16 pixel lanes -> one lane (xor shuffles), waves -> LDS, then ONE fp64
+    // atomic per channel and workgroup (a persistent grid: a few hundred atomics per address at most).
+    if (a.bn_sums) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float u = st1[n][r], q = st2[n][r];
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) {
+                    u += __shfl_xor(u, d, 64);
+                    q += __shfl_xor(q, d, 64);
+                }
+                st1[n][r] = u; st2[n][r] = q;
+            }
+        __syncthreads();                                   // every wave is done with the unit buffers
+        float* red = smem;                                 // [NW][NT*16][2]
+        if (j == 0) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    red[((wave * NT + n) * 16 + 4 * g + r) * 2] = st1[n][r];
+                    red[((wave * NT + n) * 16 + 4 * g + r) * 2 + 1] = st2[n][r];
+                }
+        }
+        __syncthreads();
+        for (int t = tid; t < NT * 16 * 2; t += NTHR) {
+            const int cl = t >> 1, which = t & 1, ch = nt0 * 16 + cl;
+            double dsum = 0.0;
+            for (int w = 0; w < NW; ++w) dsum += (double)red[((w * NT) * 16 + cl) * 2 + which];
+            if (ch < a.Cout) atomicAdd(&a.bn_sums[which * a.Cout + ch], dsum);
         }
     }
 }
@@ -1134,9 +1178,28 @@ int rv_pack_weights(const float* w, float* out, int taps, int kdim, int ndim, lo
 // algo: 0 = default, 1 = direct (LDS-free) kernel, 2 = LDS/DMA-pipelined kernel (mode 0 only)
 // in  : [B,H,W,*] pixel stride in_ld, Cin channels read from the pointer
 // out : [B,Ho,Wo,*] pixel stride out_ld, Cout channels written
+// bn_sums != NULL: on return (stream order) bn_sums[0..Cout) += per-channel sum and bn_sums[Cout..2Cout) += sum of
+// squares of the values written to `out` -- the BatchNorm2d batch statistics of the consumer (rv_bn_lrelu_fwd with
+// sums_ready = 1).  The persistent 3x3 kernel produces them in its epilogue; every other kernel is followed by the
+// BatchNorm statistics pass.
+static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int W, int Cin, float* out, int out_ld, int Ho,
+                         int Wo, int Cout, const float* wpack, const float* bias, int accumulate, int algo, double* bn_sums,
+                         bool* sums_done, hipStream_t st);
+
 int rv_conv_fwd(int mode, const float* in, int in_ld, int B, int H, int W, int Cin, float* out, int out_ld, int Ho,
-                int Wo, int Cout, const float* wpack, const float* bias, int accumulate, int algo, void* stream) {
+                int Wo, int Cout, const float* wpack, const float* bias, int accumulate, int algo, double* bn_sums,
+                void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    bool sums_done = false;
+    const int rc = conv_fwd_impl(mode, in, in_ld, B, H, W, Cin, out, out_ld, Ho, Wo, Cout, wpack, bias, accumulate, algo,
+                                 bn_sums, &sums_done, st);
+    if (rc != RV_OK || !bn_sums || sums_done) return rc;
+    return rv_internal_bn_stats(out, out_ld, (long)B * Ho * Wo, Cout, bn_sums, st);
+}
+
+static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int W, int Cin, float* out, int out_ld, int Ho,
+                         int Wo, int Cout, const float* wpack, const float* bias, int accumulate, int algo, double* bn_sums,
+                         bool* sums_done, hipStream_t st) {
     RV_CHECK_ARG(mode >= 0 && mode <= 3, "rv_conv_fwd: bad mode %d", mode);
     if (mode == 0 || mode == 1) RV_CHECK_ARG(Ho == H && Wo == W, "rv_conv_fwd: same-size conv needs Ho==H, Wo==W");
     if (mode == 2) RV_CHECK_ARG(Ho == H / 2 && Wo == W / 2, "rv_conv_fwd: down conv needs Ho=H/2, Wo=W/2");
@@ -1172,7 +1235,7 @@ int rv_conv_fwd(int mode, const float* in, int in_ld, int B, int H, int W, int C
     }
     ConvArgs a;
     a.in = in; a.in_ld = in_ld; a.H = H; a.W = W; a.out = out; a.out_ld = out_ld; a.Ho = Ho; a.Wo = Wo;
-    a.B = B; a.Cin = Cin; a.Cout = Cout; a.wpack = wpack; a.bias = bias;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.wpack = wpack; a.bias = bias; a.bn_sums = bn_sums;
     a.nchunk = Cin / (4 * R);
     a.accumulate = accumulate;
     a.vec_store = ((out_ld & 3) == 0) && ((((uintptr_t)out) & 15) == 0);
@@ -1195,7 +1258,7 @@ int rv_conv_fwd(int mode, const float* in, int in_ld, int B, int H, int W, int C
     const int fam = algo >> 8, f_nt = (algo >> 4) & 15, f_mt = algo & 15;
     if (mode == 0 && algo != 1 && fam != 1) {
         int rc3 = (fam >= 2 && fam <= 4) ? launch_conv3x3_lds(a, R, st, f_nt, f_mt, fam == 4 ? 16 : (fam == 3 ? 8 : 4)) : launch_conv3x3_lds(a, R, st);
-        if (rc3 == RV_OK) { RV_LAUNCH_CHECK("rv_conv_fwd(lds)"); return RV_OK; }
+        if (rc3 == RV_OK) { RV_LAUNCH_CHECK("rv_conv_fwd(lds)"); *sums_done = true; return RV_OK; }
         if (fam >= 2 && fam <= 4) { rv_set_error("rv_conv_fwd: forced LDS tile NT=%d MTW=%d does not fit", f_nt, f_mt); return RV_EUNSUPPORTED; }
     }
     int NT, MT;

@@ -20,8 +20,8 @@ import torch.nn.init as init
 from . import ops
 from .constants import N_BINS
 from .frontend import MelSpectrogram, Normalization
-from .ops import (ConvFn, UpCatFn, BnActFn, LinearFn, OnsetHeadsFn, LocalAttnFn, VatPerturbFn, SLOPE, bce_mean, mse_mean,
-                  abs_mean)
+from .ops import (ARENA, ConvFn, UpCatFn, BnActFn, LinearFn, OnsetHeadsFn, LocalAttnFn, VatPerturbFn, SLOPE, bce_mean,
+                  mse_mean, abs_mean)
 
 batchNorm_momentum = 0.1
 
@@ -30,13 +30,17 @@ def _p(t, detach):
     return t.detach() if (detach and t is not None) else t
 
 
-def _bn(m, z, res, detach):
-    return BnActFn.apply(z, _p(m.weight, detach), _p(m.bias, detach), m.running_mean, m.running_var,
-                         m.num_batches_tracked, res, m.training, SLOPE)
-
-
 def _conv(m, x, kind, detach, size=None):
     return ConvFn.apply(x, _p(m.weight, detach), _p(m.bias, detach), kind, size)
+
+
+def _conv_bn(conv, bn, x, kind, res, detach):
+    """lrelu(bn(conv(x))) (+ res).  In training mode the conv leaves the batch statistics of its output in a
+    zeroed fp64 slice (fused epilogue) and the BatchNorm skips its own statistics pass."""
+    stats = ARENA.take(2 * bn.num_features, x.device) if bn.training else None
+    z = ConvFn.apply(x, _p(conv.weight, detach), _p(conv.bias, detach), kind, None, stats)
+    return BnActFn.apply(z, _p(bn.weight, detach), _p(bn.bias, detach), bn.running_mean, bn.running_var,
+                         bn.num_batches_tracked, res, bn.training, SLOPE, stats)
 
 
 class block(nn.Module):
@@ -52,9 +56,9 @@ class block(nn.Module):
         self.ds = nn.Conv2d(out, out, kernel_size=ds_ksize, stride=ds_stride, padding=0)
 
     def forward(self, x, detach=False):
-        a1 = _bn(self.bn1, _conv(self.conv1, x, 'c3', detach), None, detach)
+        a1 = _conv_bn(self.conv1, self.bn1, x, 'c3', None, detach)
         sk = _conv(self.skip, x, 'c1', detach)
-        a2 = _bn(self.bn2, _conv(self.conv2, a1, 'c3', detach), sk, detach)     # lrelu(bn2(.)) + skip(x)
+        a2 = _conv_bn(self.conv2, self.bn2, a1, 'c3', sk, detach)               # lrelu(bn2(.)) + skip(x)
         xp = _conv(self.ds, a2, 'down', detach)
         return xp, (a2.shape[1], a2.shape[2])
 
@@ -80,11 +84,10 @@ class d_block(nn.Module):
         else:
             x = UpCatFn.apply(x, _p(self.us.weight, detach), _p(self.us.bias, detach), skip_src,
                               _p(skip_conv.weight, detach), _p(skip_conv.bias, detach), size)
-        x = _bn(self.bn2d, _conv(self.conv2d, x, 't3', detach), None, detach)
-        x = _conv(self.conv1d, x, 't3', detach)
-        if not self.isLast:
-            x = _bn(self.bn1d, x, None, detach)
-        return x
+        x = _conv_bn(self.conv2d, self.bn2d, x, 't3', None, detach)
+        if self.isLast:
+            return _conv(self.conv1d, x, 't3', detach)
+        return _conv_bn(self.conv1d, self.bn1d, x, 't3', None, detach)
 
 
 class Encoder(nn.Module):

@@ -183,16 +183,18 @@ _algo_cache = {}
 AUTOTUNE = True
 
 
-def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias):
+def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias, stats=None):
     """rv_conv_fwd with a per-shape choice between the LDS-free and the LDS/DMA-pipelined 3x3 kernel.  The first
     eager call of a shape times both (HIP events on the launch stream) and caches the winner; under hipGraph
-    capture an untuned shape uses the library default."""
+    capture an untuned shape uses the library default.  ``stats`` (fp64 [2*cout], zeroed): the conv also leaves the
+    BatchNorm batch statistics of its output there (fused epilogue of the persistent kernel, else a statistics pass
+    -- the tuner times whichever the candidate implies)."""
     args = (mode, ptr(x), ild, bb, h, wd, cin, ptr(out), old, ho, wo, cout, ptr(wpack), ptr(bias), 0)
     algo = 0
     if mode == 0 and os.environ.get('RV_FORCE_ALGO'):      # kernel experiments (tools/bench_conv.py)
         algo = int(os.environ['RV_FORCE_ALGO'], 0)
     elif mode == 0 and AUTOTUNE:
-        key = (bb, h, wd, cin, cout, ild, old)
+        key = (bb, h, wd, cin, cout, ild, old, stats is not None)
         algo = _algo_cache.get(key, -1)
         if algo < 0:
             if torch.cuda.is_current_stream_capturing():
@@ -202,6 +204,7 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
                 st = torch.cuda.current_stream()
                 lib = _lib.load()
                 ntile_n = (cout + 15) // 16
+                scratch = ptr(torch.zeros_like(stats)) if stats is not None else None
                 cands = [1, 2]
                 for nt in (1, 2, 3, 4):
                     if ntile_n % nt:
@@ -211,27 +214,27 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
                     cands += [0x300 | nt << 4 | mt for mt in (1, 2, 4)]
                     cands += [0x400 | nt << 4 | mt for mt in (1, 2, 4)]
                 for cand in cands:
-                    if lib.rv_conv_fwd(*args, cand, st.cuda_stream) != 0:
+                    if lib.rv_conv_fwd(*args, cand, scratch, st.cuda_stream) != 0:
                         continue                                   # tile does not fit this shape
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(st)
                     for _ in range(3):
-                        lib.rv_conv_fwd(*args, cand, st.cuda_stream)
+                        lib.rv_conv_fwd(*args, cand, scratch, st.cuda_stream)
                     e1.record(st)
                     e1.synchronize()
                     t = e0.elapsed_time(e1)
                     if best is None or t < best:
                         best, algo = t, cand
                 _algo_cache[key] = algo
-    call('rv_conv_fwd', *args, algo, stream())
+    call('rv_conv_fwd', *args, algo, ptr(stats), stream())
 
 
-def conv_forward_into(kind, x, w, b, out):
-    """out (NHWC view) = conv(x) ; shapes are taken from the views."""
+def conv_forward_into(kind, x, w, b, out, stats=None):
+    """out (NHWC view) = conv(x) ; shapes are taken from the views.  stats: see _conv_call."""
     need_gpu(x, w, out)
     bb, h, wd, cin, ild = _geom(x)
     _, ho, wo, cout, old = _geom(out)
-    _conv_call(_FWD_MODE[kind], x, ild, bb, h, wd, cin, out, old, ho, wo, cout, _pack(kind, w, 'fwd'), b)
+    _conv_call(_FWD_MODE[kind], x, ild, bb, h, wd, cin, out, old, ho, wo, cout, _pack(kind, w, 'fwd'), b, stats)
 
 
 def conv_dgrad_into(kind, dy, w, dx):
@@ -290,12 +293,12 @@ class ConvFn(Function):
     """y = conv(x) for any of the five conv kinds (new contiguous NHWC tensor)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, kind, size):
+    def forward(ctx, x, w, b, kind, size, stats=None):
         bb, h, wd, cin, _ = _geom(x)
         _, cout = _channels(kind, w)
         ho, wo = _out_hw(kind, h, wd, size)
         y = _new(bb, ho, wo, cout, x)
-        conv_forward_into(kind, x, w, b, y)
+        conv_forward_into(kind, x, w, b, y, stats)
         ctx.kind = kind
         ctx.xshape = tuple(x.shape)
         ctx.save_for_backward(x if ctx.needs_input_grad[1] else None, w)
@@ -317,7 +320,7 @@ class ConvFn(Function):
                 conv_wgrad(ctx.kind, x, dy, w, ctx.needs_input_grad[2], gw, gb)
             else:
                 dw, db = conv_wgrad(ctx.kind, x, dy, w, ctx.needs_input_grad[2])
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class UpCatFn(Function):
@@ -378,7 +381,7 @@ class BnActFn(Function):
     num_batches_tracked in place exactly like nn.BatchNorm2d(momentum=0.1)."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, running_mean, running_var, nbt, res, training, slope):
+    def forward(ctx, z, gamma, beta, running_mean, running_var, nbt, res, training, slope, stats=None):
         need_gpu(z, gamma)
         bb, h, wd, c, zld = _geom(z)
         p = bb * h * wd
@@ -389,10 +392,13 @@ class BnActFn(Function):
             mode = 2
             _BN_DEFER[0].append((running_mean, running_var, nbt, coef, c))
         # zero-initialised fp64 sums: one slice for the forward statistics, one for the backward reduction
-        ws = (ARENA.take(2 * c, z.device), ARENA.take(2 * c, z.device) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None)
+        # (``stats``: the producing conv already left the forward sums in its slice -- bn_stats_slot / ConvFn)
+        ready = training and stats is not None
+        ws = (stats if ready else ARENA.take(2 * c, z.device),
+              ARENA.take(2 * c, z.device) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None)
         rld = _geom(res)[4] if res is not None else 0
         call('rv_bn_lrelu_fwd', ptr(z), zld, p, c, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(nbt),
-             BN_MOMENTUM, BN_EPS, mode, slope, ptr(res), rld, ptr(y), c, ptr(coef), ptr(ws[0]), stream())
+             BN_MOMENTUM, BN_EPS, mode, slope, ptr(res), rld, ptr(y), c, ptr(coef), ptr(ws[0]), 1 if ready else 0, stream())
         ctx.ws = ws
         ctx.training = training
         ctx.slope = slope
@@ -422,7 +428,7 @@ class BnActFn(Function):
         if direct:
             dg = db = None
         dres = dy if ctx.needs_input_grad[6] else None
-        return (dz if ctx.needs_input_grad[0] else None), dg, db, None, None, None, dres, None, None
+        return (dz if ctx.needs_input_grad[0] else None), dg, db, None, None, None, dres, None, None, None
 
 
 # --------------------------------------------------------------------------------------------

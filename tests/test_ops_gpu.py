@@ -147,6 +147,33 @@ def test_bn_lrelu(dev, C, training, with_res):
     assert int(nbt.item()) == (1 if training else 0)
 
 
+@pytest.mark.parametrize('cin,cout,H,W,algo', [(16, 16, 21, 37, 0), (32, 24, 9, 57, 0x221), (64, 128, 12, 28, 0x321), (16, 8, 10, 19, 0),
+                                               (32, 32, 8, 30, 1), (1, 16, 9, 31, 0), (48, 24, 7, 114, 0x412)])
+def test_conv_fused_bn_statistics(dev, cin, cout, H, W, algo, monkeypatch):
+    """rv_conv_fwd(bn_sums=...) leaves sum / sum-of-squares of its output (fused epilogue of the persistent kernel,
+    statistics pass behind the others), and BatchNorm on those sums equals BatchNorm computing its own."""
+    from reconvat_amd import ops
+    B = 3
+    x = nhwc(rnd(B, cin, H, W, seed=1)).to(dev)
+    w, b = rnd(cout, cin, 3, 3, seed=2, scale=0.2).to(dev), rnd(cout, seed=3).to(dev)
+    if algo:
+        monkeypatch.setenv('RV_FORCE_ALGO', hex(algo))
+    stats = torch.zeros(2 * cout, dtype=torch.float64, device=dev)
+    z = ops.ConvFn.apply(x, w, b, 'c3', None, stats)
+    z0 = ops.ConvFn.apply(x, w, b, 'c3', None)
+    assert torch.equal(z, z0)
+    zd = z.double().reshape(-1, cout)
+    want = torch.cat([zd.sum(0), (zd * zd).sum(0)])
+    assert rel_err(stats, want) < 1e-6
+    gamma, beta = (rnd(cout, seed=4) * 0.2 + 1).to(dev), (rnd(cout, seed=5) * 0.1).to(dev)
+    outs = []
+    for st in (stats, None):
+        rm, rv, nbt = torch.zeros(cout, device=dev), torch.ones(cout, device=dev), torch.zeros((), dtype=torch.long, device=dev)
+        outs.append((ops.BnActFn.apply(z, gamma, beta, rm, rv, nbt, None, True, 0.01, st), rm, rv))
+    assert rel_err(outs[0][0], outs[1][0]) < 1e-5
+    assert rel_err(outs[0][1], outs[1][1]) < 1e-5 and rel_err(outs[0][2], outs[1][2]) < 1e-5
+
+
 @pytest.mark.parametrize('M,K,N,act', [(130, 229, 88, 1), (257, 176, 768, 0), (64, 768, 88, 1), (200, 916, 229, 1), (96, 88, 916, 0)])
 def test_linear(dev, M, K, N, act):
     from reconvat_amd import ops
