@@ -175,14 +175,15 @@ __global__ void zero_strided_k(float* c, long scm, long scn, int M, int N) {
 extern "C" {
 
 // C[m*scm + n*scn] (+)= act(sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] + bias[n]);  act: 0 none, 1 sigmoid.
-// splitk > 1 splits the reduction over extra workgroups (atomic fp32 accumulation into a zeroed C; act must be 0,
-// accumulate must be 0, C2 must be null).  C2 (nullable) receives a second copy with its own strides.
+// splitk > 1 splits the reduction over extra workgroups (atomic fp32 accumulation; act must be 0, C2 must be null):
+// with accumulate == 0 C is zeroed first, with accumulate != 0 the atomics add straight into C's contents (gradient
+// accumulation).  C2 (nullable) receives a second copy with its own strides.
 int rv_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm, long scn, float* C2,
             long sc2m, long sc2n, const float* bias, int M, int N, int K, int act, int accumulate, int splitk, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     RV_CHECK_ARG(M > 0 && N > 0 && K > 0, "rv_gemm: empty problem");
     RV_CHECK_ARG(splitk >= 1, "rv_gemm: splitk must be >= 1");
-    if (splitk > 1) RV_CHECK_ARG(act == 0 && !accumulate && !C2, "rv_gemm: splitk excludes act/accumulate/C2");
+    if (splitk > 1) RV_CHECK_ARG(act == 0 && !C2, "rv_gemm: splitk excludes act/C2");
     GemmArgs a;
     a.A = A; a.sam = sam; a.sak = sak; a.B = B; a.sbk = sbk; a.sbn = sbn; a.C = C; a.scm = scm; a.scn = scn;
     a.C2 = C2; a.sc2m = sc2m; a.sc2n = sc2n; a.bias = bias; a.M = M; a.N = N; a.K = K; a.act = act;
@@ -192,7 +193,7 @@ int rv_gemm(const float* A, long sam, long sak, const float* B, long sbk, long s
     // aligned base; K-split offsets are multiples of GBK so they preserve alignment
     a.a_vec = ((a_kfast ? sak : sam) == 1) && (((a_kfast ? sam : sak) & 3) == 0) && ((((uintptr_t)A) & 15) == 0);
     a.b_vec = ((b_kfast ? sbk : sbn) == 1) && (((b_kfast ? sbn : sbk) & 3) == 0) && ((((uintptr_t)B) & 15) == 0);
-    if (splitk > 1) {
+    if (splitk > 1 && !accumulate) {
         hipLaunchKernelGGL(zero_strided_k, dim3(cdiv((long)M * N, 256)), dim3(256), 0, st, C, scm, scn, M, N);
         RV_LAUNCH_CHECK("rv_gemm(zero)");
     }

@@ -455,11 +455,32 @@ def gemm(a, b_kn, c, bias=None, act=0, accumulate=False, splitk=1, c2=None):
          1 if accumulate else 0, splitk, stream())
 
 
-def colsum(x2d):
-    out = torch.empty(x2d.shape[1], device=x2d.device, dtype=torch.float32)
+def colsum(x2d, out=None, accumulate=False):
+    if out is None:
+        out = torch.empty(x2d.shape[1], device=x2d.device, dtype=torch.float32)
     assert x2d.stride(1) == 1
-    call('rv_colsum', ptr(x2d), x2d.stride(0), x2d.shape[0], x2d.shape[1], ptr(out), 0, stream())
+    call('rv_colsum', ptr(x2d), x2d.stride(0), x2d.shape[0], x2d.shape[1], ptr(out), 1 if accumulate else 0, stream())
     return out
+
+
+def _param_wgrad(a_t, b, param, splitk):
+    """d(param) = a_t @ b.  Under direct_param_grads() the product is accumulated straight into param.grad (split-K
+    atomics add onto it: no zero fill, no temporary, no autograd add) and None is returned."""
+    g = _grad_buf(param)
+    if g is not None:
+        gemm(a_t, b, g.view(a_t.shape[0], b.shape[1]), accumulate=True, splitk=splitk)
+        return None
+    dw = torch.empty((a_t.shape[0], b.shape[1]), device=b.device, dtype=torch.float32)
+    gemm(a_t, b, dw, splitk=splitk)
+    return dw.view_as(param)
+
+
+def _param_bgrad(dz2d, param):
+    g = _grad_buf(param)
+    if g is not None:
+        colsum(dz2d, g, accumulate=True)
+        return None
+    return colsum(dz2d)
 
 
 def _splitk_for(m_out, n_out, k):
@@ -479,6 +500,7 @@ class LinearFn(Function):
         y = torch.empty((m, n), device=x.device, dtype=torch.float32)
         gemm(x, w.t(), y, b, act)
         ctx.act = act
+        ctx.params = (w, b)
         ctx.save_for_backward(x, w, y if act == 1 else None)
         return y
 
@@ -498,10 +520,9 @@ class LinearFn(Function):
             dx = torch.empty((m, k), device=dy.device, dtype=torch.float32)
             gemm(dz, w, dx)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
-            gemm(dz.t(), x, dw, splitk=_splitk_for(n, k, m))
+            dw = _param_wgrad(dz.t(), x, ctx.params[0], _splitk_for(n, k, m))
         if ctx.needs_input_grad[2]:
-            db = colsum(dz)
+            db = _param_bgrad(dz, ctx.params[1])
         return dx, dw, db, None
 
 
@@ -520,6 +541,7 @@ class OnsetHeadsFn(Function):
         onset = torch.empty((m, 88), device=y.device, dtype=torch.float32)
         gemm(y2[..., 0], wo.t(), cat[:, :88], bo, act=1, c2=onset)
         gemm(y2[..., 1], wf.t(), cat[:, 88:], bf, act=0)
+        ctx.params = (wo, bo, wf, bf)
         ctx.save_for_backward(y, wo, wf, onset)
         return cat, onset
 
@@ -540,15 +562,13 @@ class OnsetHeadsFn(Function):
             d2 = dy.view(m, nb, 2)
             gemm(dzo, wo, d2[..., 0])
             gemm(dzf, wf, d2[..., 1])
+        pwo, pbo, pwf, pbf = ctx.params
         if ctx.needs_input_grad[1]:
-            dwo = torch.empty_like(wo)
-            gemm(dzo.t(), y2[..., 0], dwo, splitk=_splitk_for(88, nb, m))
-            dbo = colsum(dzo)
+            dwo = _param_wgrad(dzo.t(), y2[..., 0], pwo, _splitk_for(88, nb, m))
+            dbo = _param_bgrad(dzo, pbo)
         if ctx.needs_input_grad[3]:
-            dwf = torch.empty_like(wf)
-            gemm(dzf.t(), y2[..., 1], dwf, splitk=_splitk_for(88, nb, m))
-            dbf = torch.empty(88, device=y.device, dtype=torch.float32)
-            call('rv_colsum', ptr(dzf), 176, m, 88, ptr(dbf), 0, stream())
+            dwf = _param_wgrad(dzf.t(), y2[..., 1], pwf, _splitk_for(88, nb, m))
+            dbf = _param_bgrad(dzf, pbf)
         return dy, dwo, dbo, dwf, dbf
 
 
@@ -577,6 +597,7 @@ class LocalAttnFn(Function):
         call('rv_local_attn_fwd', ptr(q), ptr(k), ptr(v), ptr(relc), ptr(out), ptr(att), bb, l, groups, f // groups,
              stream())
         ctx.groups = groups
+        ctx.params = (wq, wk, wv, rel)
         ctx.save_for_backward(x2, wq, wk, wv, rel, q, k, v, att)
         ctx.mark_non_differentiable(att)
         return out, att
@@ -604,19 +625,21 @@ class LocalAttnFn(Function):
             gemm(dk, wk, dx, accumulate=True)
             gemm(dv, wv, dx, accumulate=True)
             dx = dx.view(bb, l, -1)
+        pwq, pwk, pwv, prel = ctx.params
         if ctx.needs_input_grad[1]:
             sk = _splitk_for(f, x2.shape[1], m)
-            dwq, dwk, dwv = torch.empty_like(wq), torch.empty_like(wk), torch.empty_like(wv)
-            gemm(dq.t(), x2, dwq, splitk=sk)
-            gemm(dk.t(), x2, dwk, splitk=sk)
-            gemm(dv.t(), x2, dwv, splitk=sk)
+            dwq = _param_wgrad(dq.t(), x2, pwq, sk)
+            dwk = _param_wgrad(dk.t(), x2, pwk, sk)
+            dwv = _param_wgrad(dv.t(), x2, pwv, sk)
         if ctx.needs_input_grad[4]:
             # drel[g*dh+f, w] = sum_{b,t} q[b,t,g,f] * de[b,t,g,w]
-            drel = torch.empty((f, 31), device=q.device, dtype=torch.float32)
+            grel = _grad_buf(prel)
+            direct = grel is not None
+            drel = grel.view(f, 31) if direct else torch.empty((f, 31), device=q.device, dtype=torch.float32)
             de2 = de.view(m, g, 31)
             for h in range(g):
-                gemm(q[:, h * dh:(h + 1) * dh].t(), de2[:, h, :], drel[h * dh:(h + 1) * dh], splitk=16)
-            drel = drel.view_as(rel)
+                gemm(q[:, h * dh:(h + 1) * dh].t(), de2[:, h, :], drel[h * dh:(h + 1) * dh], accumulate=direct, splitk=16)
+            drel = None if direct else drel.view_as(rel)
         return dx, dwq, dwk, dwv, drel, None
 
 
