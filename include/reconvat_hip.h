@@ -50,6 +50,12 @@ int rv_melspec_lognorm_fwd(const float* audio, long audio_stride, int B, int nsa
 long rv_packed_weight_floats(int taps, int kdim, int ndim);
 int rv_pack_weights(const float* w, float* out, int taps, int kdim, int ndim, long s_k, long s_n, int flip,
                     int scatter_cmid, int force_plain, void* stream);
+/* batched packing (all weights of the model, one launch per optimiser step): fill a HOST table entry by entry
+ * (i = 0, 1, ... in order; returns the running workgroup total, <0 on error), copy it to the device, run it. */
+long rv_pack_table_entry_bytes(void);
+long rv_pack_table_fill(void* table_host, int i, const float* w, float* out, int taps, int kdim, int ndim, long s_k, long s_n,
+                        int flip, int scatter_cmid, int force_plain);
+int rv_pack_table_run(const void* table_dev, int count, long total_blocks, void* stream);
 int rv_conv_fwd(int mode, const float* in, int in_ld, int B, int H, int W, int Cin, float* out, int out_ld, int Ho,
                 int Wo, int Cout, const float* wpack, const float* bias, int accumulate, int algo, double* bn_sums,
                 void* stream);

@@ -24,6 +24,9 @@ SIGNATURES = {
     'rv_melspec_lognorm_fwd': (I, [P, L, I, I, P, P, P, P, P, I, I, I, I, I, P, I, P, P]),
     'rv_packed_weight_floats': (L, [I, I, I]),
     'rv_pack_weights': (I, [P, P, I, I, I, L, L, I, I, I, P]),
+    'rv_pack_table_entry_bytes': (L, []),
+    'rv_pack_table_fill': (L, [P, I, P, P, I, I, I, L, L, I, I, I]),
+    'rv_pack_table_run': (I, [P, I, L, P]),
     'rv_conv_fwd': (I, [I, P, I, I, I, I, I, P, I, I, I, I, P, P, I, I, P, P]),
     'rv_conv_wgrad_workspace_bytes': (L, [I, I, I, I, I]),
     'rv_conv_wgrad': (I, [I, P, I, I, I, I, P, I, I, I, I, I, P, L, L, I, P, I, P, L, P]),

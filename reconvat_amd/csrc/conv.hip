@@ -40,9 +40,7 @@ struct PackArgs {
     long total;
 };
 
-__global__ void pack_frag_k(PackArgs a) {
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.total) return;
+__device__ __forceinline__ void pack_frag_elem(const PackArgs& a, long idx) {
     const int R = a.R;
     int r = (int)(idx % R);
     long t = idx / R;
@@ -65,16 +63,48 @@ __global__ void pack_frag_k(PackArgs a) {
     a.out[idx] = v;
 }
 
-// plain [tap][k][n] copy for the small-channel VALU kernels
-__global__ void pack_plain_k(PackArgs a) {
+__global__ void pack_frag_k(PackArgs a) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.total) return;
+    if (idx < a.total) pack_frag_elem(a, idx);
+}
+
+// plain [tap][k][n] copy for the small-channel VALU kernels
+__device__ __forceinline__ void pack_plain_elem(const PackArgs& a, long idx) {
     int n = (int)(idx % a.ndim);
     long t = idx / a.ndim;
     int k = (int)(t % a.kdim);
     int tap = (int)(t / a.kdim);
     int tt = a.flip ? (a.taps - 1 - tap) : tap;
     a.out[idx] = a.w[(long)k * a.s_k + (long)n * a.s_n + tt];
+}
+
+__global__ void pack_plain_k(PackArgs a) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < a.total) pack_plain_elem(a, idx);
+}
+
+// Every weight of the model in ONE launch (the weights change once per optimiser step, and ~100 separate 5 us pack
+// launches per step cost more than the packing itself).  tab[e].block0 = first workgroup of entry e (prefix sum);
+// a workgroup finds its entry by bisection.
+struct PackEntry {
+    PackArgs a;
+    long block0;
+};
+__global__ __launch_bounds__(256) void pack_table_k(const PackEntry* tab, int count) {
+    __shared__ PackEntry ent;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = count - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tab[mid].block0 <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        ent = tab[lo];
+    }
+    __syncthreads();
+    const long idx = ((long)blockIdx.x - ent.block0) * 256 + threadIdx.x;
+    if (idx >= ent.a.total) return;
+    if (ent.a.R == 0) pack_plain_elem(ent.a, idx);
+    else pack_frag_elem(ent.a, idx);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1153,24 +1183,54 @@ long rv_packed_weight_floats(int taps, int kdim, int ndim) {
 // the small-channel VALU kernels: kdim not a multiple of 8, or ndim <= 2).
 //   value(tap,k,n) = w[k*s_k + n*s_n + (flip ? taps-1-tap : tap)]
 //   scatter_cmid>0 (2x2/s2 scatter GEMM): n = tap4*cmid + c, value = w[k*s_k + c*s_n + tap4], taps must be 1.
-int rv_pack_weights(const float* w, float* out, int taps, int kdim, int ndim, long s_k, long s_n, int flip,
-                    int scatter_cmid, int force_plain, void* stream) {
-    PackArgs a;
+static int pack_args_make(PackArgs& a, const float* w, float* out, int taps, int kdim, int ndim, long s_k, long s_n,
+                          int flip, int scatter_cmid, int force_plain) {
     a.w = w; a.out = out; a.taps = taps; a.kdim = kdim; a.ndim = ndim;
     a.s_k = s_k; a.s_n = s_n; a.flip = flip; a.scatter_cmid = scatter_cmid;
-    int R = force_plain ? 0 : frag_R(kdim);
-    hipStream_t st = (hipStream_t)stream;
+    const int R = force_plain ? 0 : frag_R(kdim);
     if (R == 0) {
         RV_CHECK_ARG(scatter_cmid == 0, "rv_pack_weights: plain layout has no scatter form");
         a.R = 0; a.ntile_n = 0; a.nchunk = 0;
         a.total = (long)taps * kdim * ndim;
-        hipLaunchKernelGGL(pack_plain_k, dim3(cdiv(a.total, 256)), dim3(256), 0, st, a);
     } else {
         a.R = R; a.nchunk = kdim / (4 * R); a.ntile_n = (ndim + 15) / 16;
         a.total = (long)taps * a.nchunk * a.ntile_n * 64 * R;
-        hipLaunchKernelGGL(pack_frag_k, dim3(cdiv(a.total, 256)), dim3(256), 0, st, a);
     }
+    return RV_OK;
+}
+
+int rv_pack_weights(const float* w, float* out, int taps, int kdim, int ndim, long s_k, long s_n, int flip,
+                    int scatter_cmid, int force_plain, void* stream) {
+    PackArgs a;
+    const int rc = pack_args_make(a, w, out, taps, kdim, ndim, s_k, s_n, flip, scatter_cmid, force_plain);
+    if (rc != RV_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (a.R == 0) hipLaunchKernelGGL(pack_plain_k, dim3(cdiv(a.total, 256)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(pack_frag_k, dim3(cdiv(a.total, 256)), dim3(256), 0, st, a);
     RV_LAUNCH_CHECK("rv_pack_weights");
+    return RV_OK;
+}
+
+// Batched form: the caller builds a table of rv_pack_table_entry_bytes()-sized entries IN HOST MEMORY with
+// rv_pack_table_fill (entry i of `table`, same arguments as rv_pack_weights; entries must be filled in order
+// 0, 1, 2, ... because each records the running workgroup offset), copies it to the device once, and then repacks
+// every weight with one rv_pack_table_run launch per optimiser step.  rv_pack_table_fill returns the total number
+// of workgroups up to and including entry i (pass the last value as total_blocks).
+long rv_pack_table_entry_bytes(void) { return (long)sizeof(PackEntry); }
+
+long rv_pack_table_fill(void* table, int i, const float* w, float* out, int taps, int kdim, int ndim, long s_k, long s_n,
+                        int flip, int scatter_cmid, int force_plain) {
+    PackEntry* tab = (PackEntry*)table;
+    if (pack_args_make(tab[i].a, w, out, taps, kdim, ndim, s_k, s_n, flip, scatter_cmid, force_plain) != RV_OK) return -1;
+    tab[i].block0 = i == 0 ? 0 : tab[i - 1].block0 + cdiv(tab[i - 1].a.total, 256);
+    return tab[i].block0 + cdiv(tab[i].a.total, 256);
+}
+
+int rv_pack_table_run(const void* table_dev, int count, long total_blocks, void* stream) {
+    RV_CHECK_ARG(count > 0 && total_blocks > 0 && total_blocks < (1L << 31), "rv_pack_table_run: empty or oversized table");
+    hipLaunchKernelGGL(pack_table_k, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const PackEntry*)table_dev, count);
+    RV_LAUNCH_CHECK("rv_pack_table_run");
     return RV_OK;
 }
 

@@ -171,8 +171,39 @@ def _pack(kind, w, which):
     n = lib.rv_packed_weight_floats(taps, kdim, ndim)
     out = torch.empty(n, device=w.device, dtype=torch.float32)
     call('rv_pack_weights', ptr(w), ptr(out), taps, kdim, ndim, s_k, s_n, flip, scatter, plain, stream())
-    _pack_cache[key] = (tag, out)
+    _pack_cache[key] = (tag, out, w, (taps, kdim, ndim, s_k, s_n, flip, scatter, plain))
     return out
+
+
+class PackPlan:
+    """Every packed weight currently in the cache, repacked by ONE kernel launch (rv_pack_table_run).  Build it after
+    a warm-up step has populated the cache, call ``run()`` right after each optimiser step: the cache entries are
+    re-tagged as fresh, so the ~100 lazy per-layer pack launches of the next step disappear.  Entries created later
+    stay on the lazy path."""
+
+    def __init__(self, device):
+        import ctypes
+        lib = _lib.load()
+        self.entries = [(k, v) for k, v in _pack_cache.items() if v[2].device == device]
+        self.count = len(self.entries)
+        if not self.count:
+            return
+        nbytes = lib.rv_pack_table_entry_bytes() * self.count
+        host = (ctypes.c_char * nbytes)()
+        total = 0
+        for i, (_, (_, out, w, a)) in enumerate(self.entries):
+            total = lib.rv_pack_table_fill(host, i, ptr(w), ptr(out), *a)
+            if total < 0:
+                raise RuntimeError('rv_pack_table_fill: ' + _lib.last_error())
+        self.total_blocks = total
+        self.table = torch.frombuffer(host, dtype=torch.uint8).clone().to(device)
+
+    def run(self):
+        if not self.count:
+            return
+        call('rv_pack_table_run', ptr(self.table), self.count, self.total_blocks, stream())
+        for key, (_, out, w, a) in self.entries:
+            _pack_cache[key] = ((_EPOCH[0], w._version, tuple(w.shape)), out, w, a)
 
 
 _FWD_MODE = {'c3': 0, 't3': 0, 'c1': 1, 'down': 2, 'up': 3}

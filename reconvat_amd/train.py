@@ -160,6 +160,7 @@ class TrainStep:
         self.losses = None
         self.loss = None
         self.use_graph = graph
+        self.pack_plan = None
 
     def _fwd_bwd(self):
         self.opt.zero_grad()
@@ -189,11 +190,13 @@ class TrainStep:
                 self._fwd_bwd()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        # all weights are repacked by ONE launch after every optimiser step (outside the graph); the graph itself is
+        # captured with a fresh cache and therefore holds no packing kernels
+        self.pack_plan = ops.PackPlan(self.opt.flat_grad.device)
+        self.pack_plan.run()
         self.graph = torch.cuda.CUDAGraph()
-        ops.invalidate_weight_cache()          # the weight packing kernels must be part of the graph
         with torch.cuda.graph(self.graph):
             self._fwd_bwd()
-        ops.invalidate_weight_cache()
 
     def __call__(self):
         if self.use_graph:
@@ -203,9 +206,12 @@ class TrainStep:
         else:
             self.model.train()
             self._fwd_bwd()
+            if self.pack_plan is None:
+                self.pack_plan = ops.PackPlan(self.opt.flat_grad.device)
         if not self.opt.data_parallel:
             allreduce_gradients(self.opt)
         self.opt.step()
         if self.clip:
             self.opt.clip_grad_norm_(self.clip)
+        self.pack_plan.run()                   # the next step's forward finds every packed weight fresh
         return self.loss
