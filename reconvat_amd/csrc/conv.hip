@@ -975,25 +975,35 @@ struct WreduceArgs {
     int accumulate;
 };
 
+// EL output elements x (256 / EL) partial lanes per workgroup.  The host picks EL so that the grid fills the chip:
+// the small-channel layers have few outputs but hundreds of partials, and with 64 elements per workgroup their
+// reduction was a handful of workgroups walking long dependent load chains (38 us for 144 outputs).
+template <int EL>
 __global__ __launch_bounds__(256) void wgrad_reduce_k(WreduceArgs a) {
-    __shared__ float sh[4][64];
+    constexpr int PL = 256 / EL;
+    __shared__ float sh[256];
     const long nel = (long)a.taps * a.Ca * a.Cb + (a.dbias ? a.Cb : 0);
-    const int el = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const long e = (long)blockIdx.x * 64 + el;
+    const int el = threadIdx.x % EL, pl = threadIdx.x / EL;
+    const long e = (long)blockIdx.x * EL + el;
     float s0 = 0.f, s1 = 0.f;
     if (e < nel) {
         const float* p = a.part + e;
         int k = pl;
-        for (; k + 4 < a.nparts; k += 8) {
+        for (; k + PL < a.nparts; k += 2 * PL) {
             s0 += p[(long)k * a.pstride];
-            s1 += p[(long)(k + 4) * a.pstride];
+            s1 += p[(long)(k + PL) * a.pstride];
         }
-        for (; k < a.nparts; k += 4) s0 += p[(long)k * a.pstride];
+        for (; k < a.nparts; k += PL) s0 += p[(long)k * a.pstride];
     }
-    sh[pl][el] = s0 + s1;
+    sh[pl * EL + el] = s0 + s1;
     __syncthreads();
+#pragma unroll
+    for (int h = PL / 2; h >= 1; h >>= 1) {               // fixed tree: deterministic
+        if (pl < h) sh[pl * EL + el] += sh[(pl + h) * EL + el];
+        __syncthreads();
+    }
     if (pl != 0 || e >= nel) return;
-    const float s = (sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el]);
+    const float s = sh[el];
     const long nw = (long)a.taps * a.Ca * a.Cb;
     if (e < nw) {
         int bb = (int)(e % a.Cb);
@@ -1452,7 +1462,9 @@ reduce:
         r.part = a.part; r.pstride = a.pstride; r.nparts = a.nparts; r.taps = taps; r.Ca = Ca; r.Cb = Cb;
         r.dw = dw; r.s_a = s_a; r.s_b = s_b; r.flip = flip; r.dbias = dbias; r.accumulate = accumulate;
         long nel = (long)taps * Ca * Cb + (dbias ? Cb : 0);
-        hipLaunchKernelGGL(wgrad_reduce_k, dim3(cdiv(nel, 64)), dim3(256), 0, st, r);
+        if (cdiv(nel, 64) >= 256 || a.nparts <= 8) hipLaunchKernelGGL(wgrad_reduce_k<64>, dim3(cdiv(nel, 64)), dim3(256), 0, st, r);
+        else if (cdiv(nel, 16) >= 256 || a.nparts <= 32) hipLaunchKernelGGL(wgrad_reduce_k<16>, dim3(cdiv(nel, 16)), dim3(256), 0, st, r);
+        else hipLaunchKernelGGL(wgrad_reduce_k<4>, dim3(cdiv(nel, 4)), dim3(256), 0, st, r);
         RV_LAUNCH_CHECK("rv_conv_wgrad(reduce)");
     }
     return RV_OK;
