@@ -89,11 +89,14 @@ int rv_sigmoid_bwd(const float* g1, int ld1, const float* g2, int ld2, const flo
 int rv_colsum(const float* x, int ld, long M, int N, float* out, int accumulate, void* stream);
 
 /* ---- 31-frame local multi-head attention (MutliHeadAttention1D.forward, model/UNet_onset.py:56-91)
- * q,k,v,out [B,L,G*dh]; rel [G*dh,31]; att, de [B,L,G,31]. */
-int rv_local_attn_fwd(const float* q, const float* k, const float* v, const float* rel, float* out, float* att, int B, int L,
-                      int G, int dh, void* stream);
-int rv_local_attn_bwd(const float* dout, const float* q, const float* k, const float* v, const float* rel, const float* att,
-                      float* dq, float* dk, float* dv, float* de, int B, int L, int G, int dh, void* stream);
+ * q,k,v (and dq,dk,dv): rows of G*dh floats with row stride ld / dld (column slices of one fused projection buffer
+ * are fine); out, dout [B,L,G*dh] contiguous; relT [31,G*dh] = the `rel` parameter transposed (rv_pack_weights with
+ * taps=1, kdim=31, ndim=G*dh, s_k=1, s_n=31, force_plain=1 produces it); att, de [B,L,G,31]. */
+int rv_local_attn_fwd(const float* q, const float* k, const float* v, long ld, const float* relT, float* out, float* att, int B,
+                      int L, int G, int dh, void* stream);
+int rv_local_attn_bwd(const float* dout, const float* q, const float* k, const float* v, long ld, const float* relT,
+                      const float* att, float* dq, float* dk, float* dv, long dld, float* de, int B, int L, int G, int dh,
+                      void* stream);
 
 /* ---- VAT primitives (UNet_VAT.forward / _l2_normalize, model/UNet_onset.py:126-151,165-171) --------
  * x_adv = clamp(x + scale * rownormalise(prescale*d), 0, 1) over rows of n elements. */

@@ -79,6 +79,17 @@ __device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv& f) {
     return (unsigned)(((unsigned long long)__umulhi(n, f.mul) + n) >> f.shift);
 }
 
+// LDS-DMA (global -> LDS without a VGPR round trip, tracked by vmcnt): every active lane moves 16 (or 4) bytes to
+// LDS address = wave-uniform base + lane * 16 (or 4).  Wait with s_waitcnt vmcnt before a barrier publishes the data.
+__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const float* g, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+
 // bn.hip: sums[0..C) += sum_p z[p][c], sums[C..2C) += sum_p z[p][c]^2 (fp64) -- the BatchNorm2d batch statistics pass,
 // also used by rv_conv_fwd behind the conv kernels that do not produce the statistics in their epilogue.
 int rv_internal_bn_stats(const float* z, int z_ld, long P, int C, double* sums, hipStream_t st);

@@ -288,11 +288,6 @@ struct ConvLdsArgs {
     int nsplit, xcd;   // n-splits per band group; XCD-aware placement on/off
 };
 
-__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
-    // LDS destination = wave-uniform base + lane*16 bytes (hardware adds the lane offset)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 
 // wait until at most n of this wave's VMEM operations are outstanding (n wave-uniform; clamping down is safe)
 __device__ __forceinline__ void wait_vmcnt_le(int n) {

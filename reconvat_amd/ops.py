@@ -175,6 +175,20 @@ def _pack(kind, w, which):
     return out
 
 
+def _pack_rel(rel, f):
+    """rel^T [31, F] for the attention kernels (cached per weight version; part of the PackPlan table)."""
+    key = (rel.data_ptr(), 'rel', 'T')
+    tag = (_EPOCH[0], rel._version, tuple(rel.shape))
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    args = (1, 31, f, 1, 31, 0, 0, 1)            # out[w*F + c] = rel[c*31 + w]
+    out = torch.empty(31 * f, device=rel.device, dtype=torch.float32)
+    call('rv_pack_weights', ptr(rel), ptr(out), *args, stream())
+    _pack_cache[key] = (tag, out, rel, args)
+    return out
+
+
 class PackPlan:
     """Every packed weight currently in the cache, repacked by ONE kernel launch (rv_pack_table_run).  Build it after
     a warm-up step has populated the cache, call ``run()`` right after each optimiser step: the cache entries are
@@ -606,62 +620,95 @@ class OnsetHeadsFn(Function):
 # --------------------------------------------------------------------------------------------
 # local attention
 # --------------------------------------------------------------------------------------------
+def _adjacent(*ts):
+    """True when the tensors are contiguous and laid out back to back in memory (flat parameter / gradient buffers)."""
+    for a, b in zip(ts, ts[1:]):
+        if a is None or b is None or not (a.is_contiguous() and b.is_contiguous()):
+            return False
+        if a.data_ptr() + a.numel() * a.element_size() != b.data_ptr():
+            return False
+        if a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr():
+            return False                     # neighbours by accident of the allocator, not views of one buffer
+    return True
+
+
 class LocalAttnFn(Function):
     """MutliHeadAttention1D.forward (model/UNet_onset.py:56-91) on x [B, L, Fin] (contiguous):
-       returns (out [B, L, F], attention [B, L, G, 31])."""
+       returns (out [B, L, F], attention [B, L, G, 31]).
+
+    The three projections write column slices [k | q | v] of ONE [B*L, 3F] buffer (the attention kernels take a row
+    stride).  When W_k, W_q, W_v sit back to back in memory -- they do in FlatAdam's flat parameter buffer, in
+    registration order -- the projection, its input gradient and its weight gradient are one GEMM each."""
 
     @staticmethod
     def forward(ctx, x, wq, wk, wv, rel, groups):
         need_gpu(x, wq)
         bb, l, fin = x.shape
         f = wq.shape[0]
-        x2 = x.reshape(bb * l, fin)
-        q = torch.empty((bb * l, f), device=x.device, dtype=torch.float32)
-        k = torch.empty_like(q)
-        v = torch.empty_like(q)
-        gemm(x2, wq.t(), q)
-        gemm(x2, wk.t(), k)
-        gemm(x2, wv.t(), v)
+        m = bb * l
+        x2 = x.reshape(m, fin)
+        qkv = torch.empty((m, 3 * f), device=x.device, dtype=torch.float32)
+        k, q, v = qkv[:, :f], qkv[:, f:2 * f], qkv[:, 2 * f:]
+        fused = _adjacent(wk, wq, wv)
+        if fused:
+            gemm(x2, torch.as_strided(wk, (3 * f, fin), (fin, 1)).t(), qkv)
+        else:
+            gemm(x2, wk.t(), k)
+            gemm(x2, wq.t(), q)
+            gemm(x2, wv.t(), v)
         out = torch.empty((bb, l, f), device=x.device, dtype=torch.float32)
         att = torch.empty((bb, l, groups, 31), device=x.device, dtype=torch.float32)
-        relc = rel.reshape(f, 31)
-        call('rv_local_attn_fwd', ptr(q), ptr(k), ptr(v), ptr(relc), ptr(out), ptr(att), bb, l, groups, f // groups,
-             stream())
+        call('rv_local_attn_fwd', ptr(q), ptr(k), ptr(v), 3 * f, ptr(_pack_rel(rel, f)), ptr(out), ptr(att), bb, l, groups,
+             f // groups, stream())
         ctx.groups = groups
+        ctx.fused = fused
         ctx.params = (wq, wk, wv, rel)
-        ctx.save_for_backward(x2, wq, wk, wv, rel, q, k, v, att)
+        ctx.save_for_backward(x2, wq, wk, wv, rel, qkv, att)
         ctx.mark_non_differentiable(att)
         return out, att
 
     @staticmethod
     def backward(ctx, dout, _datt):
-        x2, wq, wk, wv, rel, q, k, v, att = ctx.saved_tensors
+        x2, wq, wk, wv, rel, qkv, att = ctx.saved_tensors
         g = ctx.groups
         bb, l = att.shape[0], att.shape[1]
         f = wq.shape[0]
+        fin = x2.shape[1]
         dh = f // g
-        dout = dout.contiguous()
-        dq = torch.empty_like(q)
-        dk = torch.empty_like(q)
-        dv = torch.empty_like(q)
-        de = torch.empty_like(att)
-        relc = rel.reshape(f, 31)
-        call('rv_local_attn_bwd', ptr(dout), ptr(q), ptr(k), ptr(v), ptr(relc), ptr(att), ptr(dq), ptr(dk), ptr(dv),
-             ptr(de), bb, l, g, dh, stream())
-        dx = dwq = dwk = dwv = drel = None
         m = bb * l
+        k, q, v = qkv[:, :f], qkv[:, f:2 * f], qkv[:, 2 * f:]
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        dk, dq, dv = dqkv[:, :f], dqkv[:, f:2 * f], dqkv[:, 2 * f:]
+        de = torch.empty_like(att)
+        call('rv_local_attn_bwd', ptr(dout), ptr(q), ptr(k), ptr(v), 3 * f, ptr(_pack_rel(rel, f)), ptr(att), ptr(dq), ptr(dk),
+             ptr(dv), 3 * f, ptr(de), bb, l, g, dh, stream())
+        dx = dwq = dwk = dwv = drel = None
+        fused = ctx.fused
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x2)
-            gemm(dq, wq, dx)
-            gemm(dk, wk, dx, accumulate=True)
-            gemm(dv, wv, dx, accumulate=True)
+            if fused:
+                gemm(dqkv, torch.as_strided(wk, (3 * f, fin), (fin, 1)), dx)
+            else:
+                gemm(dq, wq, dx)
+                gemm(dk, wk, dx, accumulate=True)
+                gemm(dv, wv, dx, accumulate=True)
             dx = dx.view(bb, l, -1)
         pwq, pwk, pwv, prel = ctx.params
         if ctx.needs_input_grad[1]:
-            sk = _splitk_for(f, x2.shape[1], m)
-            dwq = _param_wgrad(dq.t(), x2, pwq, sk)
-            dwk = _param_wgrad(dk.t(), x2, pwk, sk)
-            dwv = _param_wgrad(dv.t(), x2, pwv, sk)
+            gk, gq, gv = _grad_buf(pwk), _grad_buf(pwq), _grad_buf(pwv)
+            if fused and _adjacent(gk, gq, gv):
+                gemm(dqkv.t(), x2, torch.as_strided(gk, (3 * f, fin), (fin, 1)), accumulate=True,
+                     splitk=_splitk_for(3 * f, fin, m))
+            elif fused:
+                dw3 = torch.empty((3 * f, fin), device=x2.device, dtype=torch.float32)
+                gemm(dqkv.t(), x2, dw3, splitk=_splitk_for(3 * f, fin, m))
+                dwk, dwq, dwv = dw3[:f], dw3[f:2 * f], dw3[2 * f:]
+            else:
+                sk = _splitk_for(f, fin, m)
+                dwq = _param_wgrad(dq.t(), x2, pwq, sk)
+                dwk = _param_wgrad(dk.t(), x2, pwk, sk)
+                dwv = _param_wgrad(dv.t(), x2, pwv, sk)
         if ctx.needs_input_grad[4]:
             # drel[g*dh+f, w] = sum_{b,t} q[b,t,g,f] * de[b,t,g,w]
             grel = _grad_buf(prel)
