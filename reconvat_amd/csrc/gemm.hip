@@ -29,6 +29,8 @@ struct GemmArgs {
     int accumulate;     // C += (plain read-modify-write; requires splitk == 1)
     int splitk;         // >1: K split over blockIdx.z, atomicAdd epilogue (C pre-zeroed by the host wrapper)
     int a_vec, b_vec;   // 16-byte loads along the contiguous dimension are legal
+    int batch;          // independent problems over blockIdx.z / splitk: A += z*bsa, B += z*bsb, C += z*bsc
+    long bsa, bsb, bsc;
 };
 
 // One operand tile: `rows` (m or n) x GBK.  KFAST: memory is contiguous along k -> LDS layout [row][k];
@@ -82,7 +84,10 @@ struct TileIO {
 };
 
 template <bool AK, bool BK_>
-__global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a) {
+__global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a_in) {
+    GemmArgs a = a_in;
+    const int bz = blockIdx.z / a.splitk, kz = blockIdx.z - bz * a.splitk;
+    a.A += (long)bz * a.bsa; a.B += (long)bz * a.bsb; a.C += (long)bz * a.bsc;
     __shared__ __attribute__((aligned(16))) float As[GBM * LDK > GBK * LDM ? GBM * LDK : GBK * LDM];
     __shared__ __attribute__((aligned(16))) float Bs[GBN * LDK > GBK * LDM ? GBN * LDK : GBK * LDM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a) {
     const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const int kper = ((a.K + a.splitk - 1) / a.splitk + GBK - 1) / GBK * GBK;
-    const int k_begin = blockIdx.z * kper;
+    const int k_begin = kz * kper;
     const int k_end = min(a.K, k_begin + kper);
 
     f32x4 acc[2][2];   // [n-tile][m-tile]
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a) {
             const int nb = n0 + wn + x * 16 + 4 * g;
             if (m >= a.M || nb >= a.N) continue;
             f32x4 v = acc[x][y];
-            if (a.bias && (a.splitk == 1 || blockIdx.z == 0)) {
+            if (a.bias && (a.splitk == 1 || kz == 0)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (nb + r < a.N) v[r] += a.bias[nb + r];
@@ -178,26 +183,30 @@ extern "C" {
 // splitk > 1 splits the reduction over extra workgroups (atomic fp32 accumulation; act must be 0, C2 must be null):
 // with accumulate == 0 C is zeroed first, with accumulate != 0 the atomics add straight into C's contents (gradient
 // accumulation).  C2 (nullable) receives a second copy with its own strides.
+// batch > 1: `batch` independent problems of the same shape, problem z at A + z*bsa, B + z*bsb, C + z*bsc (C2 must be null).
 int rv_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm, long scn, float* C2,
-            long sc2m, long sc2n, const float* bias, int M, int N, int K, int act, int accumulate, int splitk, void* stream) {
+            long sc2m, long sc2n, const float* bias, int M, int N, int K, int act, int accumulate, int splitk, int batch,
+            long bsa, long bsb, long bsc, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     RV_CHECK_ARG(M > 0 && N > 0 && K > 0, "rv_gemm: empty problem");
     RV_CHECK_ARG(splitk >= 1, "rv_gemm: splitk must be >= 1");
+    RV_CHECK_ARG(batch >= 1 && (batch == 1 || !C2) && (long)batch * splitk < 65536, "rv_gemm: bad batch %d", batch);
     if (splitk > 1) RV_CHECK_ARG(act == 0 && !C2, "rv_gemm: splitk excludes act/C2");
     GemmArgs a;
     a.A = A; a.sam = sam; a.sak = sak; a.B = B; a.sbk = sbk; a.sbn = sbn; a.C = C; a.scm = scm; a.scn = scn;
     a.C2 = C2; a.sc2m = sc2m; a.sc2n = sc2n; a.bias = bias; a.M = M; a.N = N; a.K = K; a.act = act;
-    a.accumulate = accumulate; a.splitk = splitk;
+    a.accumulate = accumulate; a.splitk = splitk; a.batch = batch; a.bsa = bsa; a.bsb = bsb; a.bsc = bsc;
     const bool a_kfast = (sak <= sam), b_kfast = (sbk <= sbn);
     // 16-byte loads need a unit stride along the fast dimension, a 16-byte multiple along the slow one and an
     // aligned base; K-split offsets are multiples of GBK so they preserve alignment
-    a.a_vec = ((a_kfast ? sak : sam) == 1) && (((a_kfast ? sam : sak) & 3) == 0) && ((((uintptr_t)A) & 15) == 0);
-    a.b_vec = ((b_kfast ? sbk : sbn) == 1) && (((b_kfast ? sbn : sbk) & 3) == 0) && ((((uintptr_t)B) & 15) == 0);
+    a.a_vec = ((a_kfast ? sak : sam) == 1) && (((a_kfast ? sam : sak) & 3) == 0) && ((((uintptr_t)A) & 15) == 0) && (batch == 1 || (bsa & 3) == 0);
+    a.b_vec = ((b_kfast ? sbk : sbn) == 1) && (((b_kfast ? sbn : sbk) & 3) == 0) && ((((uintptr_t)B) & 15) == 0) && (batch == 1 || (bsb & 3) == 0);
     if (splitk > 1 && !accumulate) {
+        RV_CHECK_ARG(batch == 1, "rv_gemm: batched split-K needs accumulate (zero C yourself)");
         hipLaunchKernelGGL(zero_strided_k, dim3(cdiv((long)M * N, 256)), dim3(256), 0, st, C, scm, scn, M, N);
         RV_LAUNCH_CHECK("rv_gemm(zero)");
     }
-    dim3 grid(cdiv(N, GBN), cdiv(M, GBM), splitk);
+    dim3 grid(cdiv(N, GBN), cdiv(M, GBM), splitk * batch);
     if (a_kfast && b_kfast) hipLaunchKernelGGL((gemm_mfma_k<true, true>), grid, dim3(256), 0, st, a);
     else if (a_kfast && !b_kfast) hipLaunchKernelGGL((gemm_mfma_k<true, false>), grid, dim3(256), 0, st, a);
     else if (!a_kfast && b_kfast) hipLaunchKernelGGL((gemm_mfma_k<false, true>), grid, dim3(256), 0, st, a);

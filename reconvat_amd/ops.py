@@ -485,8 +485,9 @@ def _mat(t):
     return ptr(t), t.shape[0], t.shape[1], t.stride(0), t.stride(1)
 
 
-def gemm(a, b_kn, c, bias=None, act=0, accumulate=False, splitk=1, c2=None):
-    """c[m,n] (+)= act(sum_k a[m,k] * b_kn[k,n] + bias[n]) on arbitrary 2-D views."""
+def gemm(a, b_kn, c, bias=None, act=0, accumulate=False, splitk=1, c2=None, batch=1, bstrides=(0, 0, 0)):
+    """c[m,n] (+)= act(sum_k a[m,k] * b_kn[k,n] + bias[n]) on arbitrary 2-D views.  batch > 1: `batch` problems of this
+    shape, problem z offset by z * bstrides (elements) from a / b_kn / c."""
     need_gpu(a, b_kn, c)
     pa, m, k, sam, sak = _mat(a)
     pb, k2, n, sbk, sbn = _mat(b_kn)
@@ -497,7 +498,7 @@ def gemm(a, b_kn, c, bias=None, act=0, accumulate=False, splitk=1, c2=None):
     else:
         pc2, s2m, s2n = None, 0, 0
     call('rv_gemm', pa, sam, sak, pb, sbk, sbn, pc, scm, scn, pc2, s2m, s2n, ptr(bias), m, n, k, act,
-         1 if accumulate else 0, splitk, stream())
+         1 if accumulate else 0, splitk, batch, bstrides[0], bstrides[1], bstrides[2], stream())
 
 
 def colsum(x2d, out=None, accumulate=False):
@@ -713,10 +714,10 @@ class LocalAttnFn(Function):
             # drel[g*dh+f, w] = sum_{b,t} q[b,t,g,f] * de[b,t,g,w]
             grel = _grad_buf(prel)
             direct = grel is not None
-            drel = grel.view(f, 31) if direct else torch.empty((f, 31), device=q.device, dtype=torch.float32)
+            drel = grel.view(f, 31) if direct else torch.zeros((f, 31), device=q.device, dtype=torch.float32)
             de2 = de.view(m, g, 31)
-            for h in range(g):
-                gemm(q[:, h * dh:(h + 1) * dh].t(), de2[:, h, :], drel[h * dh:(h + 1) * dh], accumulate=direct, splitk=16)
+            # one batched split-K launch over the heads: head h reads q[:, h*dh:], de[:, h, :], writes drel[h*dh:]
+            gemm(q[:, :dh].t(), de2[:, 0, :], drel[:dh], accumulate=True, splitk=16, batch=g, bstrides=(dh, 31, dh * 31))
             drel = None if direct else drel.view_as(rel)
         return dx, dwq, dwk, dwv, drel, None
 

@@ -33,8 +33,8 @@ ops.call = real
 lib = _lib.load()
 groups = {}
 for a in recs:
-    # (A, sam, sak, B, sbk, sbn, C, scm, scn, C2, s2m, s2n, bias, M, N, K, act, acc, splitk, stream)
-    sig = (a[13], a[14], a[15], 'Ak' if a[2] <= a[1] else 'Am', 'Bk' if a[4] <= a[5] else 'Bn', a[16], a[17], a[18], a[1], a[2], a[4], a[5], a[7], a[8])
+    # (A, sam, sak, B, sbk, sbn, C, scm, scn, C2, s2m, s2n, bias, M, N, K, act, acc, splitk, batch, bsa, bsb, bsc, stream)
+    sig = (a[13], a[14], a[15], 'Ak' if a[2] <= a[1] else 'Am', 'Bk' if a[4] <= a[5] else 'Bn', a[16], a[17], a[18], a[1], a[2], a[4], a[5], a[7], a[8], a[19])
     g = groups.setdefault(sig, [0, a])
     g[0] += 1
 rows = []
@@ -48,10 +48,10 @@ for sig, (cnt, a) in groups.items():
     e1.record()
     e1.synchronize()
     ms = e0.elapsed_time(e1) / 5
-    fl = 2.0 * sig[0] * sig[1] * sig[2]
+    fl = 2.0 * sig[0] * sig[1] * sig[2] * sig[-1]
     rows.append((ms * cnt, cnt, ms, fl / ms / 1e9, sig))
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print(f'{len(recs)} gemm launches/step, {tot:.3f} ms/step')
 for r in rows:
-    print(f'{r[0]:7.3f} ms/step x{r[1]:3d} {r[2] * 1e3:7.1f} us {r[3]:6.1f} TF/s  M,N,K={r[4][:3]} {r[4][3]}{r[4][4]} act={r[4][5]} acc={r[4][6]} splitk={r[4][7]} strides={r[4][8:]}')
+    print(f'{r[0]:7.3f} ms/step x{r[1]:3d} {r[2] * 1e3:7.1f} us {r[3]:6.1f} TF/s  M,N,K={r[4][:3]} {r[4][3]}{r[4][4]} act={r[4][5]} acc={r[4][6]} splitk={r[4][7]} batch={r[4][-1]} strides={r[4][8:-1]}')
