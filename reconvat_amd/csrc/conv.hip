@@ -1363,7 +1363,15 @@ static WgradPlan wgrad_plan(int taps, int B, int Hv, int Ca, int Cb) {
         p.nparts = nrows < 1024 ? nrows : 1024;
         return p;
     }
-    p.TA = Ca > 16 ? 2 : 1; p.TB = Cb > 16 ? 2 : 1;
+    // channel-group shape (TA x TB tiles of 16): the one that pads the channel counts least (48 = 3 x 16, not 2 x 32);
+    // ties go to the larger group (more register reuse per LDS read)
+    long best = -1;
+    p.TA = p.TB = 1;
+    for (int ta = 2; ta >= 1; --ta)
+        for (int tb = 2; tb >= 1; --tb) {
+            const long padded = (long)cdiv(Ca, ta * 16) * ta * cdiv(Cb, tb * 16) * tb;
+            if (best < 0 || padded < best) { best = padded; p.TA = ta; p.TB = tb; }
+        }
     p.nga = cdiv(Ca, p.TA * 16); p.ngb = cdiv(Cb, p.TB * 16);
     static int want_total = 0;
     if (!want_total) { const char* e = getenv("RV_WGRAD_WGS"); want_total = e ? atoi(e) : 256; }
