@@ -607,6 +607,8 @@ struct SmallArgs {
     const float* bias;
     long npix;
     int accumulate;
+    FastDiv fd_plane, fd_wo;   // divide by Ho*Wo, by Wo (npix * COUT/4 < 2^31)
+    double* bn_sums;           // optional fused BatchNorm statistics of the output (COUT >= 4 instances)
 };
 
 // COUT >= 4: four output channels per thread (COUT/4 threads per pixel) so that a wave's stores are
@@ -618,8 +620,9 @@ __global__ __launch_bounds__(256) void conv_small_k(SmallArgs a) {
     constexpr int CPT = COUT >= 4 ? 4 : COUT;        // output channels per thread
     constexpr int TPP = COUT / CPT;                  // threads per pixel
     constexpr bool WREG = (TPP > 1) && (KH * KW * CIN * CPT <= 80);
-    const long tstride = (long)gridDim.x * blockDim.x;
-    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned tstride = gridDim.x * blockDim.x;
+    unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned tend = (unsigned)a.npix * TPP;
     const int c0 = (int)(t % TPP) * CPT;
     float wreg[WREG ? KH * KW * CIN * CPT : 1];
     if constexpr (WREG) {
@@ -633,11 +636,14 @@ __global__ __launch_bounds__(256) void conv_small_k(SmallArgs a) {
     float bias[CPT];
 #pragma unroll
     for (int co = 0; co < CPT; ++co) bias[co] = a.bias ? a.bias[c0 + co] : 0.f;
-    for (; t < a.npix * TPP; t += tstride) {
-        const long p = t / TPP;
-        int b = (int)(p / ((long)a.Ho * a.Wo));
-        int rem = (int)(p - (long)b * a.Ho * a.Wo);
-        int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+    float st1[CPT], st2[CPT];                        // BatchNorm statistics of this thread's channel quad
+#pragma unroll
+    for (int co = 0; co < CPT; ++co) st1[co] = st2[co] = 0.f;
+    for (; t < tend; t += tstride) {
+        const unsigned p = t / TPP;
+        const int b = (int)fastdiv(p, a.fd_plane);
+        const unsigned rem = p - (unsigned)b * (unsigned)(a.Ho * a.Wo);
+        const int oy = (int)fastdiv(rem, a.fd_wo), ox = (int)rem - oy * a.Wo;
         float acc[CPT];
 #pragma unroll
         for (int co = 0; co < CPT; ++co) acc[co] = bias[co];
@@ -668,19 +674,38 @@ __global__ __launch_bounds__(256) void conv_small_k(SmallArgs a) {
                         acc[co] = fmaf(xin[c], wv, acc[co]);
                     }
             }
-        float* o = a.out + p * a.out_ld + c0;
-        bool done = false;
-        if constexpr (CPT == 4) {
-            f32x4 v = (f32x4){acc[0], acc[1], acc[2], acc[3]};
-            if ((a.out_ld & 3) == 0) {
-                if (a.accumulate) { f32x4 old = *reinterpret_cast<f32x4*>(o); v += old; }
-                *reinterpret_cast<f32x4*>(o) = v;
-                done = true;
-            }
-        }
-        if (!done) {
+        float* o = a.out + (long)p * a.out_ld + c0;
+        if (a.accumulate) {
 #pragma unroll
-            for (int co = 0; co < CPT; ++co) o[co] = a.accumulate ? o[co] + acc[co] : acc[co];
+            for (int co = 0; co < CPT; ++co) acc[co] += o[co];
+        }
+        if (CPT == 4 && (a.out_ld & 3) == 0) {
+            *reinterpret_cast<f32x4*>(o) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+        } else {
+#pragma unroll
+            for (int co = 0; co < CPT; ++co) o[co] = acc[co];
+        }
+#pragma unroll
+        for (int co = 0; co < CPT; ++co) { st1[co] += acc[co]; st2[co] = fmaf(acc[co], acc[co], st2[co]); }
+    }
+    if constexpr (TPP > 1) {
+        // fused BatchNorm statistics: threads with the same channel quad (tid % TPP) fold through LDS, then one fp64
+        // atomic per channel and workgroup (the host caps the grid when statistics are requested)
+        if (a.bn_sums) {
+            __shared__ float red[256 * 2 * CPT];
+#pragma unroll
+            for (int co = 0; co < CPT; ++co) {
+                red[(threadIdx.x * CPT + co) * 2] = st1[co];
+                red[(threadIdx.x * CPT + co) * 2 + 1] = st2[co];
+            }
+            __syncthreads();
+            if (threadIdx.x < COUT * 2) {
+                const int ch = threadIdx.x >> 1, which = threadIdx.x & 1;
+                const int quad = ch / CPT, co = ch - quad * CPT;
+                double d = 0.0;
+                for (int k = quad; k < 256; k += TPP) d += (double)red[(k * CPT + co) * 2 + which];
+                atomicAdd(&a.bn_sums[which * COUT + ch], d);
+            }
         }
     }
 }
@@ -695,6 +720,7 @@ struct WgradArgs {
     float* part; long pstride;               // partial sums [nparts][taps*Ca*Cb (+Cb)]
     int rows_per_wave, nparts, ngb;          // ngb = number of b-groups
     int want_bias;
+    FastDiv fd_vplane, fd_wv;                // divide by Hv*Wv, by Wv (small-channel kernel)
 };
 
 // LDS-staged pixel-reduction GEMM.  One workgroup owns a run of V rows (b, y) and one (a-group, b-group)
@@ -917,17 +943,29 @@ __global__ __launch_bounds__(256) void wgrad_small_k(WgradArgs a) {
             for (int y = 0; y < CB; ++y) acc[t][x][y] = 0.f;
 #pragma unroll
     for (int y = 0; y < CB; ++y) accb[y] = 0.f;
-    const long npix = (long)a.B * a.Hv * a.Wv;
-    const long per = (npix + a.nparts - 1) / a.nparts;
-    const long p0 = (long)pw * per, p1 = min(p0 + per, npix);
-    for (long p = p0 + lane; p < p1; p += 64) {
-        int b = (int)(p / ((long)a.Hv * a.Wv));
-        int rem = (int)(p - (long)b * a.Hv * a.Wv);
-        int y = rem / a.Wv, x = rem - y * a.Wv;
+    const unsigned npix = (unsigned)(a.B * a.Hv * a.Wv);
+    const unsigned per = (npix + a.nparts - 1) / a.nparts;
+    const unsigned p0 = (unsigned)pw * per, p1 = min(p0 + per, npix);
+    const bool vvec = (CB % 4 == 0) && (a.v_ld % 4 == 0) && ((((uintptr_t)a.V) & 15) == 0);
+    const bool uvec = (CA % 4 == 0) && (a.u_ld % 4 == 0) && ((((uintptr_t)a.U) & 15) == 0);
+    for (unsigned p = p0 + lane; p < p1; p += 64) {
+        const int b = (int)fastdiv(p, a.fd_vplane);
+        const unsigned rem = p - (unsigned)b * (unsigned)(a.Hv * a.Wv);
+        const int y = (int)fastdiv(rem, a.fd_wv), x = (int)rem - y * a.Wv;
         float v[CB];
-        const float* vp = a.V + p * a.v_ld;
+        const float* vp = a.V + (long)p * a.v_ld;
+        if (CB % 4 == 0 && vvec) {
 #pragma unroll
-        for (int c = 0; c < CB; ++c) { v[c] = vp[c]; accb[c] += v[c]; }
+            for (int c = 0; c < CB; c += 4) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(vp + c);
+                v[c] = q[0]; v[c + 1] = q[1]; v[c + 2] = q[2]; v[c + 3] = q[3];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CB; ++c) v[c] = vp[c];
+        }
+#pragma unroll
+        for (int c = 0; c < CB; ++c) accb[c] += v[c];
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky)
 #pragma unroll
@@ -935,13 +973,22 @@ __global__ __launch_bounds__(256) void wgrad_small_k(WgradArgs a) {
                 int iy = y * S - P + ky, ix = x * S - P + kx;
                 if ((unsigned)iy >= (unsigned)a.Hu || (unsigned)ix >= (unsigned)a.Wu) continue;
                 const float* up = a.U + (((long)b * a.Hu + iy) * a.Wu + ix) * a.u_ld;
+                float u[CA];
+                if (CA % 4 == 0 && uvec) {
 #pragma unroll
-                for (int ca = 0; ca < CA; ++ca) {
-                    float u = up[ca];
+                    for (int c = 0; c < CA; c += 4) {
+                        const f32x4 q = *reinterpret_cast<const f32x4*>(up + c);
+                        u[c] = q[0]; u[c + 1] = q[1]; u[c + 2] = q[2]; u[c + 3] = q[3];
+                    }
+                } else {
+#pragma unroll
+                    for (int ca = 0; ca < CA; ++ca) u[ca] = up[ca];
+                }
+#pragma unroll
+                for (int ca = 0; ca < CA; ++ca)
 #pragma unroll
                     for (int cb = 0; cb < CB; ++cb)
-                        acc[ky * KW + kx][ca][cb] = fmaf(u, v[cb], acc[ky * KW + kx][ca][cb]);
-                }
+                        acc[ky * KW + kx][ca][cb] = fmaf(u[ca], v[cb], acc[ky * KW + kx][ca][cb]);
             }
     }
     float* dst = a.part + (long)pw * a.pstride;
@@ -1277,9 +1324,14 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
         SmallArgs s;
         s.in = in; s.in_ld = in_ld; s.H = H; s.W = W; s.out = out; s.out_ld = out_ld; s.Ho = Ho; s.Wo = Wo;
         s.B = B; s.wplain = wpack; s.bias = bias; s.npix = (long)B * Ho * Wo; s.accumulate = accumulate;
+        s.fd_plane = fastdiv_make((unsigned)(Ho * Wo)); s.fd_wo = fastdiv_make((unsigned)Wo);
         const int tpp = Cout >= 4 ? Cout / 4 : 1;
+        RV_CHECK_ARG(s.npix * tpp < (1L << 31), "rv_conv_fwd: more than 2^31 outputs");
+        s.bn_sums = tpp > 1 ? bn_sums : nullptr;
+        if (s.bn_sums) *sums_done = true;
         long nblk = cdiv(s.npix * tpp, 256);
-        if (nblk > 4096) nblk = 4096;            // grid stride (4096*256 is a multiple of every COUT/4)
+        const long cap = s.bn_sums ? 1024 : 4096;   // grid stride (a multiple of every COUT/4); fewer workgroups = fewer atomics
+        if (nblk > cap) nblk = cap;
         dim3 grid((unsigned)nblk), blk(256);
 #define RV_SMALL(ci, co, kh, kw, ss, pp)                                                          \
     if (Cin == ci && Cout == co) {                                                               \
@@ -1402,6 +1454,8 @@ int rv_conv_wgrad(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, co
     a.U = U; a.u_ld = u_ld; a.Hu = Hu; a.Wu = Wu; a.Ca = Ca; a.V = V; a.v_ld = v_ld; a.Hv = Hv; a.Wv = Wv; a.Cb = Cb;
     a.B = B; a.want_bias = dbias != nullptr;
     a.pstride = (long)taps * Ca * Cb + Cb;
+    a.fd_vplane = fastdiv_make((unsigned)(Hv * Wv)); a.fd_wv = fastdiv_make((unsigned)Wv);
+    RV_CHECK_ARG((long)B * Hv * Wv < (1L << 31), "rv_conv_wgrad: more than 2^31 pixels");
     const WgradPlan plan = wgrad_plan(taps, B, Hv, Ca, Cb);
     RV_CHECK_ARG(workspace_bytes >= (long)plan.nparts * a.pstride * 4, "rv_conv_wgrad: workspace too small");
     a.part = (float*)workspace;
