@@ -73,7 +73,7 @@ def measure_conv_phase(step_fn, device):
     groups = {}
     for name, a in records:
         if name == 'rv_conv_fwd':
-            sig = (name, a[0]) + tuple(a[2:7]) + tuple(a[8:12]) + (a[15], 'bn' if a[16] else '')
+            sig = (name, a[0]) + tuple(a[2:7]) + tuple(a[8:12]) + (a[15], ('bnbwd' if a[17] else 'bn') if a[16] else '')
         else:
             sig = (name, a[0]) + tuple(a[2:6]) + tuple(a[7:12])
         g = groups.setdefault(sig, {'count': 0, 'name': name, 'args': a})
@@ -92,6 +92,8 @@ def measure_conv_phase(step_fn, device):
             a[13] = None
             if a[16]:
                 a[16] = ws.data_ptr()                      # fused BatchNorm statistics: any fp64 scratch
+            if a[17]:
+                a[17], a[19] = out.data_ptr() + 128 * 1024 * 1024, ws.data_ptr() + 1024 * 1024   # z / coefficients: scratch
         else:
             a[1], a[6] = big.data_ptr(), big.data_ptr() + 128 * 1024 * 1024
             a[12], a[16], a[18] = out.data_ptr(), None, ws.data_ptr()

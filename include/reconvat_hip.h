@@ -44,7 +44,10 @@ int rv_melspec_lognorm_fwd(const float* audio, long audio_stride, int B, int nsa
  *   2 LDS/DMA-pipelined kernel (3x3 only) -- the host autotunes 1 vs 2 per layer shape.  bn_sums (nullable,
  *   [2*Cout] fp64, += ): per-channel sum / sum of squares of the written output, i.e. the batch statistics of the
  *   BatchNorm2d that consumes it (conv -> bn call sites, model/UNet_onset.py:196-198,221-223), produced in the conv
- *   epilogue; pass the same buffer to rv_bn_lrelu_fwd as `workspace` with sums_ready = 1.
+ *   epilogue; pass the same buffer to rv_bn_lrelu_fwd as `workspace` with sums_ready = 1.  bn_z (nullable; with
+ *   bn_z_ld, bn_coef = that layer's saved [5C] coefficients, bn_slope): the call is an INPUT-GRADIENT whose result is
+ *   d(loss)/d(output of a BatchNorm+leaky_relu with pre-normalisation input bn_z); bn_sums then receives that layer's
+ *   backward reduction (sum dd, sum dd*xhat) and rv_bn_lrelu_bwd(..., sums_ready = 1) skips its own pass over dy, z.
  * rv_conv_wgrad: G[tap][a][b] = sum_p U[f(p,tap)][a]*V[p][b] (+ column sums of V for the bias), written
  *   to dw[a*s_a + b*s_b + tap'] / dbias[b]; mode 0 = 3x3, 1 = 1x1, 2 = 2x2/s2. */
 long rv_packed_weight_floats(int taps, int kdim, int ndim);
@@ -58,7 +61,7 @@ long rv_pack_table_fill(void* table_host, int i, const float* w, float* out, int
 int rv_pack_table_run(const void* table_dev, int count, long total_blocks, void* stream);
 int rv_conv_fwd(int mode, const float* in, int in_ld, int B, int H, int W, int Cin, float* out, int out_ld, int Ho,
                 int Wo, int Cout, const float* wpack, const float* bias, int accumulate, int algo, double* bn_sums,
-                void* stream);
+                const float* bn_z, int bn_z_ld, const float* bn_coef, float bn_slope, void* stream);
 long rv_conv_wgrad_workspace_bytes(int taps, int B, int Hv, int Ca, int Cb);
 int rv_conv_wgrad(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, const float* V, int v_ld, int Hv, int Wv,
                   int Cb, int B, float* dw, long s_a, long s_b, int flip, float* dbias, int accumulate, void* workspace,
@@ -78,7 +81,7 @@ int rv_bn_running_update(float* running_mean, float* running_var, long* num_batc
                          float momentum, void* stream);
 int rv_bn_lrelu_bwd(const float* dy, int dy_ld, const float* z, int z_ld, long P, int C, const float* coef, float slope,
                     int frozen, float* dz, int dz_ld, float* dgamma, float* dbeta, int param_accumulate, void* workspace,
-                    void* stream);
+                    int sums_ready, void* stream);
 
 /* ---- linear layers (nn.Linear / torch.sigmoid call sites, model/UNet_onset.py:50-52,62-64,275,
  * 292-293,307-313,324,330): C[m*scm+n*scn] (+)= act(sum_k A[m*sam+k*sak]*B[k*sbk+n*sbn] + bias[n]);

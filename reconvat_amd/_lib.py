@@ -27,13 +27,13 @@ SIGNATURES = {
     'rv_pack_table_entry_bytes': (L, []),
     'rv_pack_table_fill': (L, [P, I, P, P, I, I, I, L, L, I, I, I]),
     'rv_pack_table_run': (I, [P, I, L, P]),
-    'rv_conv_fwd': (I, [I, P, I, I, I, I, I, P, I, I, I, I, P, P, I, I, P, P]),
+    'rv_conv_fwd': (I, [I, P, I, I, I, I, I, P, I, I, I, I, P, P, I, I, P, P, I, P, F, P]),
     'rv_conv_wgrad_workspace_bytes': (L, [I, I, I, I, I]),
     'rv_conv_wgrad': (I, [I, P, I, I, I, I, P, I, I, I, I, I, P, L, L, I, P, I, P, L, P]),
     'rv_bn_workspace_bytes': (L, [I]),
     'rv_bn_lrelu_fwd': (I, [P, I, L, I, P, P, P, P, P, F, F, I, F, P, I, P, I, P, P, I, P]),
     'rv_bn_running_update': (I, [P, P, P, P, I, F, P]),
-    'rv_bn_lrelu_bwd': (I, [P, I, P, I, L, I, P, F, I, P, I, P, P, I, P, P]),
+    'rv_bn_lrelu_bwd': (I, [P, I, P, I, L, I, P, F, I, P, I, P, P, I, P, I, P]),
     'rv_gemm': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, I, I, I, I, I, I, I, L, L, L, P]),
     'rv_sigmoid_bwd': (I, [P, I, P, I, P, I, P, I, L, I, P]),
     'rv_colsum': (I, [P, I, L, I, P, I, P]),

@@ -224,6 +224,17 @@ int rv_internal_bn_stats(const float* z, int z_ld, long P, int C, double* sums, 
     return RV_OK;
 }
 
+int rv_internal_bn_bwd_stats(const float* dy, int dy_ld, const float* z, int z_ld, long P, int C, const float* coef, float slope,
+                             double* sums, hipStream_t st) {
+    RV_CHECK_ARG(C % 4 == 0 && C <= 128 && (z_ld % 4) == 0 && (dy_ld % 4) == 0, "bn backward statistics: C=%d unsupported", C);
+    BnArgs a = {};
+    a.z = z; a.z_ld = z_ld; a.dy = dy; a.dy_ld = dy_ld; a.P = P; a.C = C; a.sums = sums; a.coef = coef; a.slope = slope;
+    const int PL = 256 / (C / 4);
+    hipLaunchKernelGGL(bn_reduce_k<true>, dim3(cdiv(P, (long)PL * BN_PIX_PER_THREAD)), dim3(256), 0, st, a);
+    RV_LAUNCH_CHECK("bn backward statistics");
+    return RV_OK;
+}
+
 extern "C" {
 
 // Bytes of workspace the BN entry points need: 2*C fp64 sums.  CONTRACT: the workspace must be ALL-ZERO on entry (the
@@ -260,18 +271,18 @@ int rv_bn_lrelu_fwd(const float* z, int z_ld, long P, int C, const float* gamma,
 
 // dz (and dgamma/dbeta when non-null) from dy; z and coef are the forward's.  frozen != 0: eval-mode BN.
 // param_accumulate != 0: dgamma/dbeta are added into their destinations (gradient accumulation).
+// sums_ready != 0: the workspace already holds the reduction (rv_conv_fwd(..., bn_sums, bn_z, ...) produced dy).
 int rv_bn_lrelu_bwd(const float* dy, int dy_ld, const float* z, int z_ld, long P, int C, const float* coef, float slope,
                     int frozen, float* dz, int dz_ld, float* dgamma, float* dbeta, int param_accumulate, void* workspace,
-                    void* stream) {
+                    int sums_ready, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     RV_CHECK_ARG(C % 4 == 0 && C <= 128, "rv_bn_lrelu_bwd: C=%d must be a multiple of 4 and <= 128", C);
     BnArgs a = {};
     a.z = z; a.z_ld = z_ld; a.dy = dy; a.dy_ld = dy_ld; a.P = P; a.C = C; a.sums = (double*)workspace;
     a.coef = coef; a.slope = slope; a.frozen = frozen; a.out = dz; a.out_ld = dz_ld; a.dgamma = dgamma; a.dbeta = dbeta; a.param_accumulate = param_accumulate;
-    if (!frozen || dgamma) {
-        const int PL = 256 / (C / 4);
-        hipLaunchKernelGGL(bn_reduce_k<true>, dim3(cdiv(P, (long)PL * BN_PIX_PER_THREAD)), dim3(256), 0, st, a);
-        RV_LAUNCH_CHECK("rv_bn_lrelu_bwd(reduce)");
+    if ((!frozen || dgamma) && !sums_ready) {
+        const int rc = rv_internal_bn_bwd_stats(dy, dy_ld, z, z_ld, P, C, coef, slope, a.sums, st);
+        if (rc != RV_OK) return rc;
     }
     hipLaunchKernelGGL(bn_apply_k<true>, dim3(bn_apply_blocks(P * (C / 4))), dim3(256), 0, st, a);
     RV_LAUNCH_CHECK("rv_bn_lrelu_bwd(apply)");

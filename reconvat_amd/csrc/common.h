@@ -93,3 +93,6 @@ __device__ __forceinline__ void glds4(const float* g, float* lds_wave_base) {
 // bn.hip: sums[0..C) += sum_p z[p][c], sums[C..2C) += sum_p z[p][c]^2 (fp64) -- the BatchNorm2d batch statistics pass,
 // also used by rv_conv_fwd behind the conv kernels that do not produce the statistics in their epilogue.
 int rv_internal_bn_stats(const float* z, int z_ld, long P, int C, double* sums, hipStream_t st);
+// ... and the backward reduction: sums += (sum dd, sum dd * xhat), dd = dy * lrelu'(z*scale+shift); coef = [mean|invstd|scale|shift|..]
+int rv_internal_bn_bwd_stats(const float* dy, int dy_ld, const float* z, int z_ld, long P, int C, const float* coef, float slope,
+                             double* sums, hipStream_t st);

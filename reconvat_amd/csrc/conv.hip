@@ -122,6 +122,9 @@ struct ConvArgs {
     int accumulate;   // out += result
     FastDiv fd_pw, fd_plane, fd_w;   // divide by Pw, by Ph*Pw and by the input width W
     double* bn_sums;  // optional [2*Cout] fp64: += per-channel sum / sum of squares of the values written to `out`
+    // bn_z != NULL turns bn_sums into the BACKWARD reduction of the BatchNorm+leaky-ReLU whose output this conv's
+    // result is the gradient of:  dd = out * lrelu'(z*scale + shift);  sums += (dd, dd * (z - mean) * invstd)
+    const float* bn_z; int bn_z_ld; const float* bn_coef; float bn_slope;
 };
 
 template <int R> struct VecR;
@@ -445,6 +448,13 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
     int lbase[MTW];
     bool pv[MTW];
     f32x4 bv[NT];
+    __shared__ __attribute__((aligned(16))) float cf[4 * 64];   // mean | invstd | scale | shift of this workgroup's channels
+    if (a.bn_z) {
+        for (int idx = tid; idx < 4 * NT * 16; idx += NTHR) {
+            const int k = idx / (NT * 16), cl = idx - k * (NT * 16), ch = nt0 * 16 + cl;
+            cf[k * 64 + cl] = ch < a.Cout ? a.bn_coef[k * a.Cout + ch] : 0.f;
+        }
+    }
     f32x4 st1[NT], st2[NT];                      // BatchNorm statistics of this thread's outputs (a.bn_sums)
 #pragma unroll
     for (int n = 0; n < NT; ++n) st1[n] = st2[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -533,6 +543,26 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
         if (c != nchunk - 1) continue;
         // epilogue of this band
         const long pix0 = ((long)b * H + y0) * W;
+        f32x4 zreg[MTW][NT];                     // fused BatchNorm backward: all z loads of the band in flight at once
+        if (a.bn_z) {
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const long opix = pix0 + (wave + NW * m) * 16 + j;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int co0 = (nt0 + n) * 16 + 4 * g;
+                    zreg[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (!pv[m] || co0 >= a.Cout) continue;
+                    const float* zp = a.bn_z + opix * a.bn_z_ld + co0;
+                    if ((a.bn_z_ld & 3) == 0 && co0 + 3 < a.Cout) zreg[m][n] = *reinterpret_cast<const f32x4*>(zp);
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (co0 + r < a.Cout) zreg[m][n][r] = zp[r];
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
             if (!pv[m] || (ABL(aa) & 8)) continue;
@@ -554,8 +584,24 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
                             o[r] = v[r];
                         }
                 }
-                st1[n] += v;
-                st2[n] += v * v;
+                if (a.bn_z) {
+                    // backward statistics: coefficients of these 4 channels from LDS, z of this pixel prefetched above
+                    const f32x4 mean4 = *reinterpret_cast<const f32x4*>(&cf[0 * 64 + n * 16 + 4 * g]);
+                    const f32x4 inv4 = *reinterpret_cast<const f32x4*>(&cf[1 * 64 + n * 16 + 4 * g]);
+                    const f32x4 sc4 = *reinterpret_cast<const f32x4*>(&cf[2 * 64 + n * 16 + 4 * g]);
+                    const f32x4 sh4 = *reinterpret_cast<const f32x4*>(&cf[3 * 64 + n * 16 + 4 * g]);
+                    const f32x4 z4 = zreg[m][n];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float zh = fmaf(z4[r], sc4[r], sh4[r]);
+                        const float dd = zh > 0.f ? v[r] : v[r] * a.bn_slope;
+                        st1[n][r] += dd;
+                        st2[n][r] = fmaf(dd, (z4[r] - mean4[r]) * inv4[r], st2[n][r]);
+                    }
+                } else {
+                    st1[n] += v;
+                    st2[n] += v * v;
+                }
             }
         }
     }
@@ -1294,24 +1340,33 @@ int rv_pack_table_run(const void* table_dev, int count, long total_blocks, void*
 // squares of the values written to `out` -- the BatchNorm2d batch statistics of the consumer (rv_bn_lrelu_fwd with
 // sums_ready = 1).  The persistent 3x3 kernel produces them in its epilogue; every other kernel is followed by the
 // BatchNorm statistics pass.
+// bn_z != NULL (with bn_z_ld, bn_coef = the [5C] coefficients rv_bn_lrelu_fwd saved, bn_slope): `out` is the gradient
+// wrt the OUTPUT of a BatchNorm+leaky-ReLU whose pre-normalisation input is bn_z, and bn_sums receives that layer's
+// backward reduction instead (sum of dd and of dd * xhat, dd = out * lrelu'): rv_bn_lrelu_bwd(..., sums_ready = 1)
+// then skips its reduction pass.
+struct BnFuse { double* sums; const float* z; int z_ld; const float* coef; float slope; };
 static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int W, int Cin, float* out, int out_ld, int Ho,
-                         int Wo, int Cout, const float* wpack, const float* bias, int accumulate, int algo, double* bn_sums,
+                         int Wo, int Cout, const float* wpack, const float* bias, int accumulate, int algo, const BnFuse& bn,
                          bool* sums_done, hipStream_t st);
 
 int rv_conv_fwd(int mode, const float* in, int in_ld, int B, int H, int W, int Cin, float* out, int out_ld, int Ho,
                 int Wo, int Cout, const float* wpack, const float* bias, int accumulate, int algo, double* bn_sums,
-                void* stream) {
+                const float* bn_z, int bn_z_ld, const float* bn_coef, float bn_slope, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     bool sums_done = false;
+    RV_CHECK_ARG(!bn_z || (bn_sums && bn_coef), "rv_conv_fwd: bn_z needs bn_sums and bn_coef");
+    const BnFuse bn = {bn_sums, bn_z, bn_z_ld, bn_coef, bn_slope};
     const int rc = conv_fwd_impl(mode, in, in_ld, B, H, W, Cin, out, out_ld, Ho, Wo, Cout, wpack, bias, accumulate, algo,
-                                 bn_sums, &sums_done, st);
+                                 bn, &sums_done, st);
     if (rc != RV_OK || !bn_sums || sums_done) return rc;
+    if (bn_z) return rv_internal_bn_bwd_stats(out, out_ld, bn_z, bn_z_ld, (long)B * Ho * Wo, Cout, bn_coef, bn_slope, bn_sums, st);
     return rv_internal_bn_stats(out, out_ld, (long)B * Ho * Wo, Cout, bn_sums, st);
 }
 
 static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int W, int Cin, float* out, int out_ld, int Ho,
-                         int Wo, int Cout, const float* wpack, const float* bias, int accumulate, int algo, double* bn_sums,
+                         int Wo, int Cout, const float* wpack, const float* bias, int accumulate, int algo, const BnFuse& bn,
                          bool* sums_done, hipStream_t st) {
+    double* bn_sums = bn.sums;
     RV_CHECK_ARG(mode >= 0 && mode <= 3, "rv_conv_fwd: bad mode %d", mode);
     if (mode == 0 || mode == 1) RV_CHECK_ARG(Ho == H && Wo == W, "rv_conv_fwd: same-size conv needs Ho==H, Wo==W");
     if (mode == 2) RV_CHECK_ARG(Ho == H / 2 && Wo == W / 2, "rv_conv_fwd: down conv needs Ho=H/2, Wo=W/2");
@@ -1327,7 +1382,7 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
         s.fd_plane = fastdiv_make((unsigned)(Ho * Wo)); s.fd_wo = fastdiv_make((unsigned)Wo);
         const int tpp = Cout >= 4 ? Cout / 4 : 1;
         RV_CHECK_ARG(s.npix * tpp < (1L << 31), "rv_conv_fwd: more than 2^31 outputs");
-        s.bn_sums = tpp > 1 ? bn_sums : nullptr;
+        s.bn_sums = (tpp > 1 && !bn.z) ? bn_sums : nullptr;
         if (s.bn_sums) *sums_done = true;
         long nblk = cdiv(s.npix * tpp, 256);
         const long cap = s.bn_sums ? 1024 : 4096;   // grid stride (a multiple of every COUT/4); fewer workgroups = fewer atomics
@@ -1353,6 +1408,7 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
     ConvArgs a;
     a.in = in; a.in_ld = in_ld; a.H = H; a.W = W; a.out = out; a.out_ld = out_ld; a.Ho = Ho; a.Wo = Wo;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.wpack = wpack; a.bias = bias; a.bn_sums = bn_sums;
+    a.bn_z = bn.z; a.bn_z_ld = bn.z_ld; a.bn_coef = bn.coef; a.bn_slope = bn.slope;
     a.nchunk = Cin / (4 * R);
     a.accumulate = accumulate;
     a.vec_store = ((out_ld & 3) == 0) && ((((uintptr_t)out) & 15) == 0);

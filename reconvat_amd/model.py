@@ -20,7 +20,7 @@ import torch.nn.init as init
 from . import ops
 from .constants import N_BINS
 from .frontend import MelSpectrogram, Normalization
-from .ops import (ARENA, ConvFn, UpCatFn, BnActFn, LinearFn, OnsetHeadsFn, LocalAttnFn, VatPerturbFn, SLOPE, bce_mean,
+from .ops import (ARENA, BnLink, ConvFn, UpCatFn, BnActFn, LinearFn, OnsetHeadsFn, LocalAttnFn, VatPerturbFn, SLOPE, bce_mean,
                   mse_mean, abs_mean)
 
 batchNorm_momentum = 0.1
@@ -34,13 +34,15 @@ def _conv(m, x, kind, detach, size=None):
     return ConvFn.apply(x, _p(m.weight, detach), _p(m.bias, detach), kind, size)
 
 
-def _conv_bn(conv, bn, x, kind, res, detach):
+def _conv_bn(conv, bn, x, kind, res, detach, bn_in=None, link=None):
     """lrelu(bn(conv(x))) (+ res).  In training mode the conv leaves the batch statistics of its output in a
-    zeroed fp64 slice (fused epilogue) and the BatchNorm skips its own statistics pass."""
+    zeroed fp64 slice (fused epilogue) and the BatchNorm skips its own statistics pass.  ``link`` (a fresh
+    ops.BnLink) is handed to the ONE conv that consumes the result as ``bn_in``: that conv's input-gradient kernel
+    then also produces this BatchNorm's backward reduction."""
     stats = ARENA.take(2 * bn.num_features, x.device) if bn.training else None
-    z = ConvFn.apply(x, _p(conv.weight, detach), _p(conv.bias, detach), kind, None, stats)
+    z = ConvFn.apply(x, _p(conv.weight, detach), _p(conv.bias, detach), kind, None, stats, bn_in)
     return BnActFn.apply(z, _p(bn.weight, detach), _p(bn.bias, detach), bn.running_mean, bn.running_var,
-                         bn.num_batches_tracked, res, bn.training, SLOPE, stats)
+                         bn.num_batches_tracked, res, bn.training, SLOPE, stats, link)
 
 
 class block(nn.Module):
@@ -56,9 +58,10 @@ class block(nn.Module):
         self.ds = nn.Conv2d(out, out, kernel_size=ds_ksize, stride=ds_stride, padding=0)
 
     def forward(self, x, detach=False):
-        a1 = _conv_bn(self.conv1, self.bn1, x, 'c3', None, detach)
+        l1 = BnLink()                                                          # a1 feeds conv2 only
+        a1 = _conv_bn(self.conv1, self.bn1, x, 'c3', None, detach, link=l1)
         sk = _conv(self.skip, x, 'c1', detach)
-        a2 = _conv_bn(self.conv2, self.bn2, a1, 'c3', sk, detach)               # lrelu(bn2(.)) + skip(x)
+        a2 = _conv_bn(self.conv2, self.bn2, a1, 'c3', sk, detach, bn_in=l1)     # lrelu(bn2(.)) + skip(x)
         xp = _conv(self.ds, a2, 'down', detach)
         return xp, (a2.shape[1], a2.shape[2])
 
@@ -84,10 +87,11 @@ class d_block(nn.Module):
         else:
             x = UpCatFn.apply(x, _p(self.us.weight, detach), _p(self.us.bias, detach), skip_src,
                               _p(skip_conv.weight, detach), _p(skip_conv.bias, detach), size)
-        x = _conv_bn(self.conv2d, self.bn2d, x, 't3', None, detach)
+        l2 = BnLink()                                                          # the bn2d output feeds conv1d only
+        x = _conv_bn(self.conv2d, self.bn2d, x, 't3', None, detach, link=l2)
         if self.isLast:
-            return _conv(self.conv1d, x, 't3', detach)
-        return _conv_bn(self.conv1d, self.bn1d, x, 't3', None, detach)
+            return ConvFn.apply(x, _p(self.conv1d.weight, detach), _p(self.conv1d.bias, detach), 't3', None, None, l2)
+        return _conv_bn(self.conv1d, self.bn1d, x, 't3', None, detach, bn_in=l2)
 
 
 class Encoder(nn.Module):

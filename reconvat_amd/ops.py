@@ -228,18 +228,24 @@ _algo_cache = {}
 AUTOTUNE = True
 
 
-def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias, stats=None):
+def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias, stats=None, bnbwd=None):
     """rv_conv_fwd with a per-shape choice between the LDS-free and the LDS/DMA-pipelined 3x3 kernel.  The first
     eager call of a shape times both (HIP events on the launch stream) and caches the winner; under hipGraph
     capture an untuned shape uses the library default.  ``stats`` (fp64 [2*cout], zeroed): the conv also leaves the
     BatchNorm batch statistics of its output there (fused epilogue of the persistent kernel, else a statistics pass
-    -- the tuner times whichever the candidate implies)."""
+    -- the tuner times whichever the candidate implies).  ``bnbwd`` = (z, coef, slope): the call is an input gradient
+    and ``stats`` receives the backward reduction of the BatchNorm whose output gradient is being produced."""
     args = (mode, ptr(x), ild, bb, h, wd, cin, ptr(out), old, ho, wo, cout, ptr(wpack), ptr(bias), 0)
+    if bnbwd is not None:
+        bz, bcoef, bslope = bnbwd
+        tail = (ptr(bz), _geom(bz)[4], ptr(bcoef), float(bslope))
+    else:
+        tail = (None, 0, None, 0.0)
     algo = 0
     if mode == 0 and os.environ.get('RV_FORCE_ALGO'):      # kernel experiments (tools/bench_conv.py)
         algo = int(os.environ['RV_FORCE_ALGO'], 0)
     elif mode == 0 and AUTOTUNE:
-        key = (bb, h, wd, cin, cout, ild, old, stats is not None)
+        key = (bb, h, wd, cin, cout, ild, old, stats is not None, bnbwd is not None)
         algo = _algo_cache.get(key, -1)
         if algo < 0:
             if torch.cuda.is_current_stream_capturing():
@@ -259,19 +265,19 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
                     cands += [0x300 | nt << 4 | mt for mt in (1, 2, 4)]
                     cands += [0x400 | nt << 4 | mt for mt in (1, 2, 4)]
                 for cand in cands:
-                    if lib.rv_conv_fwd(*args, cand, scratch, st.cuda_stream) != 0:
+                    if lib.rv_conv_fwd(*args, cand, scratch, *tail, st.cuda_stream) != 0:
                         continue                                   # tile does not fit this shape
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(st)
                     for _ in range(3):
-                        lib.rv_conv_fwd(*args, cand, scratch, st.cuda_stream)
+                        lib.rv_conv_fwd(*args, cand, scratch, *tail, st.cuda_stream)
                     e1.record(st)
                     e1.synchronize()
                     t = e0.elapsed_time(e1)
                     if best is None or t < best:
                         best, algo = t, cand
                 _algo_cache[key] = algo
-    call('rv_conv_fwd', *args, algo, ptr(stats), stream())
+    call('rv_conv_fwd', *args, algo, ptr(stats), *tail, stream())
 
 
 def conv_forward_into(kind, x, w, b, out, stats=None):
@@ -282,11 +288,31 @@ def conv_forward_into(kind, x, w, b, out, stats=None):
     _conv_call(_FWD_MODE[kind], x, ild, bb, h, wd, cin, out, old, ho, wo, cout, _pack(kind, w, 'fwd'), b, stats)
 
 
-def conv_dgrad_into(kind, dy, w, dx):
-    """dx (NHWC view) = input gradient of the conv given dy (NHWC view)."""
+def conv_dgrad_into(kind, dy, w, dx, bn_link=None):
+    """dx (NHWC view) = input gradient of the conv given dy (NHWC view).  bn_link: the BnLink of the BatchNorm that
+    produced the conv's input -- its backward reduction is then computed in this kernel's epilogue."""
     bb, h, wd, c, ild = _geom(dy)
     _, ho, wo, co, old = _geom(dx)
-    _conv_call(_DGRAD_MODE[kind], dy, ild, bb, h, wd, c, dx, old, ho, wo, co, _pack(kind, w, 'dgrad'), None)
+    stats = bnbwd = None
+    if bn_link is not None and bn_link.usable(dx):
+        stats, bnbwd = bn_link.ws, (bn_link.z, bn_link.coef, bn_link.slope)
+    _conv_call(_DGRAD_MODE[kind], dy, ild, bb, h, wd, c, dx, old, ho, wo, co, _pack(kind, w, 'dgrad'), None, stats, bnbwd)
+    if stats is not None:
+        bn_link.ready = True
+
+
+class BnLink:
+    """Connects a BatchNorm+activation node with the ONE conv that consumes its output, so that the conv's
+    input-gradient kernel can produce the BatchNorm's backward reduction in its epilogue (the gradient of the
+    BatchNorm output is exactly that conv's dgrad result -- valid only for a single consumer)."""
+
+    def __init__(self):
+        self.z = self.coef = self.ws = None
+        self.slope = 0.0
+        self.ready = False
+
+    def usable(self, dx):
+        return self.ws is not None and self.z is not None and tuple(self.z.shape) == tuple(dx.shape)
 
 
 def conv_wgrad(kind, x, dy, w, want_bias=True, dw_acc=None, db_acc=None):
@@ -338,7 +364,7 @@ class ConvFn(Function):
     """y = conv(x) for any of the five conv kinds (new contiguous NHWC tensor)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, kind, size, stats=None):
+    def forward(ctx, x, w, b, kind, size, stats=None, bn_in=None):
         bb, h, wd, cin, _ = _geom(x)
         _, cout = _channels(kind, w)
         ho, wo = _out_hw(kind, h, wd, size)
@@ -346,6 +372,7 @@ class ConvFn(Function):
         conv_forward_into(kind, x, w, b, y, stats)
         ctx.kind = kind
         ctx.xshape = tuple(x.shape)
+        ctx.bn_in = bn_in            # BnLink of the BatchNorm whose output is x (single consumer), or None
         ctx.save_for_backward(x if ctx.needs_input_grad[1] else None, w)
         ctx.params = (w, b)          # parameter objects (for direct gradient accumulation)
         return y
@@ -357,7 +384,7 @@ class ConvFn(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(ctx.xshape, device=dy.device, dtype=torch.float32)
-            conv_dgrad_into(ctx.kind, dy, w, dx)
+            conv_dgrad_into(ctx.kind, dy, w, dx, ctx.bn_in)
         if ctx.needs_input_grad[1]:
             pw, pb = ctx.params
             gw, gb = _grad_buf(pw), _grad_buf(pb)
@@ -365,7 +392,7 @@ class ConvFn(Function):
                 conv_wgrad(ctx.kind, x, dy, w, ctx.needs_input_grad[2], gw, gb)
             else:
                 dw, db = conv_wgrad(ctx.kind, x, dy, w, ctx.needs_input_grad[2])
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class UpCatFn(Function):
@@ -426,7 +453,7 @@ class BnActFn(Function):
     num_batches_tracked in place exactly like nn.BatchNorm2d(momentum=0.1)."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, running_mean, running_var, nbt, res, training, slope, stats=None):
+    def forward(ctx, z, gamma, beta, running_mean, running_var, nbt, res, training, slope, stats=None, link=None):
         need_gpu(z, gamma)
         bb, h, wd, c, zld = _geom(z)
         p = bb * h * wd
@@ -445,6 +472,10 @@ class BnActFn(Function):
         call('rv_bn_lrelu_fwd', ptr(z), zld, p, c, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(nbt),
              BN_MOMENTUM, BN_EPS, mode, slope, ptr(res), rld, ptr(y), c, ptr(coef), ptr(ws[0]), 1 if ready else 0, stream())
         ctx.ws = ws
+        ctx.link = None
+        if link is not None and training and ws[1] is not None and res is None:
+            link.z, link.coef, link.ws, link.slope, link.ready = z, coef, ws[1], slope, False
+            ctx.link = link
         ctx.training = training
         ctx.slope = slope
         ctx.params = (gamma, beta)
@@ -467,13 +498,16 @@ class BnActFn(Function):
         else:
             dg = torch.empty(c, device=z.device, dtype=torch.float32) if need_w else None
             db = torch.empty(c, device=z.device, dtype=torch.float32) if need_w else None
+        ready = ctx.link is not None and ctx.link.ready      # the consumer conv's dgrad already reduced (dy, z)
         call('rv_bn_lrelu_bwd', ptr(dy), c, ptr(z), zld, p, c, ptr(coef), ctx.slope, 0 if ctx.training else 1,
              ptr(dz), c, ptr(dg), ptr(db), 1 if direct else 0,
-             ptr(ctx.ws[1] if ctx.ws[1] is not None else ARENA.take(2 * c, z.device)), stream())
+             ptr(ctx.ws[1] if ctx.ws[1] is not None else ARENA.take(2 * c, z.device)), 1 if ready else 0, stream())
+        if ctx.link is not None:
+            ctx.link.z = ctx.link.coef = ctx.link.ws = None   # drop the references
         if direct:
             dg = db = None
         dres = dy if ctx.needs_input_grad[6] else None
-        return (dz if ctx.needs_input_grad[0] else None), dg, db, None, None, None, dres, None, None, None
+        return (dz if ctx.needs_input_grad[0] else None), dg, db, None, None, None, dres, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------------

@@ -174,6 +174,31 @@ def test_conv_fused_bn_statistics(dev, cin, cout, H, W, algo, monkeypatch):
     assert rel_err(outs[0][1], outs[1][1]) < 1e-5 and rel_err(outs[0][2], outs[1][2]) < 1e-5
 
 
+@pytest.mark.parametrize('c1,c2,H,W,algo', [(16, 16, 12, 37, 0), (24, 16, 9, 57, 0x211), (64, 32, 8, 28, 0x321), (8, 2, 6, 19, 0), (32, 32, 8, 30, 1)])
+def test_conv_dgrad_fused_bn_backward_reduction(dev, c1, c2, H, W, algo, monkeypatch):
+    """conv2(lrelu(bn(z))): with a BnLink the input-gradient kernel of conv2 also produces the BatchNorm's backward
+    reduction (epilogue of the persistent kernel, reduction pass behind the others); gradients must not change."""
+    from reconvat_amd import ops
+    B = 3
+    if algo:
+        monkeypatch.setenv('RV_FORCE_ALGO', hex(algo))
+    z0 = nhwc(rnd(B, c1, H, W, seed=1) * 2 + 0.3).to(dev)
+    g0, b0 = (rnd(c1, seed=2) * 0.2 + 1).to(dev), (rnd(c1, seed=3) * 0.1).to(dev)
+    w0, wb0 = rnd(c2, c1, 3, 3, seed=4, scale=0.2).to(dev), rnd(c2, seed=5).to(dev)
+    cot = nhwc(rnd(B, c2, H, W, seed=6)).to(dev)
+    grads = []
+    for use_link in (True, False):
+        z, g, b, w, wb = [t.clone().requires_grad_(True) for t in (z0, g0, b0, w0, wb0)]
+        rm, rv, nbt = torch.zeros(c1, device=dev), torch.ones(c1, device=dev), torch.zeros((), dtype=torch.long, device=dev)
+        link = ops.BnLink() if use_link else None
+        y = ops.BnActFn.apply(z, g, b, rm, rv, nbt, None, True, 0.01, None, link)
+        o = ops.ConvFn.apply(y, w, wb, 'c3', None, None, link)
+        (o * cot).sum().backward()
+        grads.append([t.grad.clone() for t in (z, g, b, w, wb)])
+    for a, b_ in zip(*grads):
+        assert rel_err(a, b_) < 2e-5
+
+
 @pytest.mark.parametrize('M,K,N,act', [(130, 229, 88, 1), (257, 176, 768, 0), (64, 768, 88, 1), (200, 916, 229, 1), (96, 88, 916, 0)])
 def test_linear(dev, M, K, N, act):
     from reconvat_amd import ops
