@@ -42,7 +42,7 @@ int rv_melspec_lognorm_fwd(const float* audio, long audio_stride, int B, int nsa
  *   (ConvTranspose2d(k=2,s=2)(x, output_size=...) fwd, down dgrad).  Forward AND input-gradient of
  *   every layer are instances of it (the packing decides which).  algo: 0 default, 1 LDS-free direct kernel,
  *   2 LDS/DMA-pipelined kernel (3x3 only) -- the host autotunes 1 vs 2 per layer shape.  bn_sums (nullable,
- *   [2*Cout] fp64, += ): per-channel sum / sum of squares of the written output, i.e. the batch statistics of the
+ *   rv_bn_workspace_bytes(Cout) bytes of fp64 = 8 replicas of [2*Cout] that the consumer adds up, += ): per-channel sum / sum of squares of the written output, i.e. the batch statistics of the
  *   BatchNorm2d that consumes it (conv -> bn call sites, model/UNet_onset.py:196-198,221-223), produced in the conv
  *   epilogue; pass the same buffer to rv_bn_lrelu_fwd as `workspace` with sums_ready = 1.  bn_z (nullable; with
  *   bn_z_ld, bn_coef = that layer's saved [5C] coefficients, bn_slope): the call is an INPUT-GRADIENT whose result is

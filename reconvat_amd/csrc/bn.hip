@@ -34,6 +34,7 @@ struct BnArgs {
     float* coef_out;         // [4C] written by block 0 (saved for backward)
     float momentum, eps;
     int training;
+    int ppt;                 // pixels per thread of the reduction kernels (multiple of 4)
 };
 
 // thread t -> channel quad t % (C/4), pixel lane t / (C/4); 16-byte loads, BN_PIX_PER_THREAD pixels each.
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void bn_reduce_k(BnArgs a) {
     const int c = (t % C4) * 4, pl = t / C4;
     f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (pl < PL) {
-        const long p0 = (long)blockIdx.x * PL * BN_PIX_PER_THREAD;
+        const long p0 = (long)blockIdx.x * PL * a.ppt;
         f32x4 mean, invstd, scale, shift;
         if (BWD) {
             mean = *reinterpret_cast<const f32x4*>(a.coef + c);
@@ -53,24 +54,37 @@ __global__ __launch_bounds__(256) void bn_reduce_k(BnArgs a) {
             scale = *reinterpret_cast<const f32x4*>(a.coef + 2 * C + c);
             shift = *reinterpret_cast<const f32x4*>(a.coef + 3 * C + c);
         }
-#pragma unroll 4
-        for (int k = 0; k < BN_PIX_PER_THREAD; ++k) {
-            const long p = p0 + pl + (long)k * PL;
-            if (p >= a.P) break;
-            const f32x4 z = *reinterpret_cast<const f32x4*>(a.z + p * a.z_ld + c);
-            if (BWD) {
-                const f32x4 d = *reinterpret_cast<const f32x4*>(a.dy + p * a.dy_ld + c);
+        // four pixels per trip: all eight 16-byte loads are issued before the first use (a streaming kernel lives on
+        // bytes in flight); out-of-range pixels load pixel 0 and are masked out of the sums
+        for (int k = 0; k < a.ppt; k += 4) {
+            f32x4 zv[4], dv[4];
+            bool ok[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float zh = fmaf(z[q], scale[q], shift[q]);
-                    float dd = zh > 0.f ? d[q] : d[q] * a.slope;
-                    s0[q] += dd;
-                    s1[q] += dd * ((z[q] - mean[q]) * invstd[q]);
+            for (int u = 0; u < 4; ++u) {
+                const long p = p0 + pl + (long)(k + u) * PL;
+                ok[u] = p < a.P;
+                const long pp = ok[u] ? p : 0;
+                zv[u] = *reinterpret_cast<const f32x4*>(a.z + pp * a.z_ld + c);
+                if (BWD) dv[u] = *reinterpret_cast<const f32x4*>(a.dy + pp * a.dy_ld + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!ok[u]) continue;
+                const f32x4 z = zv[u];
+                if (BWD) {
+                    const f32x4 d = dv[u];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float zh = fmaf(z[q], scale[q], shift[q]);
+                        float dd = zh > 0.f ? d[q] : d[q] * a.slope;
+                        s0[q] += dd;
+                        s1[q] += dd * ((z[q] - mean[q]) * invstd[q]);
+                    }
+                } else {
+                    s0 += z;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) s1[q] = fmaf(z[q], z[q], s1[q]);
                 }
-            } else {
-                s0 += z;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) s1[q] = fmaf(z[q], z[q], s1[q]);
             }
         }
     }
@@ -87,16 +101,16 @@ __global__ __launch_bounds__(256) void bn_reduce_k(BnArgs a) {
         const int ch = t >> 1, which = t & 1;
         double d = 0.0;
         for (int l = 0; l < PL; ++l) d += (double)sh[(l * C + ch) * 2 + which];
-        atomicAdd(&a.sums[which * C + ch], d);
+        atomicAdd(&a.sums[(blockIdx.x % RV_BN_NREP) * 2 * C + which * C + ch], d);
     }
 }
 
 // batch (training) or running (eval) mean / inverse std of channel c -- identical arithmetic in every thread
-__device__ __forceinline__ void bn_coef(const BnArgs& a, int c, float& mean, float& invstd) {
+__device__ __forceinline__ void bn_coef(const BnArgs& a, const double* fold, int c, float& mean, float& invstd) {
     if (a.training) {
         const double n = (double)a.P;
-        const double m = a.sums[c] / n;
-        double var = a.sums[a.C + c] / n - m * m;
+        const double m = fold[c] / n;
+        double var = fold[a.C + c] / n - m * m;
         if (var < 0.0) var = 0.0;
         mean = (float)m;
         invstd = (float)(1.0 / sqrt(var + (double)a.eps));
@@ -117,6 +131,12 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool fixed = (stride % C4) == 0;
     int c = (int)(idx % C4) * 4;
+    // the replicated sums are folded ONCE per workgroup (2C threads x 8 loads), not once per thread
+    __shared__ double fold[256];
+    if (BWD ? !a.frozen || a.dgamma : a.training) {
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) fold[i] = bn_sum_replicas(a.sums, C, i);
+        __syncthreads();
+    }
     f32x4 mean, invstd, scale, shift, k1, k2;
     auto fetch = [&](int cc) {
         if (BWD) {
@@ -127,20 +147,73 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
             const double invn = 1.0 / (double)a.P;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                k1[q] = a.frozen ? 0.f : (float)(a.sums[cc + q] * invn);
-                k2[q] = a.frozen ? 0.f : (float)(a.sums[C + cc + q] * invn);
+                k1[q] = a.frozen ? 0.f : (float)(fold[cc + q] * invn);
+                k2[q] = a.frozen ? 0.f : (float)(fold[C + cc + q] * invn);
             }
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float m_, is_;
-                bn_coef(a, cc + q, m_, is_);
+                bn_coef(a, fold, cc + q, m_, is_);
                 scale[q] = a.gamma[cc + q] * is_;
                 shift[q] = a.beta[cc + q] - m_ * scale[q];
             }
         }
     };
     fetch(c);
+    auto one = [&](const f32x4& z, const f32x4& d, const f32x4& r) -> f32x4 {
+        f32x4 o;
+        if (!BWD) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float zh = fmaf(z[q], scale[q], shift[q]);
+                o[q] = (zh > 0.f ? zh : zh * a.slope) + r[q];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float zh = fmaf(z[q], scale[q], shift[q]);
+                float dz = zh > 0.f ? d[q] : d[q] * a.slope;
+                float xh = (z[q] - mean[q]) * invstd[q];
+                dz = dz - k1[q] - xh * k2[q];
+                o[q] = dz * scale[q];
+            }
+        }
+        return o;
+    };
+    if (fixed) {
+        // the thread keeps its channel quad: pixels p0, p0 + pstep, ... ; four pixels per trip, every load of the trip
+        // issued before the first use, no division in the loop
+        const long pstep = stride / C4;
+        long p = idx / C4;
+        for (; p < a.P; p += 4 * pstep) {
+            f32x4 zv[4], dv[4], rv[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long pu = p + u * pstep;
+                ok[u] = pu < a.P;
+                const long pp = ok[u] ? pu : 0;
+                zv[u] = *reinterpret_cast<const f32x4*>(a.z + pp * a.z_ld + c);
+                if (BWD) dv[u] = *reinterpret_cast<const f32x4*>(a.dy + pp * a.dy_ld + c);
+                else dv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                rv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (!BWD && a.res) rv[u] = *reinterpret_cast<const f32x4*>(a.res + pp * a.res_ld + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!ok[u]) continue;
+                f32x4 o = one(zv[u], dv[u], rv[u]);
+                float* dst = a.out + (p + u * pstep) * a.out_ld + c;
+                if (a.accumulate) {
+                    f32x4 old = *reinterpret_cast<f32x4*>(dst);
+                    o += old;
+                }
+                *reinterpret_cast<f32x4*>(dst) = o;
+            }
+        }
+        idx = total;                              // skip the generic loop below
+    }
     for (; idx < total; idx += stride) {
         const long p = idx / C4;
         if (!fixed) { c = (int)(idx - p * C4) * 4; fetch(c); }
@@ -176,14 +249,14 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
         for (int cc = threadIdx.x; cc < a.C; cc += blockDim.x) {
             if (BWD) {
                 if (a.dgamma) {
-                    const float dg = (float)a.sums[a.C + cc], db = (float)a.sums[cc];
+                    const float dg = (float)fold[a.C + cc], db = (float)fold[cc];
                     a.dgamma[cc] = a.param_accumulate ? a.dgamma[cc] + dg : dg;
                     a.dbeta[cc] = a.param_accumulate ? a.dbeta[cc] + db : db;
                 }
             } else {
                 // finalize: coefficients for the backward pass, running statistics, num_batches_tracked
                 float m_, is_;
-                bn_coef(a, cc, m_, is_);
+                bn_coef(a, fold, cc, m_, is_);
                 const float sc = a.gamma[cc] * is_;
                 a.coef_out[cc] = m_;
                 a.coef_out[a.C + cc] = is_;
@@ -191,8 +264,8 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
                 a.coef_out[3 * a.C + cc] = a.beta[cc] - m_ * sc;
                 if (a.training) {
                     const double n = (double)a.P;
-                    const double mm = a.sums[cc] / n;
-                    double var = a.sums[a.C + cc] / n - mm * mm;
+                    const double mm = fold[cc] / n;
+                    double var = fold[a.C + cc] / n - mm * mm;
                     if (var < 0.0) var = 0.0;
                     const float unb = (float)(n > 1.0 ? var * n / (n - 1.0) : var);
                     a.coef_out[4 * a.C + cc] = unb;            // kept for a deferred running-stat update
@@ -214,12 +287,24 @@ static int bn_apply_blocks(long total) {
     return (int)b;
 }
 
+// Pixels per thread of a reduction launch.  Every workgroup ends with 2C fp64 atomics on the SAME 2C addresses, and those
+// serialise at the memory side (~25 ns each, measured: 1 100 workgroups cost ~30 us of pure atomic tail on a 75 MB
+// tensor), so the grid is sized to ~512 workgroups (two per CU keep enough loads in flight) instead of one per 16 pixels.
+static int bn_ppt(long P, int PL) {
+    long ppt = P / ((long)PL * 512);
+    ppt = (ppt + 3) & ~3L;
+    if (ppt < BN_PIX_PER_THREAD) ppt = BN_PIX_PER_THREAD;
+    if (ppt > 256) ppt = 256;
+    return (int)ppt;
+}
+
 int rv_internal_bn_stats(const float* z, int z_ld, long P, int C, double* sums, hipStream_t st) {
     RV_CHECK_ARG(C % 4 == 0 && C <= 128 && (z_ld % 4) == 0, "bn statistics: C=%d must be a multiple of 4 and <= 128", C);
     BnArgs a = {};
     a.z = z; a.z_ld = z_ld; a.P = P; a.C = C; a.sums = sums;
     const int PL = 256 / (C / 4);
-    hipLaunchKernelGGL(bn_reduce_k<false>, dim3(cdiv(P, (long)PL * BN_PIX_PER_THREAD)), dim3(256), 0, st, a);
+    a.ppt = bn_ppt(P, PL);
+    hipLaunchKernelGGL(bn_reduce_k<false>, dim3(cdiv(P, (long)PL * a.ppt)), dim3(256), 0, st, a);
     RV_LAUNCH_CHECK("bn statistics");
     return RV_OK;
 }
@@ -230,17 +315,18 @@ int rv_internal_bn_bwd_stats(const float* dy, int dy_ld, const float* z, int z_l
     BnArgs a = {};
     a.z = z; a.z_ld = z_ld; a.dy = dy; a.dy_ld = dy_ld; a.P = P; a.C = C; a.sums = sums; a.coef = coef; a.slope = slope;
     const int PL = 256 / (C / 4);
-    hipLaunchKernelGGL(bn_reduce_k<true>, dim3(cdiv(P, (long)PL * BN_PIX_PER_THREAD)), dim3(256), 0, st, a);
+    a.ppt = bn_ppt(P, PL);
+    hipLaunchKernelGGL(bn_reduce_k<true>, dim3(cdiv(P, (long)PL * a.ppt)), dim3(256), 0, st, a);
     RV_LAUNCH_CHECK("bn backward statistics");
     return RV_OK;
 }
 
 extern "C" {
 
-// Bytes of workspace the BN entry points need: 2*C fp64 sums.  CONTRACT: the workspace must be ALL-ZERO on entry (the
+// Bytes of workspace the BN entry points need: RV_BN_NREP replicas of 2*C fp64 sums (common.h).  CONTRACT: the workspace must be ALL-ZERO on entry (the
 // host hands out slices of one arena that is cleared once per step -- a per-call memset costs a launch, and a
 // last-workgroup self-clean costs ~4 ns of serialized atomics per workgroup); it holds the sums on exit.
-long rv_bn_workspace_bytes(int C) { return (long)(2 * C) * 8; }
+long rv_bn_workspace_bytes(int C) { return (long)RV_BN_NREP * (2 * C) * 8; }
 
 // coef: [5C] floats (mean, invstd, scale, shift, unbiased batch variance) -- saved for backward.
 // training == 1: batch statistics, running stats / num_batches_tracked updated in place;

@@ -90,7 +90,18 @@ __device__ __forceinline__ void glds4(const float* g, float* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 
-// bn.hip: sums[0..C) += sum_p z[p][c], sums[C..2C) += sum_p z[p][c]^2 (fp64) -- the BatchNorm2d batch statistics pass,
+// BatchNorm reduction workspace: RV_BN_NREP replicas of [2C] fp64 sums.  A producer workgroup adds into replica
+// (blockIdx.x % RV_BN_NREP); consumers add the replicas up.  Same-address fp64 atomics serialise at ~23 ns each at the
+// memory side, so spreading the producers over 8 copies cuts the atomic tail of every producer kernel by 8.
+#define RV_BN_NREP 8
+__device__ __forceinline__ double bn_sum_replicas(const double* sums, int C, int idx) {
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < RV_BN_NREP; ++r) s += sums[r * 2 * C + idx];
+    return s;
+}
+
+// bn.hip: (replicated, see above) sums[0..C) += sum_p z[p][c], sums[C..2C) += sum_p z[p][c]^2 (fp64) -- the BatchNorm2d batch statistics pass,
 // also used by rv_conv_fwd behind the conv kernels that do not produce the statistics in their epilogue.
 int rv_internal_bn_stats(const float* z, int z_ld, long P, int C, double* sums, hipStream_t st);
 // ... and the backward reduction: sums += (sum dd, sum dd * xhat), dd = dy * lrelu'(z*scale+shift); coef = [mean|invstd|scale|shift|..]

@@ -637,7 +637,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
             const int cl = t >> 1, which = t & 1, ch = nt0 * 16 + cl;
             double dsum = 0.0;
             for (int w = 0; w < NW; ++w) dsum += (double)red[((w * NT) * 16 + cl) * 2 + which];
-            if (ch < a.Cout) atomicAdd(&a.bn_sums[which * a.Cout + ch], dsum);
+            if (ch < a.Cout) atomicAdd(&a.bn_sums[(blockIdx.x % RV_BN_NREP) * 2 * a.Cout + which * a.Cout + ch], dsum);
         }
     }
 }
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(256) void conv_small_k(SmallArgs a) {
                 const int quad = ch / CPT, co = ch - quad * CPT;
                 double d = 0.0;
                 for (int k = quad; k < 256; k += TPP) d += (double)red[(k * CPT + co) * 2 + which];
-                atomicAdd(&a.bn_sums[which * COUT + ch], d);
+                atomicAdd(&a.bn_sums[(blockIdx.x % RV_BN_NREP) * 2 * COUT + which * COUT + ch], d);
             }
         }
     }
@@ -1182,7 +1182,9 @@ static int launch_conv3x3_lds_r(const ConvArgs& a, int NT, int MTW, int TH, int 
         auto kern = conv3x3_lds_k<R, nt, mt, NW>;                                                 \
         static bool attr_done = false;                                                            \
         if (!attr_done) {                                                                         \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            /* the kernel also has 1 KiB of static LDS: dynamic + static must stay within the 160 KiB of a CU */ \
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) \
+                (void)hipGetLastError();                                                          \
             attr_done = true;                                                                     \
         }                                                                                         \
         hipLaunchKernelGGL(kern, grid, blk, lds, st, aa);                                         \

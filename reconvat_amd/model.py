@@ -39,7 +39,7 @@ def _conv_bn(conv, bn, x, kind, res, detach, bn_in=None, link=None):
     zeroed fp64 slice (fused epilogue) and the BatchNorm skips its own statistics pass.  ``link`` (a fresh
     ops.BnLink) is handed to the ONE conv that consumes the result as ``bn_in``: that conv's input-gradient kernel
     then also produces this BatchNorm's backward reduction."""
-    stats = ARENA.take(2 * bn.num_features, x.device) if bn.training else None
+    stats = ARENA.take(ops.bn_ws_doubles(bn.num_features), x.device) if bn.training else None
     z = ConvFn.apply(x, _p(conv.weight, detach), _p(conv.bias, detach), kind, None, stats, bn_in)
     return BnActFn.apply(z, _p(bn.weight, detach), _p(bn.bias, detach), bn.running_mean, bn.running_var,
                          bn.num_batches_tracked, res, bn.training, SLOPE, stats, link)

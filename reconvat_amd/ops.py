@@ -32,7 +32,7 @@ class ZeroArena:
         self.off = 0
         self.armed = False
 
-    def begin_step(self, device, nbytes=4 << 20):
+    def begin_step(self, device, nbytes=8 << 20):
         if self.buf is None or self.buf.device != device or self.buf.numel() * 8 < nbytes:
             self.buf = torch.zeros(nbytes // 8, device=device, dtype=torch.float64)
         else:
@@ -52,6 +52,11 @@ class ZeroArena:
 
 
 ARENA = ZeroArena()
+
+
+def bn_ws_doubles(c):
+    """fp64 elements of one BatchNorm reduction workspace (rv_bn_workspace_bytes: replicated [2C] sums)."""
+    return _lib.load().rv_bn_workspace_bytes(c) // 8
 
 _BN_DEFER = [None]
 
@@ -466,8 +471,8 @@ class BnActFn(Function):
         # zero-initialised fp64 sums: one slice for the forward statistics, one for the backward reduction
         # (``stats``: the producing conv already left the forward sums in its slice -- bn_stats_slot / ConvFn)
         ready = training and stats is not None
-        ws = (stats if ready else ARENA.take(2 * c, z.device),
-              ARENA.take(2 * c, z.device) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None)
+        ws = (stats if ready else ARENA.take(bn_ws_doubles(c), z.device),
+              ARENA.take(bn_ws_doubles(c), z.device) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None)
         rld = _geom(res)[4] if res is not None else 0
         call('rv_bn_lrelu_fwd', ptr(z), zld, p, c, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(nbt),
              BN_MOMENTUM, BN_EPS, mode, slope, ptr(res), rld, ptr(y), c, ptr(coef), ptr(ws[0]), 1 if ready else 0, stream())
@@ -501,7 +506,7 @@ class BnActFn(Function):
         ready = ctx.link is not None and ctx.link.ready      # the consumer conv's dgrad already reduced (dy, z)
         call('rv_bn_lrelu_bwd', ptr(dy), c, ptr(z), zld, p, c, ptr(coef), ctx.slope, 0 if ctx.training else 1,
              ptr(dz), c, ptr(dg), ptr(db), 1 if direct else 0,
-             ptr(ctx.ws[1] if ctx.ws[1] is not None else ARENA.take(2 * c, z.device)), 1 if ready else 0, stream())
+             ptr(ctx.ws[1] if ctx.ws[1] is not None else ARENA.take(bn_ws_doubles(c), z.device)), 1 if ready else 0, stream())
         if ctx.link is not None:
             ctx.link.z = ctx.link.coef = ctx.link.ws = None   # drop the references
         if direct:

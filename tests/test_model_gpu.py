@@ -61,7 +61,7 @@ def test_unet_fwd_bwd_golden(dev):
     gmax = max(float(p.grad.abs().max()) for p in named.values() if p.grad is not None)
     for k in g.files:
         if k.startswith('g:'):
-            close_digest(named[k[2:]].grad, g[k], 2e-3, floor=2e-5 * gmax)
+            close_digest(named[k[2:]].grad, g[k], 3e-3, floor=2e-5 * gmax)
         elif k.startswith('s:'):
             assert rel_err(sd[k[2:]], torch.from_numpy(g[k])) < 1e-4, k
     assert int(sd['transcriber.Unet1_encoder.block1.bn1.num_batches_tracked']) == 1

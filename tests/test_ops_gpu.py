@@ -147,6 +147,26 @@ def test_bn_lrelu(dev, C, training, with_res):
     assert int(nbt.item()) == (1 if training else 0)
 
 
+@pytest.mark.autotune
+@pytest.mark.parametrize('cin,cout,H,W', [(16, 16, 40, 229), (64, 32, 20, 57)])
+def test_conv_autotuner(dev, cin, cout, H, W):
+    """The tuner times every legal tile of both 3x3 kernels and caches a winner; whatever it picks must agree with the
+    library default to fp32 rounding, with and without the fused BatchNorm statistics."""
+    from reconvat_amd import ops
+    x = nhwc(rnd(2, cin, H, W, seed=1)).to(dev)
+    w, b = rnd(cout, cin, 3, 3, seed=2, scale=0.2).to(dev), rnd(cout, seed=3).to(dev)
+    assert ops.AUTOTUNE
+    stats = torch.zeros(ops.bn_ws_doubles(cout), dtype=torch.float64, device=dev)
+    y_tuned = ops.ConvFn.apply(x, w, b, 'c3', None)
+    y_tuned2 = ops.ConvFn.apply(x, w, b, 'c3', None, stats)
+    assert any(k[:5] == (2, H, W, cin, cout) for k in ops._algo_cache)
+    ops.AUTOTUNE = False
+    y_def = ops.ConvFn.apply(x, w, b, 'c3', None)
+    assert rel_err(y_tuned, y_def) < 1e-5 and rel_err(y_tuned2, y_def) < 1e-5
+    zd = y_tuned2.double().reshape(-1, cout)
+    assert rel_err(stats.view(-1, 2 * cout).sum(0), torch.cat([zd.sum(0), (zd * zd).sum(0)])) < 1e-6
+
+
 @pytest.mark.parametrize('cin,cout,H,W,algo', [(16, 16, 21, 37, 0), (32, 24, 9, 57, 0x221), (64, 128, 12, 28, 0x321), (16, 8, 10, 19, 0),
                                                (32, 32, 8, 30, 1), (1, 16, 9, 31, 0), (48, 24, 7, 114, 0x412)])
 def test_conv_fused_bn_statistics(dev, cin, cout, H, W, algo, monkeypatch):
@@ -158,13 +178,13 @@ def test_conv_fused_bn_statistics(dev, cin, cout, H, W, algo, monkeypatch):
     w, b = rnd(cout, cin, 3, 3, seed=2, scale=0.2).to(dev), rnd(cout, seed=3).to(dev)
     if algo:
         monkeypatch.setenv('RV_FORCE_ALGO', hex(algo))
-    stats = torch.zeros(2 * cout, dtype=torch.float64, device=dev)
+    stats = torch.zeros(ops.bn_ws_doubles(cout), dtype=torch.float64, device=dev)
     z = ops.ConvFn.apply(x, w, b, 'c3', None, stats)
     z0 = ops.ConvFn.apply(x, w, b, 'c3', None)
     assert torch.equal(z, z0)
     zd = z.double().reshape(-1, cout)
     want = torch.cat([zd.sum(0), (zd * zd).sum(0)])
-    assert rel_err(stats, want) < 1e-6
+    assert rel_err(stats.view(-1, 2 * cout).sum(0), want) < 1e-6
     gamma, beta = (rnd(cout, seed=4) * 0.2 + 1).to(dev), (rnd(cout, seed=5) * 0.1).to(dev)
     outs = []
     for st in (stats, None):
