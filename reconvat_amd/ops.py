@@ -249,8 +249,8 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
     algo = 0
     if mode == 0 and os.environ.get('RV_FORCE_ALGO'):      # kernel experiments (tools/bench_conv.py)
         algo = int(os.environ['RV_FORCE_ALGO'], 0)
-    elif mode == 0 and AUTOTUNE:
-        key = (bb, h, wd, cin, cout, ild, old, stats is not None, bnbwd is not None)
+    elif AUTOTUNE and cin % 8 == 0 and (cout > 2 or mode == 3):     # (the small-channel VALU kernels have one form)
+        key = (mode, bb, h, wd, cin, cout, ild, old, stats is not None, bnbwd is not None)
         algo = _algo_cache.get(key, -1)
         if algo < 0:
             if torch.cuda.is_current_stream_capturing():
@@ -259,16 +259,17 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
                 best, algo = None, 0
                 st = torch.cuda.current_stream()
                 lib = _lib.load()
-                ntile_n = (cout + 15) // 16
+                ntile_n = (4 * cout if mode == 3 else cout + 15) // 16
                 scratch = ptr(torch.zeros_like(stats)) if stats is not None else None
-                cands = [1, 2]
+                cands = [1, 2] if mode == 0 else [0]
                 for nt in (1, 2, 3, 4):
                     if ntile_n % nt:
                         continue
-                    cands += [0x100 | nt << 4 | mt for mt in (1, 2, 4)]
-                    cands += [0x200 | nt << 4 | mt for mt in (1, 2, 4, 8)]
-                    cands += [0x300 | nt << 4 | mt for mt in (1, 2, 4)]
-                    cands += [0x400 | nt << 4 | mt for mt in (1, 2, 4)]
+                    cands += [0x100 | nt << 4 | mt for mt in (1, 2, 4)]     # direct kernel (every mode)
+                    if mode == 0:                                           # persistent LDS kernel, 4 / 8 / 16 waves
+                        cands += [0x200 | nt << 4 | mt for mt in (1, 2, 4, 8)]
+                        cands += [0x300 | nt << 4 | mt for mt in (1, 2, 4)]
+                        cands += [0x400 | nt << 4 | mt for mt in (1, 2, 4)]
                 for cand in cands:
                     if lib.rv_conv_fwd(*args, cand, scratch, *tail, st.cuda_stream) != 0:
                         continue                                   # tile does not fit this shape

@@ -159,7 +159,7 @@ def test_conv_autotuner(dev, cin, cout, H, W):
     stats = torch.zeros(ops.bn_ws_doubles(cout), dtype=torch.float64, device=dev)
     y_tuned = ops.ConvFn.apply(x, w, b, 'c3', None)
     y_tuned2 = ops.ConvFn.apply(x, w, b, 'c3', None, stats)
-    assert any(k[:5] == (2, H, W, cin, cout) for k in ops._algo_cache)
+    assert any(k[:6] == (0, 2, H, W, cin, cout) for k in ops._algo_cache)
     ops.AUTOTUNE = False
     y_def = ops.ConvFn.apply(x, w, b, 'c3', None)
     assert rel_err(y_tuned, y_def) < 1e-5 and rel_err(y_tuned2, y_def) < 1e-5
