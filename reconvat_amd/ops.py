@@ -247,7 +247,7 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
     else:
         tail = (None, 0, None, 0.0)
     algo = 0
-    if mode == 0 and os.environ.get('RV_FORCE_ALGO'):      # kernel experiments (tools/bench_conv.py)
+    if os.environ.get('RV_FORCE_ALGO') and (mode == 0 or os.environ.get('RV_FORCE_ALGO_ALL')):   # kernel experiments
         algo = int(os.environ['RV_FORCE_ALGO'], 0)
     elif AUTOTUNE and cin % 8 == 0 and (cout > 2 or mode == 3):     # (the small-channel VALU kernels have one form)
         key = (mode, bb, h, wd, cin, cout, ild, old, stats is not None, bnbwd is not None)
@@ -729,7 +729,7 @@ class LocalAttnFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x2)
             if fused:
-                gemm(dqkv, torch.as_strided(wk, (3 * f, fin), (fin, 1)), dx)
+                gemm(dqkv, torch.as_strided(wk, (3 * f, fin), (fin, 1)), dx, splitk=_splitk_for(m, fin, 3 * f))
             else:
                 gemm(dq, wq, dx)
                 gemm(dk, wk, dx, accumulate=True)
