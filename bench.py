@@ -227,9 +227,17 @@ def main():
             if args.verbose:
                 for t, c, m_, tf, sg in per_kernel:
                     print(f'[conv] {t:8.3f} ms/step  x{c:3d}  {m_:8.4f} ms  {tf:7.1f} TF/s  {sg}', file=sys.stderr)
+            # HBM bytes of the same launches from the committed PMC passes (rocprofv3 cannot run inside this process):
+            # tools/pmc_traffic.py over separate FETCH_SIZE / WRITE_SIZE runs of `bench.py --no-graph`, gfx950-corrected
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+            if os.path.exists(tpath):
+                with open(tpath) as fh:
+                    traffic = json.load(fh).get('traffic_bytes')
             line['roofline'] = {
                 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+                'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,
+                'traffic_scope': 'HBM bytes (FETCH_SIZE x2 + WRITE_SIZE) of all conv launches of one step, profiles/r01_pmc_traffic.json',
                 'kernel': 'conv_mfma_k / wgrad_mfma_k family (all conv launches of one step)',
                 'launches_per_step': nlaunch, 'conv_ms_per_step': round(conv_ms, 3),
                 'executed_gflop_per_step': round(conv_flops_total / 1e9, 1),
