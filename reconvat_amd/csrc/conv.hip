@@ -661,9 +661,15 @@ struct SmallArgs {
 // contiguous 16-byte pieces; the thread's KH*KW*CIN*4 weights and its bias stay in registers while it
 // walks pixels with a grid stride (the stride is a multiple of COUT/4, so its channel quad never changes).
 // COUT < 4: one thread per pixel, weights through the scalar cache.
+// output channels per thread: all of them when the input is 1-2 channels wide (the thread's few input taps are then
+// loaded once instead of once per channel quad), else a quad
+__host__ __device__ constexpr int small_cpt(int cin, int cout, int taps) {
+    return cout < 4 ? cout : ((cin <= 2 && taps > 1) ? cout : 4);
+}
+
 template <int CIN, int COUT, int KH, int KW, int S, int P>
 __global__ __launch_bounds__(256) void conv_small_k(SmallArgs a) {
-    constexpr int CPT = COUT >= 4 ? 4 : COUT;        // output channels per thread
+    constexpr int CPT = small_cpt(CIN, COUT, KH * KW);   // output channels per thread
     constexpr int TPP = COUT / CPT;                  // threads per pixel
     constexpr bool WREG = (TPP > 1) && (KH * KW * CIN * CPT <= 80);
     const unsigned tstride = gridDim.x * blockDim.x;
@@ -725,8 +731,33 @@ __global__ __launch_bounds__(256) void conv_small_k(SmallArgs a) {
 #pragma unroll
             for (int co = 0; co < CPT; ++co) acc[co] += o[co];
         }
-        if (CPT == 4 && (a.out_ld & 3) == 0) {
-            *reinterpret_cast<f32x4*>(o) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+        if constexpr (TPP == 1 && CPT % 4 == 0) {
+            // the wave's 64 pixels are contiguous in memory: transpose through LDS so that every store instruction
+            // writes 1 KiB contiguous instead of 64 scattered 16-byte pieces
+            __shared__ __attribute__((aligned(16))) float tr[4][64 * CPT];
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            const unsigned pw = p - lane;                       // first pixel of the wave
+            const bool whole = a.out_ld == COUT && pw + 64 <= (unsigned)a.npix;   // wave-uniform
+            if (whole) {
+#pragma unroll
+                for (int co = 0; co < CPT; co += 4)
+                    *reinterpret_cast<f32x4*>(&tr[wave][lane * CPT + co]) = (f32x4){acc[co], acc[co + 1], acc[co + 2], acc[co + 3]};
+                float* ob = a.out + (long)pw * COUT;
+#pragma unroll
+                for (int k = 0; k < CPT / 4; ++k)
+                    *reinterpret_cast<f32x4*>(ob + k * 256 + lane * 4) = *reinterpret_cast<const f32x4*>(&tr[wave][k * 256 + lane * 4]);
+            } else if ((a.out_ld & 3) == 0) {
+#pragma unroll
+                for (int co = 0; co < CPT; co += 4)
+                    *reinterpret_cast<f32x4*>(o + co) = (f32x4){acc[co], acc[co + 1], acc[co + 2], acc[co + 3]};
+            } else {
+#pragma unroll
+                for (int co = 0; co < CPT; ++co) o[co] = acc[co];
+            }
+        } else if (CPT % 4 == 0 && (a.out_ld & 3) == 0) {
+#pragma unroll
+            for (int co = 0; co < CPT; co += 4)
+                *reinterpret_cast<f32x4*>(o + co) = (f32x4){acc[co], acc[co + 1], acc[co + 2], acc[co + 3]};
         } else {
 #pragma unroll
             for (int co = 0; co < CPT; ++co) o[co] = acc[co];
@@ -734,22 +765,35 @@ __global__ __launch_bounds__(256) void conv_small_k(SmallArgs a) {
 #pragma unroll
         for (int co = 0; co < CPT; ++co) { st1[co] += acc[co]; st2[co] = fmaf(acc[co], acc[co], st2[co]); }
     }
-    if constexpr (TPP > 1) {
-        // fused BatchNorm statistics: threads with the same channel quad (tid % TPP) fold through LDS, then one fp64
-        // atomic per channel and workgroup (the host caps the grid when statistics are requested)
+    if constexpr (COUT >= 4) {
+        // fused BatchNorm statistics: fold over the threads that own the same channels (wave shuffles when a thread owns
+        // all channels, LDS otherwise), then one fp64 atomic per channel and workgroup (the host caps the grid)
         if (a.bn_sums) {
-            __shared__ float red[256 * 2 * CPT];
+            __shared__ float red[TPP > 1 ? 256 * 2 * CPT : 4 * 2 * COUT];
+            if constexpr (TPP > 1) {
 #pragma unroll
-            for (int co = 0; co < CPT; ++co) {
-                red[(threadIdx.x * CPT + co) * 2] = st1[co];
-                red[(threadIdx.x * CPT + co) * 2 + 1] = st2[co];
+                for (int co = 0; co < CPT; ++co) {
+                    red[(threadIdx.x * CPT + co) * 2] = st1[co];
+                    red[(threadIdx.x * CPT + co) * 2 + 1] = st2[co];
+                }
+            } else {
+                const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+                for (int co = 0; co < CPT; ++co) {
+                    const float u = wave_sum(st1[co]), q = wave_sum(st2[co]);
+                    if (lane == 0) { red[(wave * COUT + co) * 2] = u; red[(wave * COUT + co) * 2 + 1] = q; }
+                }
             }
             __syncthreads();
             if (threadIdx.x < COUT * 2) {
                 const int ch = threadIdx.x >> 1, which = threadIdx.x & 1;
-                const int quad = ch / CPT, co = ch - quad * CPT;
                 double d = 0.0;
-                for (int k = quad; k < 256; k += TPP) d += (double)red[(k * CPT + co) * 2 + which];
+                if constexpr (TPP > 1) {
+                    const int quad = ch / CPT, co = ch - quad * CPT;
+                    for (int k = quad; k < 256; k += TPP) d += (double)red[(k * CPT + co) * 2 + which];
+                } else {
+                    for (int w = 0; w < 4; ++w) d += (double)red[(w * COUT + ch) * 2 + which];
+                }
                 atomicAdd(&a.bn_sums[(blockIdx.x % RV_BN_NREP) * 2 * COUT + which * COUT + ch], d);
             }
         }
@@ -1382,9 +1426,9 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
         s.in = in; s.in_ld = in_ld; s.H = H; s.W = W; s.out = out; s.out_ld = out_ld; s.Ho = Ho; s.Wo = Wo;
         s.B = B; s.wplain = wpack; s.bias = bias; s.npix = (long)B * Ho * Wo; s.accumulate = accumulate;
         s.fd_plane = fastdiv_make((unsigned)(Ho * Wo)); s.fd_wo = fastdiv_make((unsigned)Wo);
-        const int tpp = Cout >= 4 ? Cout / 4 : 1;
+        const int tpp = Cout / small_cpt(Cin, Cout, mode == 0 ? 9 : 1);
         RV_CHECK_ARG(s.npix * tpp < (1L << 31), "rv_conv_fwd: more than 2^31 outputs");
-        s.bn_sums = (tpp > 1 && !bn.z) ? bn_sums : nullptr;
+        s.bn_sums = (Cout >= 4 && !bn.z) ? bn_sums : nullptr;
         if (s.bn_sums) *sums_done = true;
         long nblk = cdiv(s.npix * tpp, 256);
         const long cap = s.bn_sums ? 1024 : 4096;   // grid stride (a multiple of every COUT/4); fewer workgroups = fewer atomics
