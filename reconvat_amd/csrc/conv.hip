@@ -1016,85 +1016,102 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
     }
 }
 
-// VALU version for tiny channel counts (Ca*Cb*taps <= 144)
+// VALU version for tiny channel counts (Ca*Cb*taps <= 144).  One wave = one partial.  The wider channel dimension is
+// split into quads across neighbouring lanes (LPP lanes per pixel), so a lane carries 36-72 accumulators instead of 144:
+// several waves fit on a SIMD and hide the load latency, the dY row is read with coalesced 16-byte loads, and the final
+// fold is a few xor-shuffles over the pixel slots.
 template <int CA, int CB, int KH, int KW, int S, int P>
 __global__ __launch_bounds__(256) void wgrad_small_k(WgradArgs a) {
     constexpr int TAPS = KH * KW;
+    constexpr bool SPLIT_B = CB >= CA;                       // which channel dimension is spread over lanes
+    constexpr int CS = SPLIT_B ? CB : CA;
+    constexpr int Q = CS >= 4 ? 4 : CS;                      // channels of the split dimension per lane
+    constexpr int LPP = CS / Q;                              // lanes per pixel (1, 2 or 4)
+    constexpr int PPW = 64 / LPP;                            // pixels per wave trip
+    constexpr int CAL = SPLIT_B ? CA : Q, CBL = SPLIT_B ? Q : CB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ps = lane / LPP, cq = lane - ps * LPP;
+    const int a_off = SPLIT_B ? 0 : cq * Q, b_off = SPLIT_B ? cq * Q : 0;
     const int pw = blockIdx.x * 4 + wave;
     if (pw >= a.nparts) return;
-    float acc[TAPS][CA][CB];
-    float accb[CB];
+    float acc[TAPS][CAL][CBL];
+    float accb[CBL];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-        for (int x = 0; x < CA; ++x)
+        for (int x = 0; x < CAL; ++x)
 #pragma unroll
-            for (int y = 0; y < CB; ++y) acc[t][x][y] = 0.f;
+            for (int y = 0; y < CBL; ++y) acc[t][x][y] = 0.f;
 #pragma unroll
-    for (int y = 0; y < CB; ++y) accb[y] = 0.f;
+    for (int y = 0; y < CBL; ++y) accb[y] = 0.f;
     const unsigned npix = (unsigned)(a.B * a.Hv * a.Wv);
     const unsigned per = (npix + a.nparts - 1) / a.nparts;
     const unsigned p0 = (unsigned)pw * per, p1 = min(p0 + per, npix);
-    const bool vvec = (CB % 4 == 0) && (a.v_ld % 4 == 0) && ((((uintptr_t)a.V) & 15) == 0);
-    const bool uvec = (CA % 4 == 0) && (a.u_ld % 4 == 0) && ((((uintptr_t)a.U) & 15) == 0);
-    for (unsigned p = p0 + lane; p < p1; p += 64) {
+    const bool vvec = (CBL % 4 == 0) && (a.v_ld % 4 == 0) && ((((uintptr_t)a.V) & 15) == 0);
+    const bool uvec = (CAL % 4 == 0) && (a.u_ld % 4 == 0) && ((((uintptr_t)a.U) & 15) == 0);
+    for (unsigned p = p0 + ps; p < p1; p += PPW) {
         const int b = (int)fastdiv(p, a.fd_vplane);
         const unsigned rem = p - (unsigned)b * (unsigned)(a.Hv * a.Wv);
         const int y = (int)fastdiv(rem, a.fd_wv), x = (int)rem - y * a.Wv;
-        float v[CB];
-        const float* vp = a.V + (long)p * a.v_ld;
-        if (CB % 4 == 0 && vvec) {
+        float v[CBL];
+        const float* vp = a.V + (long)p * a.v_ld + b_off;
+        if (CBL % 4 == 0 && vvec) {
 #pragma unroll
-            for (int c = 0; c < CB; c += 4) {
+            for (int c = 0; c < CBL; c += 4) {
                 const f32x4 q = *reinterpret_cast<const f32x4*>(vp + c);
                 v[c] = q[0]; v[c + 1] = q[1]; v[c + 2] = q[2]; v[c + 3] = q[3];
             }
         } else {
 #pragma unroll
-            for (int c = 0; c < CB; ++c) v[c] = vp[c];
+            for (int c = 0; c < CBL; ++c) v[c] = vp[c];
         }
 #pragma unroll
-        for (int c = 0; c < CB; ++c) accb[c] += v[c];
+        for (int c = 0; c < CBL; ++c) accb[c] += v[c];
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky)
 #pragma unroll
             for (int kx = 0; kx < KW; ++kx) {
                 int iy = y * S - P + ky, ix = x * S - P + kx;
                 if ((unsigned)iy >= (unsigned)a.Hu || (unsigned)ix >= (unsigned)a.Wu) continue;
-                const float* up = a.U + (((long)b * a.Hu + iy) * a.Wu + ix) * a.u_ld;
-                float u[CA];
-                if (CA % 4 == 0 && uvec) {
+                const float* up = a.U + (((long)b * a.Hu + iy) * a.Wu + ix) * a.u_ld + a_off;
+                float u[CAL];
+                if (CAL % 4 == 0 && uvec) {
 #pragma unroll
-                    for (int c = 0; c < CA; c += 4) {
+                    for (int c = 0; c < CAL; c += 4) {
                         const f32x4 q = *reinterpret_cast<const f32x4*>(up + c);
                         u[c] = q[0]; u[c + 1] = q[1]; u[c + 2] = q[2]; u[c + 3] = q[3];
                     }
                 } else {
 #pragma unroll
-                    for (int ca = 0; ca < CA; ++ca) u[ca] = up[ca];
+                    for (int ca = 0; ca < CAL; ++ca) u[ca] = up[ca];
                 }
 #pragma unroll
-                for (int ca = 0; ca < CA; ++ca)
+                for (int ca = 0; ca < CAL; ++ca)
 #pragma unroll
-                    for (int cb = 0; cb < CB; ++cb)
+                    for (int cb = 0; cb < CBL; ++cb)
                         acc[ky * KW + kx][ca][cb] = fmaf(u[ca], v[cb], acc[ky * KW + kx][ca][cb]);
             }
     }
+    // fold the pixel slots (lanes with the same channel quad): xor over the lane bits above log2(LPP)
+    auto fold = [&](float s_) {
+#pragma unroll
+        for (int o = 32; o >= LPP; o >>= 1) s_ += __shfl_xor(s_, o, 64);
+        return s_;
+    };
     float* dst = a.part + (long)pw * a.pstride;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-        for (int ca = 0; ca < CA; ++ca)
+        for (int ca = 0; ca < CAL; ++ca)
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) {
-                float s = wave_sum(acc[t][ca][cb]);
-                if (lane == 0) dst[((long)t * CA + ca) * CB + cb] = s;
+            for (int cb = 0; cb < CBL; ++cb) {
+                const float s_ = fold(acc[t][ca][cb]);
+                if (ps == 0) dst[((long)t * CA + a_off + ca) * CB + b_off + cb] = s_;
             }
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-        float s = wave_sum(accb[cb]);
-        if (lane == 0 && a.want_bias) dst[(long)TAPS * CA * CB + cb] = s;
+    for (int cb = 0; cb < CBL; ++cb) {
+        const float s_ = fold(accb[cb]);
+        if (ps == 0 && a.want_bias && (SPLIT_B || cq == 0)) dst[(long)TAPS * CA * CB + b_off + cb] = s_;
     }
 }
 
@@ -1514,7 +1531,7 @@ static WgradPlan wgrad_plan(int taps, int B, int Hv, int Ca, int Cb) {
     p.small = (Ca * Cb * taps <= 144) && (Ca < 8 || Cb < 8);
     if (p.small) {
         p.TA = p.TB = p.nga = p.ngb = 1; p.rows_per_wave = 0;
-        p.nparts = nrows < 1024 ? nrows : 1024;
+        { static int np = getenv("RV_WGS_NPARTS") ? atoi(getenv("RV_WGS_NPARTS")) : 4096; p.nparts = nrows < np ? nrows : np; }
         return p;
     }
     // channel-group shape (TA x TB tiles of 16): the one that pads the channel counts least (48 = 3 x 16, not 2 x 32);
