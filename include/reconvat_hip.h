@@ -124,6 +124,15 @@ int rv_adam_step(float* p, const float* g, float* m, float* v, long n, const lon
 int rv_counter_add(long* counter, long inc, void* stream);
 int rv_clip_scale(float* g, long n, const float* total_norm, float max_norm, void* stream);
 
+/* ---- data feed: PianoRollAudioDataset.__getitem__ (model/dataset.py:35-69) for a whole batch on the device.
+ * audio: int16 corpus; label, velocity (nullable): uint8 corpora ([steps, n_keys] rolls, label 3 = onset, 2 = frame,
+ * 1 = offset); audio_begin / label_begin: DEVICE arrays of B element offsets (the host draws them with the reference's
+ * RandomState rule).  out_audio [B, seq_len] = int16 / 32768; onset / offset (nullable) / frame / out_velocity (nullable)
+ * [B, n_steps, n_keys] = (label == 3) / (label == 1) / (label > 1) / velocity / 128, all float32, bit-exact. */
+int rv_crop_segments(const short* audio, const unsigned char* label, const unsigned char* velocity, const long* audio_begin,
+                     const long* label_begin, int B, long seq_len, int n_steps, int n_keys, float* out_audio, float* onset,
+                     float* offset, float* frame, float* out_velocity, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

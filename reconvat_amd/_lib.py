@@ -47,6 +47,7 @@ SIGNATURES = {
     'rv_adam_step': (I, [P, P, P, P, L, P, F, L, F, F, F, F, F, P]),
     'rv_counter_add': (I, [P, L, P]),
     'rv_clip_scale': (I, [P, L, P, F, P]),
+    'rv_crop_segments': (I, [P, P, P, P, P, I, L, I, I, P, P, P, P, P, P]),
 }
 
 _lib = None

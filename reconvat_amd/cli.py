@@ -37,7 +37,7 @@ def base_config(o, onset_script):
         step_size_up=100, max_lr=1e-4, learning_rate=1e-3, learning_rate_decay_steps=1000,
         learning_rate_decay_rate=0.98, leave_one_out=None, clip_gradient_norm=3, refresh=False,
         # MI355X-side extras (not in the reference)
-        graph=False, fused_optimizer=True, saving_freq=saving_freq,
+        graph=False, fused_optimizer=True, saving_freq=saving_freq, device_feed=True,
     )
     c.update(o)
     if torch.cuda.is_available() and torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory < 10e9:
@@ -84,7 +84,7 @@ class ScalarLog:
 def run_training(onset_script, spec, resume_iteration, train_on, batch_size, sequence_length, small, supersmall,
                  train_batch_size, learning_rate, learning_rate_decay_steps, learning_rate_decay_rate, alpha,
                  clip_gradient_norm, validation_length, refresh, device, epoches, logdir, log, iteration, VAT_start, VAT,
-                 XI, eps, reconstruction, graph, fused_optimizer, saving_freq, **_unused):
+                 XI, eps, reconstruction, graph, fused_optimizer, saving_freq, device_feed=True, **_unused):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if world > 1:
@@ -99,8 +99,14 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
     l_set, ul_set, val_set, _full = prepare_VAT_dataset(sequence_length=sequence_length, validation_length=validation_length,
                                                         refresh=refresh, device=device, small=small, supersmall=supersmall,
                                                         dataset=train_on, rank=rank)
-    ul_loader = DataLoader(ul_set, batch_size, shuffle=True, drop_last=True) if VAT else None
-    l_loader = DataLoader(l_set, train_batch_size, shuffle=True, drop_last=True)
+    if device_feed and hasattr(l_set, 'data') and str(device).startswith('cuda'):
+        # corpus resident in HBM, batches cropped/decoded by rv_crop_segments (reconvat_amd/feed.py)
+        from .feed import device_loader
+        l_loader = device_loader(l_set, train_batch_size, device, seed=42 + rank)
+        ul_loader = device_loader(ul_set, batch_size, device, seed=43 + rank) if VAT else None
+    else:
+        ul_loader = DataLoader(ul_set, batch_size, shuffle=True, drop_last=True) if VAT else None
+        l_loader = DataLoader(l_set, train_batch_size, shuffle=True, drop_last=True)
 
     cls = UNet_Onset if onset_script else UNet
     torch.manual_seed(0)                                   # identical initial weights on every rank

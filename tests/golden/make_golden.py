@@ -326,8 +326,55 @@ def g_train_step():
     save('train_step', **out)
 
 
+def g_dataset():
+    """The reference's PianoRollAudioDataset.__getitem__ (model/dataset.py:35-69) on in-memory tracks: crop positions
+    of a RandomState(42) stream over 12 consecutive items, and the decoded crops themselves (exact)."""
+    from oracle import dataset as od
+    tracks = od.synthetic_tracks()
+
+    class InMemory(ref.dataset.PianoRollAudioDataset):
+        @classmethod
+        def available_groups(cls):
+            return ['g']
+
+        def files(self, group):
+            return [(i, None) for i in range(len(tracks))]
+
+        def load(self, i, _tsv):
+            t = tracks[i]
+            return dict(path=t['path'], audio=torch.from_numpy(t['audio']), label=torch.from_numpy(t['label']),
+                        velocity=torch.from_numpy(t['velocity']))
+
+    seq = 16384
+    ds = InMemory('.', sequence_length=seq, seed=42)
+    rs = np.random.RandomState(42)
+    out = {'order': [], 'start_idx': []}
+    order = [0, 1, 2, 2, 1, 0, 0, 0, 1, 2, 1, 2]
+    for n, idx in enumerate(order):
+        item = ds[idx]
+        step_begin, begin = od.draw_begin(rs, len(tracks[idx]['audio']), seq)
+        mine = od.crop_item(tracks[idx], step_begin, seq)
+        assert item['start_idx'] == begin == mine['start_idx']
+        for k in ('audio', 'onset', 'offset', 'frame', 'velocity'):
+            assert np.array_equal(item[k].numpy(), mine[k]), (n, k)          # bit-exact
+            if n < 3:
+                out[f'{n}_{k}'] = item[k].numpy()
+        out['order'].append(idx)
+        out['start_idx'].append(begin)
+        out.setdefault('audio_sum', []).append(float(item['audio'].double().sum()))
+        out.setdefault('frame_sum', []).append(float(item['frame'].sum()))
+        out.setdefault('onset_sum', []).append(float(item['onset'].sum()))
+        out.setdefault('velocity_sum', []).append(float(item['velocity'].double().sum()))
+    # whole-track item (sequence_length=None): no crop, velocity float
+    full = InMemory('.', sequence_length=None)[1]
+    out['full_len'] = len(full['audio'])
+    out['full_audio_sum'] = float(full['audio'].double().sum())
+    out['full_frame_sum'] = float(full['frame'].sum())
+    save('dataset', **{k: np.asarray(v) for k, v in out.items()})
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['frontend', 'unet', 'attention', 'networks', 'vat', 'run_on_batch', 'train_step']
+    which = sys.argv[1:] or ['frontend', 'unet', 'attention', 'networks', 'vat', 'run_on_batch', 'train_step', 'dataset']
     for w in which:
         print('==', w)
         globals()['g_' + w]()
