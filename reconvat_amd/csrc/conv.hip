@@ -860,6 +860,9 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
 #pragma unroll
     for (int y = 0; y < TB; ++y) accb[y] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bool do_bias = a.want_bias && ga == 0 && hp == 0;
+    float accbs[TB];                                         // per-lane partial column sums of V (lane (i, g): pixels x0+g)
+#pragma unroll
+    for (int y = 0; y < TB; ++y) accbs[y] = 0.f;
 
     for (int k = tid; k < stage_floats; k += NTHR) smem[k] = 0.f;   // padding / unused channels stay zero
     __syncthreads();
@@ -948,10 +951,20 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
                 }
             }
             if (do_bias) {
+                // bias gradient on the VALU (co-issues with the MFMAs): only the ga == 0 workgroups carry it, and as two
+                // extra MFMAs per step it made exactly those workgroups -- hence the whole launch -- ~10 % longer
 #pragma unroll
-                for (int tb = 0; tb < TB; ++tb)
-                    accb[tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, vf[tb], accb[tb], 0, 0, 0);
+                for (int tb = 0; tb < TB; ++tb) accbs[tb] += vf[tb];
             }
+        }
+    }
+    if (do_bias) {                                           // pixel lanes g -> every lane of a channel holds the sum
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) {
+            float sb = accbs[tb];
+            sb += __shfl_xor(sb, 16, 64);
+            sb += __shfl_xor(sb, 32, 64);
+            accb[tb] = (f32x4){sb, sb, sb, sb};
         }
     }
     // fold the x groups through LDS (x group w > 0 publishes, x group 0 of the same half accumulates)
