@@ -60,6 +60,18 @@ def bn_ws_doubles(c):
 
 _BN_DEFER = [None]
 
+# Two-stream VAT (model._Base._vat_two_streams).  Off by default: TrainStep switches it on once the weights are packed
+# by the one-launch plan and the conv autotuner has run (neither tolerates a concurrent second stream).
+DUAL_STREAM = [False]
+_SIDE = {}
+
+
+def side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
 
 class deferred_bn_updates:
     """Inside this context train-mode BatchNorm forwards use batch statistics but do NOT touch running_mean /

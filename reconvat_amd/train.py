@@ -152,7 +152,7 @@ class TrainStep:
     captured once into a hipGraph and replayed; the all-reduce and the optimiser kernel stay outside the
     graph so that the collective is an ordinary RCCL call."""
 
-    def __init__(self, model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=True):
+    def __init__(self, model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=True, dual_stream=True):
         self.model, self.opt, self.alpha, self.VAT, self.clip = model, opt, alpha, VAT, clip
         self.batch = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
         self.batch_ul = {k: v.clone() for k, v in batch_ul.items() if torch.is_tensor(v)} if batch_ul else None
@@ -161,14 +161,21 @@ class TrainStep:
         self.loss = None
         self.use_graph = graph
         self.pack_plan = None
+        self.dual_stream = dual_stream        # the two VAT chains on two HIP streams (model._vat_two_streams)
+        self._dual_ready = False              # ... from the second step on: the first one packs weights and autotunes
 
     def _fwd_bwd(self):
         self.opt.zero_grad()
         ops.ARENA.begin_step(self.opt.flat_grad.device)
-        with ops.direct_param_grads():      # conv grads accumulate straight into the flat bucket
-            _, losses, _ = self.model.run_on_batch(self.batch, self.batch_ul, self.VAT)
-            loss = weighted_loss(losses, self.alpha)
-            loss.backward()
+        prev_dual = ops.DUAL_STREAM[0]
+        ops.DUAL_STREAM[0] = self.dual_stream and self._dual_ready
+        try:
+            with ops.direct_param_grads():      # conv grads accumulate straight into the flat bucket
+                _, losses, _ = self.model.run_on_batch(self.batch, self.batch_ul, self.VAT)
+                loss = weighted_loss(losses, self.alpha)
+                loss.backward()
+        finally:
+            ops.DUAL_STREAM[0] = prev_dual
         ops.ARENA.end_step()
         self.losses = {k: v.detach() for k, v in losses.items()}
         self.loss = loss.detach()
@@ -185,9 +192,12 @@ class TrainStep:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for _ in range(warmup):
-                ops.invalidate_weight_cache()
+            ops.invalidate_weight_cache()
+            for w in range(warmup):
                 self._fwd_bwd()
+                # after the first step every weight is packed (nothing changes them here) and every conv shape is
+                # tuned: from now on the step may use the second stream
+                self._dual_ready = True
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         # all weights are repacked by ONE launch after every optimiser step (outside the graph); the graph itself is
@@ -208,6 +218,7 @@ class TrainStep:
             self._fwd_bwd()
             if self.pack_plan is None:
                 self.pack_plan = ops.PackPlan(self.opt.flat_grad.device)
+            self._dual_ready = True
         if not self.opt.data_parallel:
             allreduce_gradients(self.opt)
         self.opt.step()

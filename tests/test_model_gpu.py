@@ -348,3 +348,33 @@ def test_graph_capture_matches_eager(dev):
         torch.cuda.synchronize()
         res.append((float(loss), {k: float(v) for k, v in step.losses.items()}))
     assert abs(res[0][0] - res[1][0]) < 2e-3 * abs(res[0][0]), res
+
+
+def test_two_stream_vat_matches_single_stream(dev):
+    """model._vat_two_streams (unlabelled and labelled VAT chains on two HIP streams, BatchNorm updates deferred and
+    replayed in the reference's order) must give the single-stream step: losses, gradients, running statistics."""
+    from oracle import fixture as fx
+    from reconvat_amd import ops
+    bl, bul = _batches(dev)
+    n_ul, n_l = fx.fixture_noise((2, 1, 64, 229), 'd0_ul').to(dev), fx.fixture_noise((2, 1, 64, 229), 'd0_l').to(dev)
+    res = []
+    for dual in (False, True):
+        m = build('onset', True, dev)
+        seq = [n_ul, n_l]
+        m.vat_loss.noise = lambda t, seq=seq: seq.pop(0).clone()
+        ops.DUAL_STREAM[0] = dual
+        try:
+            _, losses, _ = m.run_on_batch(bl, bul, True)
+            sum(losses.values()).backward()
+        finally:
+            ops.DUAL_STREAM[0] = False
+        torch.cuda.synchronize()
+        res.append(({k: float(v) for k, v in losses.items()}, {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None},
+                    {k: v.clone() for k, v in m.state_dict().items() if 'running' in k or 'num_batches' in k}))
+    (l0, g0, s0), (l1, g1, s1) = res
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 1e-6 * max(abs(l0[k]), 1e-6), k
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k                 # same update sequence, bit for bit
+    for k in g0:
+        assert rel_err(g1[k], g0[k]) < 1e-5, k

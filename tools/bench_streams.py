@@ -1,0 +1,60 @@
+"""Does running two independent transcriber chains on two HIP streams beat running them back to back?
+(forward + input-gradient backward of the VAT power iteration, B=8 each, captured in hipGraphs)"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import reconvat_amd as ra
+from reconvat_amd import ops
+
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+m = ra.UNet_Onset((2, 2), (2, 2), log=True, reconstruction=True, mode='imagewise', spec='Mel', device=str(dev), XI=1e-6, eps=2).to(dev)
+m.train()
+xs = [torch.rand(8, 1, 640, 229, device=dev) for _ in range(2)]
+
+
+def chain(x):
+    with ops.deferred_bn_updates():
+        with torch.no_grad():
+            m.transcriber(x)
+        d = torch.randn_like(x).requires_grad_(True)
+        xa = ops.VatPerturbFn.apply(x, d, 1e-6)
+        roll, onset, _ = m.transcriber(xa, True)
+        g, = torch.autograd.grad(roll.sum() + onset.sum(), d)
+    return g
+
+
+def both_serial():
+    return chain(xs[0]), chain(xs[1])
+
+
+side = torch.cuda.Stream()
+
+
+def both_parallel():
+    cur = torch.cuda.current_stream()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        a = chain(xs[0])
+    b = chain(xs[1])
+    cur.wait_stream(side)
+    return a, b
+
+
+for fn in (both_serial, both_parallel):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fn()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        g.replay()
+    e1.record(); e1.synchronize()
+    print(f'{fn.__name__}: {e0.elapsed_time(e1) / 10:.3f} ms')
