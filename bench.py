@@ -150,6 +150,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=8, help='labelled AND unlabelled segments per GPU')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--single-stream', action='store_true', help='disable the two-stream step schedule (A/B)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--verbose', action='store_true', help='dump the per-launch conv table to stderr')
@@ -177,7 +178,8 @@ def main():
     gen = torch.Generator().manual_seed(1000 + rank)      # distinct data shard per rank
     batch, batch_ul = synthetic_batch(args.batch, gen, device), synthetic_batch(args.batch, gen, device)
     torch.manual_seed(77 + rank)                  # VAT noise stream
-    step = ra.TrainStep(model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=not args.no_graph)
+    step = ra.TrainStep(model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=not args.no_graph,
+                        dual_stream=not args.single_stream)
     used_graph = not args.no_graph
     if used_graph:
         try:
@@ -216,7 +218,7 @@ def main():
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'ReconVAT UNet_Onset VAT=True reconstruction=True, per-GPU B_l={args.batch} + '
                                f'B_ul={args.batch} segments of 327680 samples (640 frames x 229 mel), Adam+StepLR, fp32',
-                   'parallelism': f'dp{world}', 'hipgraph': used_graph, 'labelled_only_audio_s_per_s': round(audio_s / 2, 2),
+                   'parallelism': f'dp{world}', 'hipgraph': used_graph, 'two_stream_schedule': not args.single_stream, 'labelled_only_audio_s_per_s': round(audio_s / 2, 2),
                    'final_loss': round(loss, 5), 'vat_nan_flag': nan_flag},
     }
     if rank == 0 and world == 1:

@@ -361,15 +361,21 @@ class _Base(nn.Module):
             pending.apply()                                   # position of the main forward pass
         return out, lds, r_adv, r_norm
 
-    def _vat_two_streams(self, audio_ul, audio_l):
-        """Both VAT calls of a training step with their weight-gradient-free parts -- front-end, target pass, power
-        iteration: ~40 % of the step -- running CONCURRENTLY: the unlabelled chain on a side stream, the labelled chain
-        (sharing the main forward pass as in _vat_reusing_forward) on the current one.  Two independent kernel chains
-        hide each other's launch tails and latency-bound kernels (measured 17 % on this region).  Nothing in the
-        region writes shared state: parameter gradients are not produced (detached weights), and every BatchNorm
-        running-statistic update is deferred and replayed after the join in the reference's order
-        (UL target, UL xi*d, UL r_adv, L target, L xi*d, L r_adv, main forward).
-        Returns (spec_l, main outputs, lds_ul, d_ul, lds_l, r_adv_l, d_l)."""
+    def _vat_two_streams(self, audio_ul, audio_l, recon_fn=None):
+        """A training step as TWO concurrent kernel chains of equal length (two independent chains hide each other's
+        launch tails and latency-bound kernels; measured 17 % on the overlapped region):
+
+            side stream : front-end(ul), UL target pass, UL power iteration | reconstruction branch R -> T(recon) + its losses
+            this stream : front-end(l), main forward T(x), L power iteration | UL final pass, L final pass
+
+        and, because autograd runs every node's backward on its forward stream, the backward splits the same way
+        (side: T(recon), R; here: UL final, L final, then T(x) which joins both).  Shared state is kept race-free:
+        * the power iterations produce no parameter gradients (detached weights); the reconstruction branch's parameter
+          gradients go to the side stream's twin of the flat gradient bucket (ops.SIDE_GRADS, folded in by TrainStep);
+        * every BatchNorm running-statistic update of the concurrent passes is deferred and replayed on this stream in
+          the reference's order: UL target, UL xi*d, UL final, L target, L xi*d, L final, main forward, R, T(recon).
+        `recon_fn(first, spec)` runs the reconstruction branch (None: model without reconstructor).
+        Returns (spec_l, main outputs, lds_ul, d_ul, lds_l, r_adv_l, d_l, recon_fn's result)."""
         cur = torch.cuda.current_stream()
         side = ops.side_stream(audio_l.device)
         ref_len = audio_l.shape[-1]
@@ -378,22 +384,39 @@ class _Base(nn.Module):
             spec_ul = self._front(audio_ul, ref_len)
             with ops.deferred_bn_updates() as pend_ul:
                 xa_ul, r_ul, dn_ul, refs_ul = self.vat_loss.power_iteration(self, spec_ul)
+            ul_done = torch.cuda.Event()
+            ul_done.record(side)
         spec = self._front(audio_l, ref_len)
         with ops.deferred_bn_updates() as pend_main:
             out = self.transcriber(spec)
+        pack, pend_r = None, None
+        if recon_fn is not None:
+            main_done = torch.cuda.Event()
+            main_done.record(cur)
+            with torch.cuda.stream(side):
+                side.wait_event(main_done)
+                for t in (spec,) + tuple(out):
+                    t.record_stream(side)
+                with ops.deferred_bn_updates() as pend_r:
+                    pack = recon_fn(out, spec)
         with ops.deferred_bn_updates() as pend_l:
             xa_l, r_l, dn_l, refs_l = self.vat_loss.power_iteration(self, spec, refs=out[:-1])
-        cur.wait_stream(side)
+        cur.wait_event(ul_done)
         for t in (spec_ul, xa_ul, r_ul, dn_ul) + tuple(refs_ul):
             t.record_stream(cur)                              # produced on the side stream, consumed here from now on
-        self.vat_loss.check_nan()
         pend_ul.apply()
         lds_ul = self.vat_loss.final_loss(self, xa_ul, refs_ul)
         pend_main.apply()                                     # position of the labelled no_grad target pass
         pend_l.apply()
         lds_l = self.vat_loss.final_loss(self, xa_l, refs_l)
         pend_main.apply()                                     # position of the main forward pass
-        return spec, out, lds_ul, dn_ul, lds_l, r_l, dn_l
+        cur.wait_stream(side)
+        if pack is not None:
+            for t in pack.values():
+                t.record_stream(cur)
+            pend_r.apply()                                    # R and T(recon): last in the reference's sequence
+        self.vat_loss.check_nan()
+        return spec, out, lds_ul, dn_ul, lds_l, r_l, dn_l, pack
 
     def load_my_state_dict(self, state_dict):
         own_state = self.state_dict()
@@ -435,8 +458,15 @@ class UNet_Onset(_Base):
         if onset_label.dim() == 2:
             onset_label = onset_label.unsqueeze(0)
         dual = bool(batch_ul) and VAT and self.training and ops.DUAL_STREAM[0] and audio_label.is_cuda
+        pack = None
         if dual:
-            spec, first, lds_ul, r_norm_ul, lds_l, r_adv, r_norm_l = self._vat_two_streams(batch_ul['audio'], audio_label)
+            def recon_fn(first_, spec_):
+                rec_, _, _, roll2_, onset2_, _ = self(spec_, first_)
+                return {'rec': rec_, 'frame2': roll2_, 'onset2': onset2_,
+                        'l_rec': mse_mean(rec_.squeeze(1), spec_.squeeze(1)),
+                        'l_frame2': bce_mean(roll2_, frame_label), 'l_onset2': bce_mean(onset2_, onset_label)}
+            spec, first, lds_ul, r_norm_ul, lds_l, r_adv, r_norm_l, pack = self._vat_two_streams(
+                batch_ul['audio'], audio_label, recon_fn if self.reconstruction else None)
             r_norm_ul, r_norm_l, r_adv = abs_mean(r_norm_ul), abs_mean(r_norm_l), r_adv.squeeze(1)
         elif batch_ul:
             spec = self._front(batch_ul['audio'], audio_label.shape[-1])
@@ -459,7 +489,18 @@ class UNet_Onset(_Base):
             lds_l = {'frame': torch.tensor(0.), 'onset': torch.tensor(0.)}
             r_norm_l = torch.tensor(0.)
         tag = 'train' if self.training else 'test'
-        if self.reconstruction:
+        if self.reconstruction and pack is not None:
+            pianoroll, onset, a = first
+            predictions = {'frame': pianoroll, 'onset': onset, 'frame2': pack['frame2'], 'onset2': pack['onset2'], 'attention': a,
+                           'r_adv': r_adv, 'reconstruction': pack['rec']}
+            losses = {
+                f'loss/{tag}_reconstruction': pack['l_rec'],
+                f'loss/{tag}_frame': bce_mean(pianoroll, frame_label),
+                f'loss/{tag}_frame2': pack['l_frame2'],
+                f'loss/{tag}_onset': bce_mean(onset, onset_label),
+                f'loss/{tag}_onset2': pack['l_onset2'],
+            }
+        elif self.reconstruction:
             reconstrut, pianoroll, onset, pianoroll2, onset2, a = self(spec, first)
             predictions = {'frame': pianoroll, 'onset': onset, 'frame2': pianoroll2, 'onset2': onset2, 'attention': a,
                            'r_adv': r_adv, 'reconstruction': reconstrut}
@@ -514,7 +555,7 @@ class UNet(_Base):
             frame_label = frame_label.unsqueeze(0)
         dual = bool(batch_ul) and VAT and self.training and ops.DUAL_STREAM[0] and audio_label.is_cuda
         if dual:
-            spec, first, lds_ul, r_norm_ul, lds_l, r_adv, r_norm_l = self._vat_two_streams(batch_ul['audio'], audio_label)
+            spec, first, lds_ul, r_norm_ul, lds_l, r_adv, r_norm_l, _ = self._vat_two_streams(batch_ul['audio'], audio_label)
             r_norm_ul, r_norm_l, r_adv = abs_mean(r_norm_ul), abs_mean(r_norm_l), r_adv.squeeze(1)
         elif batch_ul:
             spec = self._front(batch_ul['audio'], audio_label.shape[-1])

@@ -107,10 +107,22 @@ class direct_param_grads:
         _DIRECT[0] = self.prev
 
 
+# (flat gradient bucket, its side-stream twin): backward kernels that run on the side stream accumulate into the twin, so
+# the two concurrent backward chains never read-modify-write the same addresses; FlatAdam.merge_side_grads() adds it in.
+SIDE_GRADS = [None]
+
+
 def _grad_buf(t):
-    if _DIRECT[0] and t is not None and t.requires_grad and t.grad is not None:
-        return t.grad
-    return None
+    if not (_DIRECT[0] and t is not None and t.requires_grad and t.grad is not None):
+        return None
+    sg = SIDE_GRADS[0]
+    if sg is not None and DUAL_STREAM[0]:
+        side = _SIDE.get((t.device.type, t.device.index))
+        if side is not None and torch.cuda.current_stream(t.device) == side:
+            main, twin = sg
+            off = (t.grad.data_ptr() - main.data_ptr()) // 4
+            return twin[off:off + t.grad.numel()].view_as(t.grad)
+    return t.grad
 
 
 def invalidate_weight_cache():

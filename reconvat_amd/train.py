@@ -85,6 +85,7 @@ class FlatAdam:
         n = sum(p.numel() for p in self.params)
         self.flat_param = torch.empty(n, device=dev, dtype=torch.float32)
         self.flat_grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.flat_grad_side = None            # twin bucket of the side stream (TrainStep two-stream mode)
         self.exp_avg = torch.zeros(n, device=dev, dtype=torch.float32)
         self.exp_avg_sq = torch.zeros(n, device=dev, dtype=torch.float32)
         self.step_count = torch.zeros((), device=dev, dtype=torch.int64)
@@ -104,8 +105,20 @@ class FlatAdam:
         self.data_parallel = data_parallel      # all-reduce the flat bucket inside step()
         ops.invalidate_weight_cache()
 
+    def enable_side_bucket(self):
+        if self.flat_grad_side is None:
+            self.flat_grad_side = torch.zeros_like(self.flat_grad)
+        return self.flat_grad_side
+
+    def merge_side_grads(self):
+        """flat_grad += side-stream twin (call on the main stream after joining the side stream)."""
+        if self.flat_grad_side is not None:
+            self.flat_grad.add_(self.flat_grad_side)
+
     def zero_grad(self, set_to_none=False):
         self.flat_grad.zero_()
+        if self.flat_grad_side is not None:
+            self.flat_grad_side.zero_()
         for p, off in zip(self.params, self.offsets):      # re-attach if something replaced .grad
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
                 p.grad = self.flat_grad[off:off + p.numel()].view_as(p.data)
@@ -167,15 +180,22 @@ class TrainStep:
     def _fwd_bwd(self):
         self.opt.zero_grad()
         ops.ARENA.begin_step(self.opt.flat_grad.device)
-        prev_dual = ops.DUAL_STREAM[0]
-        ops.DUAL_STREAM[0] = self.dual_stream and self._dual_ready
+        prev_dual, prev_side = ops.DUAL_STREAM[0], ops.SIDE_GRADS[0]
+        dual = self.dual_stream and self._dual_ready and self.batch_ul is not None and self.VAT
+        ops.DUAL_STREAM[0] = dual
+        if dual:
+            ops.SIDE_GRADS[0] = (self.opt.flat_grad, self.opt.enable_side_bucket())
         try:
             with ops.direct_param_grads():      # conv grads accumulate straight into the flat bucket
                 _, losses, _ = self.model.run_on_batch(self.batch, self.batch_ul, self.VAT)
                 loss = weighted_loss(losses, self.alpha)
                 loss.backward()
+            if dual:
+                # the side stream ran the reconstruction branch's backward into its own bucket: join, then fold
+                torch.cuda.current_stream().wait_stream(ops.side_stream(self.opt.flat_grad.device))
+                self.opt.merge_side_grads()
         finally:
-            ops.DUAL_STREAM[0] = prev_dual
+            ops.DUAL_STREAM[0], ops.SIDE_GRADS[0] = prev_dual, prev_side
         ops.ARENA.end_step()
         self.losses = {k: v.detach() for k, v in losses.items()}
         self.loss = loss.detach()

@@ -378,3 +378,44 @@ def test_two_stream_vat_matches_single_stream(dev):
         assert torch.equal(s0[k], s1[k]), k                 # same update sequence, bit for bit
     for k in g0:
         assert rel_err(g1[k], g0[k]) < 1e-5, k
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_train_step_two_streams_equals_single_stream(dev, graph):
+    """TrainStep's forward+backward with the two-stream schedule (side-stream twin gradient bucket, deferred BatchNorm
+    updates, eager and hipGraph-captured) produces the gradients, losses and running statistics of the single-stream
+    schedule.  Compared BEFORE any optimiser step: Adam turns rounding-level gradient differences of noise-gradient
+    parameters into +-lr steps, so parameter trajectories are not comparable across summation orders."""
+    import reconvat_amd as ra
+    from oracle import fixture as fx
+    bl, bul = _batches(dev)
+    res = []
+    for dual in (False, True):
+        m = build('onset', True, dev)
+        opt = ra.FlatAdam(m.parameters(), lr=1e-3)
+        d = [fx.fixture_noise((2, 1, 64, 229), 'd0_ul').to(dev), fx.fixture_noise((2, 1, 64, 229), 'd0_l').to(dev)]
+        state = {'i': 0}
+
+        def noise(t, d=d, state=state):
+            state['i'] += 1
+            return d[state['i'] % 2].clone()
+        m.vat_loss.noise = noise
+        step = ra.TrainStep(m, opt, bl, bul, graph=graph, dual_stream=dual)
+        if graph:
+            step.capture()
+            step.graph.replay()
+        else:
+            m.train()
+            step._fwd_bwd()              # first pass: single stream by design (packing, tuning)
+            step._dual_ready = True
+            step._fwd_bwd()
+        torch.cuda.synchronize()
+        assert (opt.flat_grad_side is not None) == dual
+        res.append((float(step.loss), {k: float(v) for k, v in step.losses.items()}, opt.flat_grad.clone(),
+                    {k: v.clone() for k, v in m.state_dict().items() if 'running' in k}))
+    (l0, ls0, g0, s0), (l1, ls1, g1, s1) = res
+    for k in ls0:
+        assert abs(ls0[k] - ls1[k]) <= 1e-5 * max(abs(ls0[k]), 1e-6), (k, ls0[k], ls1[k])
+    assert rel_err(g1, g0) < 1e-4            # fp32 gradients of this network carry ~1e-5 (of the max) summation-order noise
+    for k in s0:
+        assert rel_err(s1[k], s0[k]) < 1e-6, k
