@@ -37,7 +37,7 @@ def base_config(o, onset_script):
         step_size_up=100, max_lr=1e-4, learning_rate=1e-3, learning_rate_decay_steps=1000,
         learning_rate_decay_rate=0.98, leave_one_out=None, clip_gradient_norm=3, refresh=False,
         # MI355X-side extras (not in the reference)
-        graph=False, fused_optimizer=True, saving_freq=saving_freq, device_feed=True,
+        graph=True, fused_optimizer=True, saving_freq=saving_freq, device_feed=True,
     )
     c.update(o)
     if torch.cuda.is_available() and torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory < 10e9:
