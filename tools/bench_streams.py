@@ -11,7 +11,8 @@ dev = torch.device('cuda:0')
 torch.manual_seed(0)
 m = ra.UNet_Onset((2, 2), (2, 2), log=True, reconstruction=True, mode='imagewise', spec='Mel', device=str(dev), XI=1e-6, eps=2).to(dev)
 m.train()
-xs = [torch.rand(8, 1, 640, 229, device=dev) for _ in range(2)]
+NCH = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+xs = [torch.rand(8, 1, 640, 229, device=dev) for _ in range(NCH)]
 
 
 def chain(x):
@@ -26,20 +27,23 @@ def chain(x):
 
 
 def both_serial():
-    return chain(xs[0]), chain(xs[1])
+    return [chain(x) for x in xs]
 
 
-side = torch.cuda.Stream()
+sides = [torch.cuda.Stream() for _ in range(NCH - 1)]
 
 
 def both_parallel():
     cur = torch.cuda.current_stream()
-    side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        a = chain(xs[0])
-    b = chain(xs[1])
-    cur.wait_stream(side)
-    return a, b
+    outs = []
+    for sd, x in zip(sides, xs[1:]):
+        sd.wait_stream(cur)
+        with torch.cuda.stream(sd):
+            outs.append(chain(x))
+    outs.append(chain(xs[0]))
+    for sd in sides:
+        cur.wait_stream(sd)
+    return outs
 
 
 for fn in (both_serial, both_parallel):
