@@ -12,6 +12,7 @@ import json
 import os
 from datetime import datetime
 
+import numpy as np
 import torch
 import torch.distributed as dist
 from torch.utils.data import DataLoader
@@ -160,8 +161,20 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
                 torch.save(optimizer.state_dict(), os.path.join(logdir, 'last-optimizer-state.pt'))
     if rank == 0:
         torch.save(model.state_dict(), os.path.join(logdir, 'model-final.pt'))
-        print('Training finished. (Full-song MAPS evaluation needs mir_eval, which is outside the MI355X hot path: '
-              'load model-final.pt into the reference\'s evaluate.py for note/frame F1.)')
+        # final evaluation as in the reference scripts (train_UNet_Onset_VAT.py:140-160): note / frame metrics on the
+        # validation segments (reconvat_amd/evaluate.py)
+        from .evaluate import evaluate_wo_velocity
+        model.eval()
+        with torch.no_grad():
+            loader = DataLoader(val_set, 1, shuffle=False)
+            metrics = evaluate_wo_velocity((b for i, b in enumerate(loader) if i < 4), model, reconstruction=reconstruction,
+                                           onset=onset_script, VAT=True)
+        for key, values in sorted(metrics.items()):
+            if key.startswith('metric/') and values:
+                writer.add_scalar('validation/' + key, float(np.mean(values)), epoches)
+        f1 = float(np.mean(metrics['metric/frame/f1'])) if metrics['metric/frame/f1'] else float('nan')
+        print(f'Training finished.  validation frame F1 {f1:.4f}, note F1 '
+              f"{float(np.mean(metrics['metric/note/f1'])) if metrics['metric/note/f1'] else float('nan'):.4f}")
     if world > 1:
         dist.destroy_process_group()
     return model

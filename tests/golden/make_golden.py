@@ -373,8 +373,45 @@ def g_dataset():
     save('dataset', **{k: np.asarray(v) for k, v in out.items()})
 
 
+def decoding_rolls(seed, T=300, P=88):
+    """Smooth random posteriorgrams with note-like runs (shared with tests/test_decoding.py through this recipe)."""
+    rng = np.random.RandomState(seed)
+    frames = np.zeros((T, P), np.float32)
+    onsets = np.zeros((T, P), np.float32)
+    for _ in range(120):
+        t0, p, ln = rng.randint(0, T), rng.randint(0, P), rng.randint(1, 40)
+        frames[t0:t0 + ln, p] = rng.uniform(0.3, 1.0)
+        if rng.rand() < 0.8:
+            onsets[t0:min(T, t0 + rng.randint(1, 4)), p] = rng.uniform(0.3, 1.0)
+    onsets += rng.uniform(0, 0.2, size=onsets.shape).astype(np.float32)
+    frames += rng.uniform(0, 0.2, size=frames.shape).astype(np.float32)
+    velocity = rng.uniform(0, 1, size=frames.shape).astype(np.float32)
+    return onsets, frames, velocity
+
+
+def g_decoding():
+    """model/decoding.py (extract_notes_wo_velocity rule1 / rule2, extract_notes, notes_to_frames) on seeded rolls."""
+    from reconvat_amd import decoding as md
+    out = {}
+    for seed in (0, 1, 2):
+        on, fr, vel = (torch.from_numpy(a) for a in decoding_rolls(seed))
+        for rule in ('rule1', 'rule2'):
+            p, i = ref.decoding.extract_notes_wo_velocity(on, fr, 0.5, 0.5, rule=rule)
+            p2, i2 = md.extract_notes_wo_velocity(on, fr, 0.5, 0.5, rule=rule)
+            assert np.array_equal(p, p2) and np.array_equal(i, i2), (seed, rule)
+            out[f'{seed}_{rule}_p'], out[f'{seed}_{rule}_i'] = p, i
+        p, i, v = ref.decoding.extract_notes(on, fr, vel, 0.4, 0.6)
+        p2, i2, v2 = md.extract_notes(on, fr, vel, 0.4, 0.6)
+        assert np.array_equal(p, p2) and np.array_equal(i, i2) and np.allclose(v, v2, rtol=1e-6), seed
+        out[f'{seed}_v_p'], out[f'{seed}_v_i'], out[f'{seed}_v_v'] = p, i, v
+        t, f = ref.decoding.notes_to_frames(out[f'{seed}_rule1_p'], out[f'{seed}_rule1_i'], fr.shape)
+        out[f'{seed}_nf_count'] = np.array([len(x) for x in f])
+    save('decoding', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['frontend', 'unet', 'attention', 'networks', 'vat', 'run_on_batch', 'train_step', 'dataset']
+    which = sys.argv[1:] or ['frontend', 'unet', 'attention', 'networks', 'vat', 'run_on_batch', 'train_step', 'dataset',
+                             'decoding']
     for w in which:
         print('==', w)
         globals()['g_' + w]()

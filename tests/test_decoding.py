@@ -1,0 +1,104 @@
+"""Evaluation path: note decoding against the golden produced by the reference's model/decoding.py
+(exact), and the restated mir_eval metrics on cases with known answers (parity unpinned for those two functions)."""
+import os
+
+import numpy as np
+import torch
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def decoding_rolls(seed, T=300, P=88):
+    """Same recipe as tests/golden/make_golden.py::decoding_rolls."""
+    rng = np.random.RandomState(seed)
+    frames = np.zeros((T, P), np.float32)
+    onsets = np.zeros((T, P), np.float32)
+    for _ in range(120):
+        t0, p, ln = rng.randint(0, T), rng.randint(0, P), rng.randint(1, 40)
+        frames[t0:t0 + ln, p] = rng.uniform(0.3, 1.0)
+        if rng.rand() < 0.8:
+            onsets[t0:min(T, t0 + rng.randint(1, 4)), p] = rng.uniform(0.3, 1.0)
+    onsets += rng.uniform(0, 0.2, size=onsets.shape).astype(np.float32)
+    frames += rng.uniform(0, 0.2, size=frames.shape).astype(np.float32)
+    velocity = rng.uniform(0, 1, size=frames.shape).astype(np.float32)
+    return onsets, frames, velocity
+
+
+def test_decoding_matches_reference_golden():
+    from reconvat_amd import decoding as md
+    g = np.load(os.path.join(G, 'decoding.npz'))
+    for seed in (0, 1, 2):
+        on, fr, vel = (torch.from_numpy(a) for a in decoding_rolls(seed))
+        for rule in ('rule1', 'rule2'):
+            p, i = md.extract_notes_wo_velocity(on, fr, 0.5, 0.5, rule=rule)
+            assert np.array_equal(p, g[f'{seed}_{rule}_p']) and np.array_equal(i, g[f'{seed}_{rule}_i'])
+        p, i, v = md.extract_notes(on, fr, vel, 0.4, 0.6)
+        assert np.array_equal(p, g[f'{seed}_v_p']) and np.array_equal(i, g[f'{seed}_v_i'])
+        assert np.allclose(v, g[f'{seed}_v_v'], rtol=1e-6)
+        _, f = md.notes_to_frames(g[f'{seed}_rule1_p'], g[f'{seed}_rule1_i'], fr.shape)
+        assert np.array_equal(np.array([len(x) for x in f]), g[f'{seed}_nf_count'])
+    # edge cases: empty rolls, a note running to the last frame
+    z = torch.zeros(10, 88)
+    p, i = md.extract_notes_wo_velocity(z, z)
+    assert len(p) == 0 and len(i) == 0
+    on = torch.zeros(10, 88); fr = torch.zeros(10, 88)
+    on[7, 3] = 1; fr[7:, 3] = 1
+    p, i = md.extract_notes_wo_velocity(on, fr)
+    assert p.tolist() == [3] and i.tolist() == [[7, 10]]
+
+
+def test_note_and_frame_metrics_known_answers():
+    from reconvat_amd import evaluate as ev
+    hz = ev.midi_to_hz
+    assert abs(hz(69) - 440.0) < 1e-9 and abs(hz(81) - 880.0) < 1e-9
+    ref_i = np.array([[0.0, 1.0], [1.0, 2.0], [2.0, 2.5]])
+    ref_p = hz(np.array([60, 64, 67]))
+    # identical transcription
+    assert ev.evaluate_notes(ref_i, ref_p, ref_i, ref_p) == (1.0, 1.0, 1.0, 1.0)
+    # onset 40 ms late (inside), second note 60 ms late (outside), third a semitone off (outside), one extra note
+    est_i = np.array([[0.04, 1.0], [1.06, 2.0], [2.0, 2.5], [3.0, 3.2]])
+    est_p = hz(np.array([60, 64, 68, 50]))
+    p, r, f, o = ev.evaluate_notes(ref_i, ref_p, est_i, est_p, offset_ratio=None)
+    assert (p, r) == (0.25, 1 / 3) and abs(f - 2 * p * r / (p + r)) < 1e-12 and abs(o - 0.96) < 1e-9
+    # offsets: first reference note lasts 1 s -> tolerance 0.2 s; an estimate ending 0.3 s early misses with offsets
+    est_i2 = np.array([[0.0, 0.7]])
+    assert ev.evaluate_notes(ref_i, ref_p, est_i2, hz(np.array([60])), offset_ratio=None)[0] == 1.0
+    assert ev.evaluate_notes(ref_i, ref_p, est_i2, hz(np.array([60])))[0] == 0.0
+    # one-to-one matching: two estimates near one reference note count once
+    est_i3 = np.array([[0.0, 1.0], [0.01, 1.0]])
+    p, r, _, _ = ev.evaluate_notes(ref_i[:1], ref_p[:1], est_i3, hz(np.array([60, 60])), offset_ratio=None)
+    assert (p, r) == (0.5, 1.0)
+    assert ev.evaluate_notes(ref_i, ref_p, np.zeros((0, 2)), np.array([])) == (0.0, 0.0, 0.0, 0.0)
+    # frames: 3 frames, reference {60,64} {60} {}, estimate {60} {60,62} {65}
+    t = np.arange(3) * 0.032
+    rf = [hz(np.array([60, 64])), hz(np.array([60])), np.array([])]
+    ef = [hz(np.array([60])), hz(np.array([60, 62])), hz(np.array([65]))]
+    m = ev.evaluate_frames(t, rf, t, ef)
+    assert m['Precision'] == 2 / 4 and m['Recall'] == 2 / 3 and m['Accuracy'] == 2 / 5
+    assert m['Miss Error'] == 1 / 3 and m['False Alarm Error'] == 2 / 3 and m['Substitution Error'] == 0.0
+    assert m['Total Error'] == 3 / 3
+    assert ev.evaluate_frames(t, rf, t, rf)['Precision'] == 1.0
+
+
+def test_evaluate_wo_velocity_keys_and_perfect_score():
+    """The loop mirrors the reference's metric keys; a 'model' that returns the labels scores 1.0 everywhere."""
+    from reconvat_amd import evaluate as ev
+    on_np, fr_np, _ = decoding_rolls(5, T=120)
+    on, fr = torch.from_numpy((on_np > 0.5).astype(np.float32)), torch.from_numpy((fr_np > 0.5).astype(np.float32))
+    fr = torch.maximum(fr, on)
+
+    class Oracle:
+        def run_on_batch(self, label, batch_ul=None, VAT=False):
+            pred = {'onset': label['onset'].clone(), 'frame': label['frame'].clone(), 'onset2': label['onset'].clone(),
+                    'frame2': label['frame'].clone()}
+            return pred, {'loss/test_frame': torch.tensor(0.25)}, None
+
+    data = [{'onset': on.unsqueeze(0), 'frame': fr.unsqueeze(0), 'path': 'x'}]
+    m = ev.evaluate_wo_velocity(data, Oracle(), reconstruction=True, VAT=True)
+    for k in ('metric/note/f1', 'metric/note-with-offsets/f1', 'metric/frame/f1', 'metric/note/f1_2', 'metric/frame/f1_2',
+              'metric/MusicNet/micro_avg_P', 'metric/frame/precision', 'metric/frame/recall', 'metric/frame/accuracy',
+              'metric/frame/total_error', 'metric/note/overlap', 'loss/test_frame'):
+        assert k in m, k
+    assert abs(m['metric/note/f1'][0] - 1.0) < 1e-12 and abs(m['metric/frame/f1'][0] - 1.0) < 1e-9
+    assert abs(m['metric/note-with-offsets/f1_2'][0] - 1.0) < 1e-12 and m['metric/frame/total_error'][0] == 0.0
+    assert m['loss/test_frame'] == [0.25]
