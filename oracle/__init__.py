@@ -22,4 +22,6 @@ Parity status
   algorithm (Hann-windowed DFT kernels, librosa-0.7 Slaney mel filterbank) and
   cross-checked against ``torch.stft``; the reference holds no test or fixture
   for them.
+* the data-item rule (``oracle/dataset.py``, integer / byte work): PINNED bit-exactly -- ``tests/golden/dataset.npz``
+  holds the outputs of the reference's own ``PianoRollAudioDataset.__getitem__`` on in-memory tracks.
 """
