@@ -158,16 +158,16 @@ __global__ __launch_bounds__(256) void colsum_k(const float* x, int ld, long M, 
 
 // narrow matrices (N % 4 == 0, N <= 256; the up-conv bias gradients over millions of pixels): 16-byte loads,
 // thread -> (column quad, row lane), 32 rows per thread, LDS fold, one atomic per column per workgroup
-__global__ __launch_bounds__(256) void colsum_vec_k(const float* x, int ld, long M, int N, float* out) {
+__global__ __launch_bounds__(256) void colsum_vec_k(const float* x, int ld, long M, int N, float* out, int rpt) {
     __shared__ float sh[256 * 4];
     const int C4 = N >> 2, PL = 256 / C4;
     const int t = threadIdx.x;
     const int c = (t % C4) * 4, pl = t / C4;
     f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (pl < PL) {
-        const long p0 = (long)blockIdx.x * PL * 32;
+        const long p0 = (long)blockIdx.x * PL * rpt;
 #pragma unroll 4
-        for (int k = 0; k < 32; ++k) {
+        for (int k = 0; k < rpt; ++k) {
             const long p = p0 + pl + (long)k * PL;
             if (p >= M) break;
             s += *reinterpret_cast<const f32x4*>(x + p * ld + c);
@@ -287,9 +287,14 @@ int rv_sigmoid_bwd(const float* g1, int ld1, const float* g2, int ld2, const flo
 int rv_colsum(const float* x, int ld, long M, int N, float* out, int accumulate, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * N, st);
-    if ((N & 3) == 0 && N <= 256 && (ld & 3) == 0 && ((((uintptr_t)x) & 15) == 0) && M >= 4096) {
+    if ((N & 3) == 0 && N <= 256 && (ld & 3) == 0 && ((((uintptr_t)x) & 15) == 0) && M >= 1024) {
+        // rows per thread: ~512 workgroups -- enough to fill the chip on the 5 120-row linear layers (32 rows per thread
+        // left 15 workgroups there), few enough that the per-column atomics (serialised, ~23 ns each) stay a short tail
         const int PL = 256 / (N / 4);
-        hipLaunchKernelGGL(colsum_vec_k, dim3(cdiv(M, (long)PL * 32)), dim3(256), 0, st, x, ld, M, N, out);
+        long rpt = M / ((long)PL * 512);
+        if (rpt < 4) rpt = 4;
+        if (rpt > 64) rpt = 64;
+        hipLaunchKernelGGL(colsum_vec_k, dim3(cdiv(M, (long)PL * rpt)), dim3(256), 0, st, x, ld, M, N, out, (int)rpt);
     } else {
         int rpb = 256;
         dim3 grid(cdiv(N, 64), cdiv(M, rpb));
