@@ -7,12 +7,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from torch.utils.data import DataLoader
-from oracle import dataset as od          # synthetic tracks only (test infrastructure)
 from reconvat_amd.feed import DeviceCorpus
 from reconvat_amd.dataset import PianoRollAudioDataset
 
 dev = torch.device('cuda:0')
-tracks = od.synthetic_tracks(n=32, seed=5, min_len=2_000_000, max_len=3_000_000)
+rng = np.random.RandomState(5)
+tracks = []
+for i in range(32):
+    t = int(rng.randint(2_000_000, 3_000_000))
+    steps = (t - 1) // 512 + 1
+    tracks.append({'path': f'track{i}.flac', 'audio': rng.randint(-32768, 32768, size=t).astype(np.int16),
+                   'label': rng.randint(0, 4, size=(steps, 88)).astype(np.uint8),
+                   'velocity': rng.randint(0, 128, size=(steps, 88)).astype(np.uint8)})
 
 
 class Mem(PianoRollAudioDataset):
