@@ -79,6 +79,10 @@ int rv_bn_lrelu_fwd(const float* z, int z_ld, long P, int C, const float* gamma,
                     void* stream);
 int rv_bn_running_update(float* running_mean, float* running_var, long* num_batches_tracked, const float* coef, int C,
                          float momentum, void* stream);
+/* all deferred running-statistic updates of a step in one launch: table (DEVICE int64 words) = nlayers x {running_mean,
+ * running_var, num_batches_tracked, C, first, count} followed by the coef pointers; layer l applies coefs[first .. first+count)
+ * in order. */
+int rv_bn_running_update_table(const long* table, int nlayers, float momentum, void* stream);
 int rv_bn_lrelu_bwd(const float* dy, int dy_ld, const float* z, int z_ld, long P, int C, const float* coef, float slope,
                     int frozen, float* dz, int dz_ld, float* dgamma, float* dbeta, int param_accumulate, void* workspace,
                     int sums_ready, void* stream);

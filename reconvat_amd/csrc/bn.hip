@@ -15,6 +15,12 @@
 
 #define BN_PIX_PER_THREAD 16
 
+// running <- (1 - momentum) * running + momentum * batch, with the rounding sequence pinned (one multiply, one fused
+// multiply-add) so that the fused finalize, the per-layer replay and the table replay are bit-identical
+__device__ __forceinline__ float bn_momentum_update(float running, float batch, float momentum) {
+    return __fmaf_rn(momentum, batch, __fmul_rn(1.f - momentum, running));
+}
+
 struct BnArgs {
     const float* z; int z_ld;
     const float* dy; int dy_ld;
@@ -270,8 +276,8 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
                     const float unb = (float)(n > 1.0 ? var * n / (n - 1.0) : var);
                     a.coef_out[4 * a.C + cc] = unb;            // kept for a deferred running-stat update
                     if (a.training == 1) {
-                        a.running_mean[cc] = (1.f - a.momentum) * a.running_mean[cc] + a.momentum * m_;
-                        a.running_var[cc] = (1.f - a.momentum) * a.running_var[cc] + a.momentum * unb;
+                        a.running_mean[cc] = bn_momentum_update(a.running_mean[cc], m_, a.momentum);
+                        a.running_var[cc] = bn_momentum_update(a.running_var[cc], unb, a.momentum);
                     }
                 }
             }
@@ -382,8 +388,38 @@ __global__ void bn_running_update_k(float* rm, float* rv, long* nbt, const float
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && nbt) *nbt += 1;
     if (c >= C) return;
-    rm[c] = (1.f - momentum) * rm[c] + momentum * coef[c];
-    rv[c] = (1.f - momentum) * rv[c] + momentum * coef[4 * C + c];
+    rm[c] = bn_momentum_update(rm[c], coef[c], momentum);
+    rv[c] = bn_momentum_update(rv[c], coef[4 * C + c], momentum);
+}
+
+// Table form: every deferred update of a training step in ONE launch.  `table` (device, int64 words) holds, per BatchNorm
+// layer, {running_mean, running_var, num_batches_tracked, C, first, count} and then a flat list of coef pointers; workgroup
+// l applies layer l's `count` updates in list order (the order matters: momentum updates do not commute).
+__global__ __launch_bounds__(128) void bn_running_update_table_k(const long* table, int nlayers, float momentum) {
+    const long* e = table + (long)blockIdx.x * 6;
+    float* rm = (float*)e[0];
+    float* rv = (float*)e[1];
+    long* nbt = (long*)e[2];
+    const int C = (int)e[3];
+    const long first = e[4], count = e[5];
+    const long* coefs = table + (long)nlayers * 6 + first;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float m = rm[c], v = rv[c];
+        for (long k = 0; k < count; ++k) {
+            const float* coef = (const float*)coefs[k];
+            m = bn_momentum_update(m, coef[c], momentum);
+            v = bn_momentum_update(v, coef[4 * C + c], momentum);
+        }
+        rm[c] = m; rv[c] = v;
+    }
+    if (threadIdx.x == 0 && nbt) *nbt += count;
+}
+
+int rv_bn_running_update_table(const long* table, int nlayers, float momentum, void* stream) {
+    RV_CHECK_ARG(table && nlayers > 0, "rv_bn_running_update_table: empty table");
+    hipLaunchKernelGGL(bn_running_update_table_k, dim3(nlayers), dim3(128), 0, (hipStream_t)stream, table, nlayers, momentum);
+    RV_LAUNCH_CHECK("rv_bn_running_update_table");
+    return RV_OK;
 }
 
 int rv_bn_running_update(float* running_mean, float* running_var, long* num_batches_tracked, const float* coef, int C,

@@ -404,17 +404,18 @@ class _Base(nn.Module):
         cur.wait_event(ul_done)
         for t in (spec_ul, xa_ul, r_ul, dn_ul) + tuple(refs_ul):
             t.record_stream(cur)                              # produced on the side stream, consumed here from now on
-        pend_ul.apply()
-        lds_ul = self.vat_loss.final_loss(self, xa_ul, refs_ul)
-        pend_main.apply()                                     # position of the labelled no_grad target pass
-        pend_l.apply()
-        lds_l = self.vat_loss.final_loss(self, xa_l, refs_l)
-        pend_main.apply()                                     # position of the main forward pass
+        with ops.deferred_bn_updates() as pend_ulf:
+            lds_ul = self.vat_loss.final_loss(self, xa_ul, refs_ul)
+        with ops.deferred_bn_updates() as pend_lf:
+            lds_l = self.vat_loss.final_loss(self, xa_l, refs_l)
         cur.wait_stream(side)
         if pack is not None:
             for t in pack.values():
                 t.record_stream(cur)
-            pend_r.apply()                                    # R and T(recon): last in the reference's sequence
+        # every running-statistic update of the step, in the reference's order, in ONE launch (pend_main twice: the
+        # labelled no_grad target pass and the main forward pass are the same computation)
+        seq = [pend_ul, pend_ulf, pend_main, pend_l, pend_lf, pend_main] + ([pend_r] if pend_r is not None else [])
+        ops.replay_bn_updates(seq, audio_l.device)
         self.vat_loss.check_nan()
         return spec, out, lds_ul, dn_ul, lds_l, r_l, dn_l, pack
 

@@ -92,6 +92,49 @@ class deferred_bn_updates:
             call('rv_bn_running_update', ptr(rm), ptr(rv), ptr(nbt), ptr(coef), c, BN_MOMENTUM, stream())
 
 
+_REPLAY_KEEP = []          # pinned host tables of captured replays must outlive their hipGraph
+_REPLAY_POOL = []          # pre-allocated pinned staging buffers for capture
+
+
+def replay_bn_updates(pendings, device):
+    """Apply the deferred BatchNorm updates of several passes -- `pendings`: deferred_bn_updates objects in the order of
+    the reference's update sequence (an object may appear twice) -- with ONE launch: per layer the updates are chained
+    in that order inside the kernel (rv_bn_running_update_table)."""
+    layers, order = {}, []
+    for pend in pendings:
+        for rm, rv, nbt, coef, c in pend.items:
+            key = ptr(rm)
+            if key not in layers:
+                layers[key] = [ptr(rm), ptr(rv), ptr(nbt) or 0, c, []]
+                order.append(key)
+            layers[key][4].append(ptr(coef))
+    if not order:
+        return
+    head, coefs = [], []
+    for key in order:
+        rm, rv, nbt, c, lst = layers[key]
+        head += [rm, rv, nbt, c, len(coefs), len(lst)]
+        coefs += lst
+    words = head + coefs
+    # pinned staging buffers are allocated ahead of time (no host allocation may happen under hipGraph capture); a
+    # captured copy node re-reads its buffer at every replay, so buffers used under capture are never recycled
+    capturing = torch.cuda.is_current_stream_capturing()
+    if capturing:
+        if not _REPLAY_POOL:
+            raise RuntimeError('replay_bn_updates: no pinned staging buffer left for hipGraph capture')
+        host = _REPLAY_POOL.pop()
+        _REPLAY_KEEP.append(host)
+        assert len(words) <= host.numel(), 'BatchNorm replay table larger than the staging buffer'
+        host[:len(words)] = torch.tensor(words, dtype=torch.int64)
+    else:
+        if len(_REPLAY_POOL) < 4:
+            _REPLAY_POOL.extend(torch.empty(4096, dtype=torch.int64).pin_memory() for _ in range(4))
+        host = torch.tensor(words, dtype=torch.int64).pin_memory()      # (the pinned allocator is stream-aware)
+    table = host[:len(words)].to(device, non_blocking=True)
+    call('rv_bn_running_update_table', ptr(table), len(order), BN_MOMENTUM, stream())
+    table.record_stream(torch.cuda.current_stream(device))
+
+
 
 class direct_param_grads:
     """Context manager: while active, conv / BatchNorm backward kernels ACCUMULATE their parameter gradients
