@@ -96,6 +96,12 @@ _REPLAY_KEEP = []          # pinned host tables of captured replays must outlive
 _REPLAY_POOL = []          # pre-allocated pinned staging buffers for capture
 
 
+def prepare_replay_pool(n=4):
+    """Pinned staging buffers for replay_bn_updates under hipGraph capture (call outside capture)."""
+    while len(_REPLAY_POOL) < n:
+        _REPLAY_POOL.append(torch.empty(4096, dtype=torch.int64).pin_memory())
+
+
 def replay_bn_updates(pendings, device):
     """Apply the deferred BatchNorm updates of several passes -- `pendings`: deferred_bn_updates objects in the order of
     the reference's update sequence (an object may appear twice) -- with ONE launch: per layer the updates are chained
@@ -127,8 +133,7 @@ def replay_bn_updates(pendings, device):
         assert len(words) <= host.numel(), 'BatchNorm replay table larger than the staging buffer'
         host[:len(words)] = torch.tensor(words, dtype=torch.int64)
     else:
-        if len(_REPLAY_POOL) < 4:
-            _REPLAY_POOL.extend(torch.empty(4096, dtype=torch.int64).pin_memory() for _ in range(4))
+        prepare_replay_pool()
         host = torch.tensor(words, dtype=torch.int64).pin_memory()      # (the pinned allocator is stream-aware)
     table = host[:len(words)].to(device, non_blocking=True)
     call('rv_bn_running_update_table', ptr(table), len(order), BN_MOMENTUM, stream())

@@ -176,6 +176,8 @@ class TrainStep:
         self.pack_plan = None
         self.dual_stream = dual_stream        # the two VAT chains on two HIP streams (model._vat_two_streams)
         self._dual_ready = False              # ... from the second step on: the first one packs weights and autotunes
+        if dual_stream and self.batch['audio'].is_cuda:
+            ops.prepare_replay_pool()
 
     def _fwd_bwd(self):
         self.opt.zero_grad()
