@@ -50,7 +50,35 @@ __global__ __launch_bounds__(256) void crop_label_k(CropArgs a) {
     const long o = (long)b * a.nlab;
     const float kv = 1.0f / 128.0f;
     const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.nlab; i += stride) {
+    // four labels per thread when everything is 4-byte (inputs) / 16-byte (outputs) aligned: one dword load, float4 stores
+    const bool vec = ((((uintptr_t)lab) | (vel ? (uintptr_t)vel : 0)) & 3) == 0 && ((o | a.nlab) & 3) == 0 &&
+                     (((uintptr_t)a.onset | (uintptr_t)a.frame | (uintptr_t)a.offset | (uintptr_t)a.out_velocity) & 15) == 0;
+    long done = 0;
+    if (vec) {
+        const long n4 = a.nlab >> 2;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            const unsigned l4 = *reinterpret_cast<const unsigned*>(lab + i * 4);
+            f32x4 on, of, fr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned l = (l4 >> (8 * q)) & 255u;
+                on[q] = l == 3 ? 1.f : 0.f;
+                of[q] = l == 1 ? 1.f : 0.f;
+                fr[q] = l > 1 ? 1.f : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(a.onset + o + i * 4) = on;
+            if (a.offset) *reinterpret_cast<f32x4*>(a.offset + o + i * 4) = of;
+            *reinterpret_cast<f32x4*>(a.frame + o + i * 4) = fr;
+            if (vel && a.out_velocity) {
+                const unsigned v4 = *reinterpret_cast<const unsigned*>(vel + i * 4);
+                *reinterpret_cast<f32x4*>(a.out_velocity + o + i * 4) =
+                    (f32x4){(float)(v4 & 255u) * kv, (float)((v4 >> 8) & 255u) * kv, (float)((v4 >> 16) & 255u) * kv,
+                            (float)(v4 >> 24) * kv};
+            }
+        }
+        done = n4 << 2;
+    }
+    for (long i = done + (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.nlab; i += stride) {
         const unsigned char l = lab[i];
         a.onset[o + i] = l == 3 ? 1.f : 0.f;
         if (a.offset) a.offset[o + i] = l == 1 ? 1.f : 0.f;
