@@ -102,3 +102,32 @@ def test_evaluate_wo_velocity_keys_and_perfect_score():
     assert abs(m['metric/note/f1'][0] - 1.0) < 1e-12 and abs(m['metric/frame/f1'][0] - 1.0) < 1e-9
     assert abs(m['metric/note-with-offsets/f1_2'][0] - 1.0) < 1e-12 and m['metric/frame/total_error'][0] == 0.0
     assert m['loss/test_frame'] == [0.25]
+
+
+def test_save_midi_roundtrip(tmp_path):
+    """reconvat_amd.midi.save_midi (reference model/midi.py:53-83 semantics): parse the bytes back."""
+    import struct
+    from reconvat_amd.midi import save_midi
+    from reconvat_amd.evaluate import midi_to_hz
+    pitches = midi_to_hz(np.array([60, 64, 67]))
+    intervals = np.array([[0.0, 0.5], [0.25, 1.0], [1.0, 1.032]])
+    path = tmp_path / 'x.mid'
+    save_midi(str(path), pitches, intervals, [127, 0.5, 1.0])
+    data = path.read_bytes()
+    assert data[:4] == b'MThd' and struct.unpack('>IHHH', data[4:14]) == (6, 1, 1, 480)
+    assert data[14:18] == b'MTrk'
+    n = struct.unpack('>I', data[18:22])[0]
+    body = data[22:22 + n]
+    assert len(data) == 22 + n and body[-4:] == b'\x00\xff\x2f\x00'
+    i, tick, events = 0, 0, []
+    while i < len(body) - 4:
+        d = 0
+        while True:
+            b = body[i]; i += 1
+            d = (d << 7) | (b & 0x7F)
+            if not b & 0x80:
+                break
+        tick += d
+        events.append((tick, body[i], body[i + 1], body[i + 2])); i += 3
+    assert events == [(0, 0x90, 60, 127), (240, 0x90, 64, 63), (480, 0x80, 60, 127), (960, 0x80, 64, 63),
+                      (960, 0x90, 67, 127), (990, 0x80, 67, 127)]
