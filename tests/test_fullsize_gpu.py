@@ -1,0 +1,118 @@
+"""BASELINE-size checks (B = 8 segments of 327 680 samples -> 640 frames x 229 mel) through size-independent
+properties, where a CPU reference would take minutes: linearity and adjointness of the convolutions, exact invariants of
+BatchNorm / softmax attention / the front-end normalisation / the VAT perturbation, and a checksum-of-checksums of the
+full U-Net against itself under a batch permutation."""
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+B, T, F = 8, 640, 229
+
+
+def _rand(*shape, seed, dev):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1).to(dev)
+
+
+@pytest.mark.parametrize('kind,cin,cout,h,w', [('c3', 16, 16, T, F), ('c3', 32, 32, T // 2, F // 2), ('t3', 192, 96, T // 8, F // 8),
+                                              ('c3', 1, 16, T, F), ('t3', 8, 2, T, F), ('c1', 16, 32, T // 2, F // 2),
+                                              ('down', 16, 16, T, F), ('up', 16, 16, T // 2, F // 2)])
+def test_conv_linearity_and_adjoint_full_size(dev, kind, cin, cout, h, w):
+    """conv(a x + b y) = a conv(x) + b conv(y) - (a + b - 1) bias, and <conv(x) - bias, v> = <x, dgrad(v)>, at the layer
+    shapes of the benchmark (forward, input-gradient and weight-gradient kernels on full-size tensors)."""
+    from reconvat_amd import ops
+    x, y = _rand(B, h, w, cin, seed=1, dev=dev), _rand(B, h, w, cin, seed=2, dev=dev)
+    wshape = {'c3': (cout, cin, 3, 3), 't3': (cin, cout, 3, 3), 'c1': (cout, cin, 1, 1), 'down': (cout, cin, 2, 2),
+              'up': (cin, cout, 2, 2)}[kind]
+    wt = (_rand(*wshape, seed=3, dev=dev) * 0.1).requires_grad_(True)
+    bias = _rand(cout, seed=4, dev=dev).requires_grad_(True)
+    size = (2 * h + 1, 2 * w + 1) if kind == 'up' else None
+    conv = lambda t: ops.ConvFn.apply(t, wt, bias, kind, size)
+    a, b = 0.75, -1.5
+    lhs = conv(a * x + b * y)
+    rhs = a * conv(x) + b * conv(y) - (a + b - 1) * bias
+    assert rel_err(lhs, rhs) < 2e-5
+    xg = x.clone().requires_grad_(True)
+    out = conv(xg)
+    v = _rand(*out.shape, seed=5, dev=dev)
+    (out * v).sum().backward()
+    lin = (out.detach() - bias.detach()).double()
+    dot1 = (lin * v.double()).sum()
+    dot2 = (x.double() * xg.grad.double()).sum()
+    assert abs(float(dot1 - dot2)) <= 2e-5 * max(abs(float(dot1)), float(lin.abs().max()) * 1e3)
+    # weight gradient: <conv_w(x) , v> is linear in w  ->  <w, dw> = <conv(x) - bias, v>
+    dotw = (wt.detach().double() * wt.grad.double()).sum()
+    assert abs(float(dotw - dot1)) <= 1e-4 * max(abs(float(dot1)), 1.0)
+    assert rel_err(bias.grad, v.reshape(-1, cout).double().sum(0).float()) < 1e-5
+
+
+def test_batchnorm_invariants_full_size(dev):
+    from reconvat_amd import ops
+    for c, h, w in ((16, T, F), (128, T // 8, F // 8)):
+        z = (_rand(B, h, w, c, seed=6, dev=dev) * 3 + 0.7).requires_grad_(True)
+        g, b = torch.ones(c, device=dev, requires_grad=True), torch.zeros(c, device=dev, requires_grad=True)
+        rm, rv, nbt = torch.zeros(c, device=dev), torch.ones(c, device=dev), torch.zeros((), dtype=torch.long, device=dev)
+        y = ops.BnActFn.apply(z, g, b, rm, rv, nbt, None, True, 1.0)         # slope 1: plain batch norm
+        yd = y.detach().double().reshape(-1, c)
+        assert float(yd.mean(0).abs().max()) < 1e-5 and float((yd.var(0, unbiased=False) - 1).abs().max()) < 1e-4
+        zd = z.detach().double().reshape(-1, c)
+        assert rel_err(rm, (0.1 * zd.mean(0)).float()) < 1e-5
+        assert rel_err(rv, (0.9 + 0.1 * zd.var(0, unbiased=True)).float()) < 1e-5
+        # the input gradient of a batch norm is orthogonal to 1 and to the normalised activations, per channel
+        (y * _rand(*y.shape, seed=7, dev=dev)).sum().backward()
+        gd = z.grad.double().reshape(-1, c)
+        scale = float(gd.abs().max()) * gd.shape[0]
+        assert float(gd.sum(0).abs().max()) < 1e-5 * scale and float((gd * yd).sum(0).abs().max()) < 1e-5 * scale
+
+
+def test_attention_rows_and_shift_equivariance_full_size(dev):
+    from reconvat_amd import ops
+    f, g, fin = 768, 6, 176
+    x = _rand(B, T, fin, seed=8, dev=dev)
+    w = [_rand(f, fin, seed=9 + i, dev=dev) * 0.05 for i in range(3)]
+    rel = _rand(1, f, 31, seed=12, dev=dev)
+    out, att = ops.LocalAttnFn.apply(x, w[0], w[1], w[2], rel, g)
+    assert float((att.double().sum(-1) - 1).abs().max()) < 1e-5 and float(att.min()) >= 0
+    # frames far from the clip edges only see their 31-frame window: shifting the clip shifts the output
+    out2, _ = ops.LocalAttnFn.apply(torch.roll(x, 5, dims=1), w[0], w[1], w[2], rel, g)
+    assert rel_err(out2[:, 40:600], torch.roll(out, 5, dims=1)[:, 40:600]) < 1e-5
+
+
+def test_frontend_and_vat_invariants_full_size(dev):
+    import reconvat_amd as ra
+    from reconvat_amd import ops
+    m = ra.UNet_Onset((2, 2), (2, 2), log=True, reconstruction=False, mode='imagewise', spec='Mel', XI=1e-6, eps=2).to(dev)
+    audio = _rand(B, 327680, seed=13, dev=dev) * 0.1
+    spec = m._front(audio, 327680)
+    assert spec.shape == (B, 1, T, F)
+    flat = spec.reshape(B, -1)
+    assert torch.equal(flat.min(1).values, torch.zeros(B, device=dev)) and torch.equal(flat.max(1).values, torch.ones(B, device=dev))
+    # scaling the audio shifts the log-mel by a constant, which the per-clip min-max normalisation removes
+    spec2 = m._front(audio * 0.5, 327680)
+    assert rel_err(spec2, spec) < 2e-3                      # (the +1e-5 inside the log is not scale-free)
+    d = _rand(*spec.shape, seed=14, dev=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    x_adv, r_adv, d_norm = ops.vat_adversarial(spec, d, 1e10, 2.0, flag)
+    rn = r_adv.norm(dim=-1)
+    assert torch.allclose(rn, torch.full_like(rn, 2.0), rtol=1e-5) and int(flag.item()) == 0
+    assert float(x_adv.min()) >= 0 and float(x_adv.max()) <= 1
+    assert torch.allclose(d_norm.norm(dim=-1), torch.ones_like(rn), rtol=1e-5)
+
+
+def test_unet_batch_permutation_full_size(dev):
+    """The transcriber at full size: per-sample outputs do not depend on the position in the batch (train-mode BatchNorm
+    statistics are permutation invariant), and the batch checksum is reproduced."""
+    import reconvat_amd as ra
+    torch.manual_seed(3)
+    m = ra.UNet_Onset((2, 2), (2, 2), log=True, reconstruction=False, mode='imagewise', spec='Mel', XI=1e-6, eps=2).to(dev)
+    m.train()
+    x = torch.rand(B, 1, T, F, generator=torch.Generator().manual_seed(5)).to(dev)
+    perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device=dev)
+    with torch.no_grad():
+        roll, onset, att = m.transcriber(x)
+        roll_p, onset_p, att_p = m.transcriber(x[perm])
+    assert rel_err(roll_p, roll[perm]) < 1e-4 and rel_err(onset_p, onset[perm]) < 1e-4
+    assert abs(float(roll.double().sum() - roll_p.double().sum())) < 1e-4 * float(roll.double().sum())
+    assert roll.shape == (B, T, 88) and att.shape == (B, T, 6, 31)
