@@ -244,6 +244,9 @@ def main():
                 'launches_per_step': nlaunch, 'conv_ms_per_step': round(conv_ms, 3),
                 'executed_gflop_per_step': round(conv_flops_total / 1e9, 1),
                 'reference_gflop_per_step': 1531.0,
+                # SURVEY 8(d) counts the reference's conv work (1 531 GFLOP incl. the weight gradients of the power
+                # iteration that this build provably does not need); `frac` above credits only what was executed
+                'frac_counting_reference_work': round(1531.0e9 / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                 'top': [{'ms_per_step': round(t, 3), 'count': c, 'ms': round(m, 4), 'tflops': round(tf, 1), 'sig': list(map(str, s))}
                         for t, c, m, tf, s in per_kernel[:6]],
             }
