@@ -137,6 +137,35 @@ int rv_crop_segments(const short* audio, const unsigned char* label, const unsig
                      const long* label_begin, int B, long seq_len, int n_steps, int n_keys, float* out_audio, float* onset,
                      float* offset, float* frame, float* out_velocity, void* stream);
 
+/* ---- Onsets&Frames baseline pieces (model/onset_frame_VAT.py:321-415,603-635) -------------------------------------
+ * Bidirectional one-layer nn.LSTM(batch_first=True) recurrence (the `sequence_model` of Onset_Stack / Combine_Stack,
+ * model/onset_frame_VAT.py:614,370-381,401-410).  The caller computes the input projections of every step with rv_gemm:
+ *   xg [B,T,2,4H] = x W_ih^T + b_ih + b_hh   (direction-major halves, PyTorch gate order i,f,g,o)
+ * and this entry runs the T sequential steps of both directions in ONE persistent launch (W_hh [4H,H] per direction held
+ * in registers as MFMA operands, h exchanged through `out`, per-workgroup step counters in `flags`).
+ * out [B,T,2H] (forward half | reverse half, as nn.LSTM returns it); gates [B,T,2,4,H] (activated) and cs [B,T,2,H]
+ * are saved for the backward pass (both NULL = inference).  flags: rv_lstm_flag_bytes(H) bytes of device scratch, reset by
+ * the call itself; the last int is non-zero afterwards if a workgroup gave up waiting (co-residency violated).
+ * B <= 8; H in {384, 32}.  rv_lstm_bwd: dout [B,T,2H] -> dxg [B,T,2,4H]; dW_ih, dW_hh, db and dx are GEMMs / column sums
+ * of dxg done by the caller. */
+long rv_lstm_flag_bytes(int H);
+int rv_lstm_fwd(const float* xg, const float* whh_fwd, const float* whh_rev, float* out, float* gates, float* cs, int* flags,
+                int B, int T, int H, void* stream);
+int rv_lstm_bwd(const float* dout, const float* whh_fwd, const float* whh_rev, const float* gates, const float* cs, float* dxg,
+                int* flags, int B, int T, int H, void* stream);
+
+/* nn.MaxPool2d((1,2)) over the frequency axis of an NHWC tensor x [rows, W, C] -> y [rows, W/2, C] fused with the
+ * nn.Dropout(p) that follows it in ConvStack (model/onset_frame_VAT.py:336-343; p = 0 disables the drop).  code
+ * [rows, W/2, C] bytes: bit 0 = the odd column was the max, bit 1 = kept.  Kept values are scaled by 1/(1-p). */
+int rv_maxpool_w2_dropout_fwd(const float* x, float* y, unsigned char* code, long rows, int W, int C, float p, unsigned seed,
+                              void* stream);
+int rv_maxpool_w2_dropout_bwd(const float* dy, const unsigned char* code, float* dx, long rows, int W, int C, float p,
+                              void* stream);
+/* nn.Dropout(p) (model/onset_frame_VAT.py:346-348).  Forward: code_in NULL, code_out receives the keep mask.  Backward:
+ * pass the saved mask as code_in (seed unused) and dy as x. */
+int rv_dropout(const float* x, float* y, unsigned char* code_out, const unsigned char* code_in, long n, float p, unsigned seed,
+               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

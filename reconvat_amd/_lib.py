@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RECONVAT_HIP_LIB') or os.path.join(_HERE, 'libreconvat_hip.so')
 
 P = ctypes.c_void_p
+U = ctypes.c_uint
 I = ctypes.c_int
 L = ctypes.c_long
 F = ctypes.c_float
@@ -49,6 +50,12 @@ SIGNATURES = {
     'rv_counter_add': (I, [P, L, P]),
     'rv_clip_scale': (I, [P, L, P, F, P]),
     'rv_crop_segments': (I, [P, P, P, P, P, I, L, I, I, P, P, P, P, P, P]),
+    'rv_lstm_flag_bytes': (L, [I]),
+    'rv_lstm_fwd': (I, [P, P, P, P, P, P, P, I, I, I, P]),
+    'rv_lstm_bwd': (I, [P, P, P, P, P, P, P, I, I, I, P]),
+    'rv_maxpool_w2_dropout_fwd': (I, [P, P, P, L, I, I, F, U, P]),
+    'rv_maxpool_w2_dropout_bwd': (I, [P, P, P, L, I, I, F, P]),
+    'rv_dropout': (I, [P, P, P, P, L, F, U, P]),
 }
 
 _lib = None

@@ -1474,6 +1474,7 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
             RV_SMALL(1, 16, 3, 3, 1, 1) RV_SMALL(16, 1, 3, 3, 1, 1)
             RV_SMALL(8, 2, 3, 3, 1, 1)  RV_SMALL(2, 8, 3, 3, 1, 1)
             RV_SMALL(8, 1, 3, 3, 1, 1)  RV_SMALL(1, 8, 3, 3, 1, 1)
+            RV_SMALL(1, 48, 3, 3, 1, 1) RV_SMALL(48, 1, 3, 3, 1, 1)      // ConvStack layer 0 (model/onset_frame_VAT.py:328)
         } else if (mode == 1) {
             RV_SMALL(1, 16, 1, 1, 1, 0) RV_SMALL(16, 1, 1, 1, 1, 0)
         }
@@ -1568,7 +1569,12 @@ static WgradPlan wgrad_plan(int taps, int B, int Hv, int Ca, int Cb) {
 }
 
 // Workspace (bytes) rv_conv_wgrad needs for the given problem.
+// a one-channel input against a wide dY (ConvStack layer 0, 1 -> 48) runs as Cb/16 launches of the (1, 16) VALU kernel on
+// 16-channel slices of dY
+static inline bool wgrad_sliced(int taps, int Ca, int Cb) { return taps == 9 && Ca == 1 && Cb > 16 && Cb % 16 == 0; }
+
 long rv_conv_wgrad_workspace_bytes(int taps, int B, int Hv, int Ca, int Cb) {
+    if (wgrad_sliced(taps, Ca, Cb)) Cb = 16;
     WgradPlan p = wgrad_plan(taps, B, Hv, Ca, Cb);
     return (long)p.nparts * ((long)taps * Ca * Cb + Cb) * 4;
 }
@@ -1582,6 +1588,14 @@ int rv_conv_wgrad(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, co
     hipStream_t st = (hipStream_t)stream;
     RV_CHECK_ARG(mode >= 0 && mode <= 2, "rv_conv_wgrad: bad mode %d", mode);
     const int taps = mode == 0 ? 9 : (mode == 1 ? 1 : 4);
+    if (wgrad_sliced(taps, Ca, Cb)) {
+        for (int c0 = 0; c0 < Cb; c0 += 16) {
+            const int rc = rv_conv_wgrad(mode, U, u_ld, Hu, Wu, Ca, V + c0, v_ld, Hv, Wv, 16, B, dw + c0 * s_b, s_a, s_b, flip,
+                                         dbias ? dbias + c0 : nullptr, accumulate, workspace, workspace_bytes, stream);
+            if (rc != RV_OK) return rc;
+        }
+        return RV_OK;
+    }
     WgradArgs a;
     a.U = U; a.u_ld = u_ld; a.Hu = Hu; a.Wu = Wu; a.Ca = Ca; a.V = V; a.v_ld = v_ld; a.Hv = Hv; a.Wv = Wv; a.Cb = Cb;
     a.B = B; a.want_bias = dbias != nullptr;

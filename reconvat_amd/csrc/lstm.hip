@@ -1,0 +1,323 @@
+// Bidirectional LSTM recurrence and the ConvStack pooling/dropout pieces of the Onsets&Frames baseline, gfx950.
+//
+// Reference anchors:
+//   nn.LSTM(input, H, batch_first=True, bidirectional=True) ..... model/onset_frame_VAT.py:614 (sequence_model)
+//   Onset_Stack.forward_LSTM / Combine_Stack.forward_LSTM ........ model/onset_frame_VAT.py:370-381,401-410
+//   nn.MaxPool2d((1, 2)) + nn.Dropout(0.25) ...................... model/onset_frame_VAT.py:336-343
+//   nn.Dropout(0.5) behind the ConvStack's Linear ................ model/onset_frame_VAT.py:346-348
+//
+// The input projections x W_ih^T + b_ih + b_hh of all time steps are one MFMA GEMM (rv_gemm) done by the caller; the
+// kernels here run only the sequential part.  One persistent launch covers both directions and all T steps:
+//   * direction d, workgroup j owns hidden units [16 j, 16 j + 16).  Its slice of W_hh stays in VGPRs for the whole
+//     sequence (H/4 registers per lane), laid out as the A operand of v_mfma_f32_16x16x4_f32;
+//   * per step the workgroup stages h_{t-1} (B x H) into LDS, issues H/4 MFMAs per wave (batch on the N side), applies
+//     the gate non-linearities in the accumulator layout (a lane ends up with the four gates of one (unit, batch)
+//     cell), writes h_t into the output tensor -- which is also the exchange buffer for the next step -- and
+//     publishes a per-workgroup step counter;
+//   * workgroups of one direction synchronise through those counters (release/acquire at agent scope); nothing else
+//     is shared.  All 2*H/16 workgroups must be co-resident, which 256 CUs guarantee for H <= 1024.
+// The backward kernel is the same machine run over W_hh^T with the K = 4H reduction split over the four waves.
+#include "common.h"
+
+#define LSTM_SPIN_LIMIT (1 << 22)
+
+struct LstmArgs {
+    const float* xg;        // fwd: [B,T,2,4H] gate pre-activations from the input GEMM; bwd: unused
+    const float* whh[2];    // [4H, H] per direction (gate order i, f, g, o)
+    float* out;             // fwd: [B,T,2H] hidden states
+    float* gates;           // [B,T,2,4,H] activated gates (saved by fwd, read by bwd)
+    float* cs;              // [B,T,2,H] cell states
+    const float* dout;      // bwd: [B,T,2H]
+    float* dxg;             // bwd: [B,T,2,4H] gradient wrt xg
+    int* flags;             // [2][H/16] step counters + [1] error word, zeroed by the host wrapper
+    int B, T;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// wait until every workgroup of this direction has published step >= s; wave 0 polls, one counter per lane
+template <int NWG>
+__device__ __forceinline__ void wait_step(int* flag, int* err, int s, int tid) {
+    if (tid < NWG) {
+        int spins = 0;
+        while (__hip_atomic_load(&flag[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < s) {
+            if (++spins > LSTM_SPIN_LIMIT) { atomicOr(err, 1); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void lstm_fwd_k(LstmArgs a) {
+    constexpr int NC = H / 16, NWG = H / 16, LDH = H + 4;
+    static_assert(NWG <= 64, "one polling lane per workgroup");
+    const int d = blockIdx.x / NWG, j = blockIdx.x - d * NWG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+    const int B = a.B, T = a.T;
+    __shared__ __attribute__((aligned(16))) float hs[8][LDH];
+    int* flag = a.flags + d * NWG;
+    int* err = a.flags + 2 * NWG;
+
+    // A operand: row li <-> (unit ubase + li/4, gate li%4); lane holds k = 16c + 4g + {0..3} of that row
+    const int ubase = j * 16 + wave * 4;
+    f32x4 wreg[NC];
+    {
+        const float* wrow = a.whh[d] + ((long)(li & 3) * H + ubase + (li >> 2)) * H + 4 * g;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) wreg[c] = *reinterpret_cast<const f32x4*>(wrow + 16 * c);
+    }
+    const int unit = ubase + g, b = li;
+    const bool cell = b < B;
+    float cstate = 0.f;
+    for (int s = 0; s < T; ++s) {
+        const int t = d ? T - 1 - s : s;
+        const long cellbase = (((long)b * T + t) * 2 + d) * 4 * H + unit;
+        float pre[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cell) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pre[i] = a.xg[cellbase + (long)i * H];
+        }
+        if (s > 0) {
+            wait_step<NWG>(flag, err, s, tid);
+            const int tp = d ? t + 1 : t - 1;
+            for (int idx = tid; idx < B * (H / 4); idx += 256) {
+                const int bb = idx / (H / 4), k4 = idx - bb * (H / 4);
+                *reinterpret_cast<f32x4*>(&hs[bb][4 * k4]) =
+                    *reinterpret_cast<const f32x4*>(a.out + ((long)bb * T + tp) * 2 * H + d * H + 4 * k4);
+            }
+            __syncthreads();
+            f32x4 acc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const f32x4 hb = *reinterpret_cast<const f32x4*>(&hs[li & 7][16 * c + 4 * g]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[c][q], hb[q], acc[q], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pre[i] += (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
+        }
+        if (cell) {
+            const float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), gg = tanhf(pre[2]), go = sigmoidf_(pre[3]);
+            cstate = fmaf(gf, cstate, gi * gg);
+            const float h = go * tanhf(cstate);
+            a.out[((long)b * T + t) * 2 * H + d * H + unit] = h;
+            if (a.gates) {
+                a.gates[cellbase] = gi; a.gates[cellbase + H] = gf; a.gates[cellbase + 2 * H] = gg; a.gates[cellbase + 3 * H] = go;
+                a.cs[(((long)b * T + t) * 2 + d) * H + unit] = cstate;
+            }
+        }
+        __syncthreads();      // every wave's h_t stores are issued and complete (workgroup-scope release) ...
+        if (tid == 0) __hip_atomic_store(&flag[j], s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... and published
+    }
+}
+
+// Backward through time.  Step s handles t = (d ? s : T-1-s); the recurrent term of dh_t is W_hh^T dpre_{t'} with t' the
+// step handled just before.  Wave w reduces over gate block w (k = w*H .. w*H+H-1); the four partial 16x16 tiles are
+// added through LDS and threads 0..127 (unit, batch) do the cell arithmetic.
+template <int H>
+__global__ __launch_bounds__(256) void lstm_bwd_k(LstmArgs a) {
+    constexpr int NC = H / 16, NWG = H / 16, LDD = 4 * H + 4;
+    const int d = blockIdx.x / NWG, j = blockIdx.x - d * NWG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+    const int B = a.B, T = a.T;
+    __shared__ __attribute__((aligned(16))) float ds[8][LDD];
+    __shared__ float part[4][16][8];
+    int* flag = a.flags + d * NWG;
+    int* err = a.flags + 2 * NWG;
+
+    // A operand: row li <-> unit 16j + li; k <-> W_hh row w*H + 16c + 4g + {0..3}
+    float wreg[NC][4];
+    {
+        const float* wcol = a.whh[d] + ((long)wave * H + 4 * g) * H + j * 16 + li;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wreg[c][q] = wcol[(long)(16 * c + q) * H];
+    }
+    const int unit = j * 16 + (tid >> 3), b = tid & 7;
+    const bool cell = tid < 128 && b < B;
+    float dc_carry = 0.f;
+    for (int s = 0; s < T; ++s) {
+        const int t = d ? s : T - 1 - s;
+        const int tfp = d ? t + 1 : t - 1;           // the step the forward pass ran before t (c_{prev})
+        const long cellbase = (((long)b * T + t) * 2 + d) * 4 * H + unit;
+        float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, ct = 0.f, cp = 0.f, dh = 0.f;
+        if (cell) {
+            gi = a.gates[cellbase]; gf = a.gates[cellbase + H]; gg = a.gates[cellbase + 2 * H]; go = a.gates[cellbase + 3 * H];
+            ct = a.cs[(((long)b * T + t) * 2 + d) * H + unit];
+            cp = (tfp >= 0 && tfp < T) ? a.cs[(((long)b * T + tfp) * 2 + d) * H + unit] : 0.f;
+            dh = a.dout[((long)b * T + t) * 2 * H + d * H + unit];
+        }
+        if (s > 0) {
+            wait_step<NWG>(flag, err, s, tid);
+            const int tn = d ? t - 1 : t + 1;        // handled in the previous iteration
+            for (int idx = tid; idx < B * H; idx += 256) {
+                const int bb = idx / H, k4 = idx - bb * H;
+                *reinterpret_cast<f32x4*>(&ds[bb][4 * k4]) =
+                    *reinterpret_cast<const f32x4*>(a.dxg + (((long)bb * T + tn) * 2 + d) * 4 * H + 4 * k4);
+            }
+            __syncthreads();
+            f32x4 acc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const f32x4 db = *reinterpret_cast<const f32x4*>(&ds[li & 7][wave * H + 16 * c + 4 * g]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[c][q], db[q], acc[q], 0, 0, 0);
+            }
+            if (li < 8) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) part[wave][4 * g + i][li] = (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
+            }
+            __syncthreads();
+            if (cell) dh += (part[0][tid >> 3][b] + part[1][tid >> 3][b]) + (part[2][tid >> 3][b] + part[3][tid >> 3][b]);
+        }
+        if (cell) {
+            const float th = tanhf(ct);
+            const float d_o = dh * th;
+            const float dc = fmaf(dh * go, 1.f - th * th, dc_carry);
+            const float d_i = dc * gg, d_g = dc * gi, d_f = dc * cp;
+            dc_carry = dc * gf;
+            a.dxg[cellbase] = d_i * gi * (1.f - gi);
+            a.dxg[cellbase + H] = d_f * gf * (1.f - gf);
+            a.dxg[cellbase + 2 * H] = d_g * (1.f - gg * gg);
+            a.dxg[cellbase + 3 * H] = d_o * go * (1.f - go);
+        }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&flag[j], s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+extern "C" long rv_lstm_flag_bytes(int H) { return (long)(2 * (H / 16) + 1) * sizeof(int); }
+
+static int lstm_check(int B, int T, int H) {
+    RV_CHECK_ARG(B >= 1 && B <= 8, "rv_lstm: batch %d not in 1..8 (one 16-wide MFMA column tile, 8 staged rows)", B);
+    RV_CHECK_ARG(T >= 1, "rv_lstm: T=%d", T);
+    RV_CHECK_ARG(H == 384 || H == 32, "rv_lstm: hidden size %d not instantiated (384, 32)", H);
+    return RV_OK;
+}
+
+extern "C" int rv_lstm_fwd(const float* xg, const float* whh_fwd, const float* whh_rev, float* out, float* gates, float* cs,
+                           int* flags, int B, int T, int H, hipStream_t st) {
+    if (int rc = lstm_check(B, T, H)) return rc;
+    RV_CHECK_ARG(xg && whh_fwd && whh_rev && out && flags, "rv_lstm_fwd: null pointer");
+    RV_CHECK_ARG((gates == nullptr) == (cs == nullptr), "rv_lstm_fwd: gates and cs are saved together");
+    LstmArgs a = {};
+    a.xg = xg; a.whh[0] = whh_fwd; a.whh[1] = whh_rev; a.out = out; a.gates = gates; a.cs = cs; a.flags = flags; a.B = B; a.T = T;
+    if (hipMemsetAsync(flags, 0, rv_lstm_flag_bytes(H), st) != hipSuccess) { rv_set_error("rv_lstm_fwd: memset failed"); return RV_ELAUNCH; }
+    dim3 grid(2 * (H / 16)), blk(256);
+    if (H == 384) hipLaunchKernelGGL((lstm_fwd_k<384>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((lstm_fwd_k<32>), grid, blk, 0, st, a);
+    RV_LAUNCH_CHECK("lstm_fwd");
+    return RV_OK;
+}
+
+extern "C" int rv_lstm_bwd(const float* dout, const float* whh_fwd, const float* whh_rev, const float* gates, const float* cs,
+                           float* dxg, int* flags, int B, int T, int H, hipStream_t st) {
+    if (int rc = lstm_check(B, T, H)) return rc;
+    RV_CHECK_ARG(dout && whh_fwd && whh_rev && gates && cs && dxg && flags, "rv_lstm_bwd: null pointer");
+    LstmArgs a = {};
+    a.dout = dout; a.whh[0] = whh_fwd; a.whh[1] = whh_rev; a.gates = const_cast<float*>(gates); a.cs = const_cast<float*>(cs);
+    a.dxg = dxg; a.flags = flags; a.B = B; a.T = T;
+    if (hipMemsetAsync(flags, 0, rv_lstm_flag_bytes(H), st) != hipSuccess) { rv_set_error("rv_lstm_bwd: memset failed"); return RV_ELAUNCH; }
+    dim3 grid(2 * (H / 16)), blk(256);
+    if (H == 384) hipLaunchKernelGGL((lstm_bwd_k<384>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((lstm_bwd_k<32>), grid, blk, 0, st, a);
+    RV_LAUNCH_CHECK("lstm_bwd");
+    return RV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool2d((1,2)) over the frequency axis of an NHWC tensor fused with the Dropout that follows it, and a plain
+// Dropout.  keep-mask from a counter hash of (seed, element index): the backward pass recomputes nothing, it reads the
+// one-byte code the forward wrote (bit 0: the odd column won the max, bit 1: kept).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned hash32(unsigned x, unsigned seed) {
+    x ^= seed; x *= 0x9E3779B1u; x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ bool keep_draw(long idx, unsigned seed, float p) {
+    const unsigned h = hash32((unsigned)idx, seed ^ (unsigned)(idx >> 32) * 0x27D4EB2Fu);
+    return (h >> 8) * (1.0f / 16777216.0f) >= p;
+}
+
+__global__ __launch_bounds__(256) void pool_drop_fwd_k(const float* x, float* y, unsigned char* code, long rows, int W, int Wo, int C,
+                                                       float p, float scale, unsigned seed) {
+    const long n = rows * Wo * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long rw = i / C;
+        const int wo = (int)(rw % Wo);
+        const long r = rw / Wo;
+        const float* src = x + ((r * W + 2 * wo) * (long)C + c);
+        const float v0 = src[0], v1 = src[C];
+        const bool odd = v1 > v0;
+        const bool keep = p <= 0.f || keep_draw(i, seed, p);
+        y[i] = keep ? (odd ? v1 : v0) * scale : 0.f;
+        code[i] = (unsigned char)((odd ? 1 : 0) | (keep ? 2 : 0));
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_drop_bwd_k(const float* dy, const unsigned char* code, float* dx, long rows, int W, int Wo,
+                                                       int C, float scale) {
+    const long n = rows * W * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long rw = i / C;
+        const int w = (int)(rw % W);
+        const long r = rw / W;
+        const int wo = w >> 1;
+        float v = 0.f;
+        if (wo < Wo) {
+            const long o = (r * Wo + wo) * (long)C + c;
+            const unsigned char cd = code[o];
+            if ((cd & 2) && (cd & 1) == (w & 1)) v = dy[o] * scale;
+        }
+        dx[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void dropout_k(const float* x, float* y, unsigned char* code, const unsigned char* code_in, long n,
+                                                 float p, float scale, unsigned seed) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const bool keep = code_in ? (code_in[i] != 0) : (p <= 0.f || keep_draw(i, seed, p));
+        y[i] = keep ? x[i] * scale : 0.f;
+        if (code) code[i] = keep ? 1 : 0;
+    }
+}
+
+static inline int ew_grid(long n) { long g = (n + 255) / 256; return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
+
+// x [rows, W, C] -> y [rows, W/2, C]; p: drop probability of the Dropout behind the pool (0 = none)
+extern "C" int rv_maxpool_w2_dropout_fwd(const float* x, float* y, unsigned char* code, long rows, int W, int C, float p, unsigned seed,
+                                         hipStream_t st) {
+    RV_CHECK_ARG(x && y && code && rows >= 0 && W >= 2 && C >= 1 && p >= 0.f && p < 1.f, "rv_maxpool_w2_dropout_fwd: bad arguments");
+    const int Wo = W / 2;
+    if (rows == 0) return RV_OK;
+    hipLaunchKernelGGL(pool_drop_fwd_k, dim3(ew_grid(rows * Wo * C)), dim3(256), 0, st, x, y, code, rows, W, Wo, C, p, 1.0f / (1.0f - p), seed);
+    RV_LAUNCH_CHECK("pool_drop_fwd");
+    return RV_OK;
+}
+
+extern "C" int rv_maxpool_w2_dropout_bwd(const float* dy, const unsigned char* code, float* dx, long rows, int W, int C, float p,
+                                         hipStream_t st) {
+    RV_CHECK_ARG(dy && dx && code && rows >= 0 && W >= 2 && C >= 1 && p >= 0.f && p < 1.f, "rv_maxpool_w2_dropout_bwd: bad arguments");
+    if (rows == 0) return RV_OK;
+    hipLaunchKernelGGL(pool_drop_bwd_k, dim3(ew_grid(rows * W * C)), dim3(256), 0, st, dy, code, dx, rows, W, W / 2, C, 1.0f / (1.0f - p));
+    RV_LAUNCH_CHECK("pool_drop_bwd");
+    return RV_OK;
+}
+
+// forward: code_out receives the keep mask; backward: pass the saved mask as code_in (seed is then ignored) and dy as x
+extern "C" int rv_dropout(const float* x, float* y, unsigned char* code_out, const unsigned char* code_in, long n, float p, unsigned seed,
+                          hipStream_t st) {
+    RV_CHECK_ARG(x && y && n >= 0 && p >= 0.f && p < 1.f, "rv_dropout: bad arguments");
+    if (n == 0) return RV_OK;
+    hipLaunchKernelGGL(dropout_k, dim3(ew_grid(n)), dim3(256), 0, st, x, y, code_out, code_in, n, p, 1.0f / (1.0f - p), seed);
+    RV_LAUNCH_CHECK("dropout");
+    return RV_OK;
+}

@@ -967,3 +967,131 @@ def melspec(audio, tables, do_log, normalise, hop=512):
          ptr(tables['mel_start']), ptr(tables['mel_len']), ptr(tables['mel_w']), tables['mel_w'].shape[1], n_mels, hop,
          1 if do_log else 0, 1 if normalise else 0, ptr(out), t, ptr(ws), stream())
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# Onsets&Frames baseline pieces: BiLSTM, MaxPool2d((1,2)) + Dropout, Dropout
+# --------------------------------------------------------------------------------------------
+_SEED = [0x1234567]
+
+
+def next_seed():
+    """Counter-hash seed of the next dropout draw (deterministic per process; ``seed_dropout`` resets it)."""
+    _SEED[0] = (_SEED[0] * 1664525 + 1013904223) & 0xFFFFFFFF
+    return _SEED[0]
+
+
+def seed_dropout(seed):
+    _SEED[0] = int(seed) & 0xFFFFFFFF
+
+
+class BiLstmFn(Function):
+    """nn.LSTM(I, H, batch_first=True, bidirectional=True)(x)[0] with zero initial state
+    (model/onset_frame_VAT.py:614; Onset_Stack.forward_LSTM :370-381, Combine_Stack.forward_LSTM :401-410).
+    Parameter order: forward direction (w_ih [4H,I], w_hh [4H,H], b_ih, b_hh) then the ``_reverse`` four."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+        need_gpu(x, w_ih)
+        bb, t, i = x.shape
+        h = w_hh.shape[1]
+        x2 = x.reshape(bb * t, i)
+        xg = torch.empty((bb * t, 2, 4 * h), device=x.device, dtype=torch.float32)
+        gemm(x2, w_ih.t(), xg[:, 0, :], b_ih + b_hh)
+        gemm(x2, w_ih_r.t(), xg[:, 1, :], b_ih_r + b_hh_r)
+        out = torch.empty((bb, t, 2 * h), device=x.device, dtype=torch.float32)
+        train = any(ctx.needs_input_grad)
+        gates = torch.empty((bb, t, 2, 4, h), device=x.device, dtype=torch.float32) if train else None
+        cs = torch.empty((bb, t, 2, h), device=x.device, dtype=torch.float32) if train else None
+        flags = torch.empty(_lib.load().rv_lstm_flag_bytes(h) // 4, device=x.device, dtype=torch.int32)
+        w_hh, w_hh_r = w_hh.contiguous(), w_hh_r.contiguous()
+        call('rv_lstm_fwd', ptr(xg), ptr(w_hh), ptr(w_hh_r), ptr(out), ptr(gates), ptr(cs), ptr(flags), bb, t, h, stream())
+        ctx.params = (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
+        ctx.save_for_backward(x2, out, gates, cs, w_ih, w_hh, w_ih_r, w_hh_r)
+        ctx.dims = (bb, t, i, h)
+        ctx.flags = flags
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, out, gates, cs, w_ih, w_hh, w_ih_r, w_hh_r = ctx.saved_tensors
+        bb, t, i, h = ctx.dims
+        dout = dout.contiguous()
+        dxg = torch.empty((bb * t, 2, 4 * h), device=dout.device, dtype=torch.float32)
+        call('rv_lstm_bwd', ptr(dout), ptr(w_hh), ptr(w_hh_r), ptr(gates), ptr(cs), ptr(dxg), ptr(ctx.flags), bb, t, h, stream())
+        # h_{prev} of every step: the output shifted by one step along each direction's own time arrow
+        hprev = torch.zeros((bb, t, 2, h), device=dout.device, dtype=torch.float32)
+        o4 = out.view(bb, t, 2, h)
+        hprev[:, 1:, 0] = o4[:, :-1, 0]
+        hprev[:, :-1, 1] = o4[:, 1:, 1]
+        hprev = hprev.view(bb * t, 2, h)
+        grads = [None] * 9
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((bb * t, i), device=dout.device, dtype=torch.float32)
+            gemm(dxg[:, 0, :], w_ih, dx)
+            gemm(dxg[:, 1, :], w_ih_r, dx, accumulate=True)
+            grads[0] = dx.view(bb, t, i)
+        for d, base in ((0, 1), (1, 5)):
+            dz = dxg[:, d, :]
+            p_ih, p_hh, p_bi, p_bh = ctx.params[base - 1:base + 3]
+            if ctx.needs_input_grad[base]:
+                grads[base] = _param_wgrad(dz.t(), x2, p_ih, _splitk_for(4 * h, i, bb * t))
+            if ctx.needs_input_grad[base + 1]:
+                grads[base + 1] = _param_wgrad(dz.t(), hprev[:, d, :], p_hh, _splitk_for(4 * h, h, bb * t))
+            if ctx.needs_input_grad[base + 2]:
+                grads[base + 2] = _param_bgrad(dz, p_bi)
+            if ctx.needs_input_grad[base + 3]:
+                grads[base + 3] = _param_bgrad(dz, p_bh)
+        return tuple(grads)
+
+
+class PoolDropFn(Function):
+    """nn.MaxPool2d((1,2)) then nn.Dropout(p) on an NHWC tensor (model/onset_frame_VAT.py:336-343)."""
+
+    @staticmethod
+    def forward(ctx, x, p, training):
+        need_gpu(x)
+        x = x.contiguous()
+        bb, hh, w, c = x.shape
+        y = torch.empty((bb, hh, w // 2, c), device=x.device, dtype=torch.float32)
+        code = torch.empty((bb, hh, w // 2, c), device=x.device, dtype=torch.uint8)
+        p = float(p) if training else 0.0
+        call('rv_maxpool_w2_dropout_fwd', ptr(x), ptr(y), ptr(code), bb * hh, w, c, p, next_seed(), stream())
+        ctx.p, ctx.xshape = p, tuple(x.shape)
+        ctx.save_for_backward(code)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        code, = ctx.saved_tensors
+        bb, hh, w, c = ctx.xshape
+        dx = torch.empty(ctx.xshape, device=dy.device, dtype=torch.float32)
+        call('rv_maxpool_w2_dropout_bwd', ptr(dy.contiguous()), ptr(code), ptr(dx), bb * hh, w, c, ctx.p, stream())
+        return dx, None, None
+
+
+class DropoutFn(Function):
+    """nn.Dropout(p) in training mode (model/onset_frame_VAT.py:346-348)."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        need_gpu(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        code = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+        call('rv_dropout', ptr(x), ptr(y), ptr(code), None, x.numel(), float(p), next_seed(), stream())
+        ctx.p = float(p)
+        ctx.save_for_backward(code)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        code, = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        call('rv_dropout', ptr(dy), ptr(dx), None, ptr(code), dy.numel(), ctx.p, 0, stream())
+        return dx, None
+
+
+def dropout(x, p, training):
+    return DropoutFn.apply(x, p) if (training and p > 0.0) else x
