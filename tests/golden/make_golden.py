@@ -26,6 +26,7 @@ import _refload  # noqa: E402
 from oracle import fixture as fx  # noqa: E402
 from oracle import frontend as ofe  # noqa: E402
 from oracle import model as om  # noqa: E402
+from oracle import onset_frames as oo  # noqa: E402
 
 torch.set_num_threads(8)
 ref = _refload.load_reference()
@@ -409,9 +410,113 @@ def g_decoding():
     save('decoding', **out)
 
 
+def build_onf(training=True, xi=1e-6, eps=1e-1):
+    """The reference's Onsets&Frames baseline (model/onset_frame_VAT.py:603) on the oracle's fixture weights, with the
+    drop probability of its nn.Dropout instances set to 0 on the INSTANCES (random masks have no golden value)."""
+    net = ref.OnsetsAndFrames_VAT_full(229, 88, model_complexity=48, log=True, mode='imagewise', spec='Mel', XI=xi, eps=eps)
+    params = oo.fixture_params()
+    net.load_state_dict(params, strict=True)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    net.train(training)
+    return net, fx.clone_params(params)
+
+
+def g_onset_frames():
+    out = {}
+    real_randn_like = torch.randn_like
+    x = fx.fixture_spec(2, 64, 'onf_spec').squeeze(1)
+    # forward / backward of the network proper, train and eval mode
+    for training in (True, False):
+        net, params = build_onf(training)
+        o_r, a_r, f_r = net(x)
+        o_o, a_o, f_o = oo.forward(params, training, x)
+        for nm, a, b in (('onset', o_o, o_r), ('act', a_o, a_r), ('frame', f_o, f_r)):
+            close(a, b, 2e-5, f'onf {nm} t{int(training)}')
+            out[f'fwd_t{int(training)}_{nm}'] = b
+        if training:
+            gy = [fx.hashed(f'onf_gy{i}', tuple(o_r.shape), 1.0) for i in range(3)]
+            (o_r * gy[0] + a_r * gy[1] + f_r * gy[2]).sum().backward()
+            sd = net.state_dict()
+            for k in sd:
+                if 'running' in k:
+                    close(params[k], sd[k], 1e-5, k)
+                    out['bn:' + k] = sd[k].clone()
+            for k in params:
+                if params[k].dtype == torch.float32 and not k.startswith('spectrogram') and 'running' not in k:
+                    params[k].requires_grad_(True)
+            o_o, a_o, f_o = oo.forward(params, True, x)
+            (o_o * gy[0] + a_o * gy[1] + f_o * gy[2]).sum().backward()
+            named = dict(net.named_parameters())
+            gmax = max(p.grad.abs().max().item() for p in named.values())
+            for k, p in named.items():
+                err = (params[k].grad - p.grad).abs().max().item()
+                assert err <= 2e-3 * p.grad.abs().max().item() + 1e-5 * gmax, ('onf grad ' + k, err)
+                out['grad:' + k] = digest(p.grad, 48)
+            out['gmax'] = gmax
+    # stepwise VAT with injected noise: well-conditioned (XI=1e-1) and the script's own (XI=1e-6, eps=1e-1)
+    for tag, xi, eps in (('wc', 1e-1, 2.0), ('real', 1e-6, 1e-1)):
+        net, params = build_onf(True, xi, eps)
+        d0 = fx.fixture_noise(x.shape, 'onf_d0')
+        grabbed = {}
+
+        def fake(t, **kw):
+            d = d0.clone()
+            if kw.get('requires_grad'):
+                d.requires_grad_(True)
+            grabbed['d'] = d
+            return d
+        torch.randn_like = fake
+        try:
+            lds, r_adv, dn = net.vat_loss(net, x)
+        finally:
+            torch.randn_like = real_randn_like
+        lo, ro, dno, go = oo.vat(params, True, x, xi, eps, d0)
+        close(lo, lds, 1e-3, 'onf lds ' + tag)
+        out[f'vat_{tag}_lds'] = lds.item()
+        out[f'vat_{tag}_rnorm'] = dn.abs().mean().item()
+        out[f'vat_{tag}_radv_rownorm'] = r_adv.norm(dim=-1).flatten()[:8]
+        if tag == 'wc':
+            close(go, grabbed['d'].grad, 1e-3, 'onf d.grad'); close(ro, r_adv, 1e-3, 'onf r_adv')
+            out['vat_wc_g'] = grabbed['d'].grad
+            out['vat_wc_radv'] = r_adv
+        print('onf vat', tag, 'cos(r_adv ref, oracle) =', F.cosine_similarity(ro.flatten(), r_adv.flatten(), dim=0).item())
+    # run_on_batch: every (VAT, mode) combination the scripts reach
+    for vat in (False, True):
+        for training in (True, False):
+            net, params = build_onf(training, 1e-6, 1e-1)
+            bl, bul = _batch(2, 64, 'L'), _batch(2, 64, 'UL')
+            noises = [fx.fixture_noise((2, 64, 229), 'onf_d0_ul'), fx.fixture_noise((2, 64, 229), 'onf_d0_l')]
+            use_ul = vat and training
+            seq = list(noises if use_ul else noises[1:])
+
+            def fake(t, **kw):
+                d = seq.pop(0).clone()
+                return d.requires_grad_(True) if kw.get('requires_grad') else d
+            torch.randn_like = fake
+            try:
+                pr, lr, sr = net.run_on_batch(bl, bul if use_ul else None, vat)
+            finally:
+                torch.randn_like = real_randn_like
+            po, lo, so = oo.run_on_batch(params, training, bl, bul if use_ul else None, vat, 1e-6, 1e-1,
+                                         d0_l=noises[1], d0_ul=noises[0])
+            assert list(lo.keys()) == list(lr.keys()), (list(lo.keys()), list(lr.keys()))
+            key = f'rob_v{int(vat)}_t{int(training)}'
+            for k in lr:
+                close(lo[k], lr[k], 5e-3 if 'r_norm' in k else (1e-3 if 'LDS' in k else 2e-5), key + k)   # XI=1e-6: d.grad is near rounding noise, its direction (r_norm) is ill-conditioned
+            close(so, sr, 1e-6, 'onf spec')
+            close(po['frame'], pr['frame'], 2e-5, 'onf frame')
+            out[key + '_losses'] = np.array([v.item() for v in lr.values()])
+            out[key + '_keys'] = np.array(list(lr.keys()))
+            out[key + '_frame'] = digest(pr['frame'], 256)
+            out[key + '_onset'] = digest(pr['onset'], 256)
+    save('onset_frames', **out)
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['frontend', 'unet', 'attention', 'networks', 'vat', 'run_on_batch', 'train_step', 'dataset',
-                             'decoding']
+                             'decoding', 'onset_frames']
     for w in which:
         print('==', w)
         globals()['g_' + w]()
