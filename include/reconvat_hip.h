@@ -156,15 +156,17 @@ int rv_lstm_bwd(const float* dout, const float* whh_fwd, const float* whh_rev, c
 
 /* nn.MaxPool2d((1,2)) over the frequency axis of an NHWC tensor x [rows, W, C] -> y [rows, W/2, C] fused with the
  * nn.Dropout(p) that follows it in ConvStack (model/onset_frame_VAT.py:336-343; p = 0 disables the drop).  code
- * [rows, W/2, C] bytes: bit 0 = the odd column was the max, bit 1 = kept.  Kept values are scaled by 1/(1-p). */
+ * [rows, W/2, C] bytes: bit 0 = the odd column was the max, bit 1 = kept.  Kept values are scaled by 1/(1-p).  The mask is a
+ * counter hash of (seed, *epoch, index); epoch (nullable) is a device counter bumped per training step, which keeps the
+ * draws fresh when the launch is replayed from a hipGraph. */
 int rv_maxpool_w2_dropout_fwd(const float* x, float* y, unsigned char* code, long rows, int W, int C, float p, unsigned seed,
-                              void* stream);
+                              const long* epoch, void* stream);
 int rv_maxpool_w2_dropout_bwd(const float* dy, const unsigned char* code, float* dx, long rows, int W, int C, float p,
                               void* stream);
 /* nn.Dropout(p) (model/onset_frame_VAT.py:346-348).  Forward: code_in NULL, code_out receives the keep mask.  Backward:
  * pass the saved mask as code_in (seed unused) and dy as x. */
 int rv_dropout(const float* x, float* y, unsigned char* code_out, const unsigned char* code_in, long n, float p, unsigned seed,
-               void* stream);
+               const long* epoch, void* stream);
 
 #ifdef __cplusplus
 }

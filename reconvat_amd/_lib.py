@@ -53,9 +53,9 @@ SIGNATURES = {
     'rv_lstm_flag_bytes': (L, [I]),
     'rv_lstm_fwd': (I, [P, P, P, P, P, P, P, I, I, I, P]),
     'rv_lstm_bwd': (I, [P, P, P, P, P, P, P, I, I, I, P]),
-    'rv_maxpool_w2_dropout_fwd': (I, [P, P, P, L, I, I, F, U, P]),
+    'rv_maxpool_w2_dropout_fwd': (I, [P, P, P, L, I, I, F, U, P, P]),
     'rv_maxpool_w2_dropout_bwd': (I, [P, P, P, L, I, I, F, P]),
-    'rv_dropout': (I, [P, P, P, P, L, F, U, P]),
+    'rv_dropout': (I, [P, P, P, P, L, F, U, P, P]),
 }
 
 _lib = None

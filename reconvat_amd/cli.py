@@ -1,4 +1,5 @@
-"""Shared body of the two drop-in training entry points (train_UNet_Onset_VAT.py / train_UNet_VAT.py).
+"""Shared body of the drop-in training entry points (train_UNet_Onset_VAT.py / train_UNet_VAT.py /
+train_baseline_onset_frame_VAT.py).
 
 Keeps the reference CLI (`python train_UNet_Onset_VAT.py with key=value ...`, keys and defaults of
 train_UNet_Onset_VAT.py:28-78 / train_UNet_VAT.py:26-79) and loop semantics (:128-154): epochs of
@@ -63,6 +64,26 @@ def base_config(o, onset_script):
     return c
 
 
+def baseline_config(o):
+    """Config scope of train_baseline_onset_frame_VAT.py:25-73 (model_name='onset_frame' is the one on the MI355X path)."""
+    c = dict(
+        root='runs', onset_stack=True, device='cuda:0', log=True, w_size=31, model_complexity=48, spec='Mel',
+        resume_iteration=None, train_on='String', iteration=10, alpha=1, VAT=False, XI=1e-6, eps=1e-1, VAT_mode='all',
+        model_name='onset_frame', VAT_start=0, small=True, supersmall=False, batch_size=8, train_batch_size=8,
+        sequence_length=327680, epoches=20000, learning_rate=5e-4, learning_rate_decay_steps=10000,
+        learning_rate_decay_rate=0.98, leave_one_out=None, clip_gradient_norm=3, refresh=False, reconstruction=False,
+        graph=True, fused_optimizer=True, saving_freq=saving_freq, device_feed=True,
+    )
+    c.update(o)
+    if c['model_name'] != 'onset_frame':
+        raise NotImplementedError("only model_name='onset_frame' (OnsetsAndFrames_VAT_full) is built for MI355X")
+    if 'validation_length' not in o:
+        c['validation_length'] = c['sequence_length']
+    if 'logdir' not in o:
+        c['logdir'] = f"{c['root']}/baseline_Onset_Frame-" + datetime.now().strftime('%y%m%d-%H%M%S')
+    return c
+
+
 class ScalarLog:
     """TensorBoard SummaryWriter when available, else one JSON line per (tag, step)."""
 
@@ -85,7 +106,7 @@ class ScalarLog:
 def run_training(onset_script, spec, resume_iteration, train_on, batch_size, sequence_length, small, supersmall,
                  train_batch_size, learning_rate, learning_rate_decay_steps, learning_rate_decay_rate, alpha,
                  clip_gradient_norm, validation_length, refresh, device, epoches, logdir, log, iteration, VAT_start, VAT,
-                 XI, eps, reconstruction, graph, fused_optimizer, saving_freq, device_feed=True, **_unused):
+                 XI, eps, reconstruction, graph, fused_optimizer, saving_freq, device_feed=True, model_complexity=48, **_unused):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if world > 1:
@@ -109,9 +130,14 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
         ul_loader = DataLoader(ul_set, batch_size, shuffle=True, drop_last=True) if VAT else None
         l_loader = DataLoader(l_set, train_batch_size, shuffle=True, drop_last=True)
 
-    cls = UNet_Onset if onset_script else UNet
     torch.manual_seed(0)                                   # identical initial weights on every rank
-    model = cls(ds_ksize, ds_stride, log=log, reconstruction=reconstruction, mode=mode, spec=spec, device=device, XI=XI, eps=eps)
+    if onset_script == 'baseline':
+        from .onset_frames import OnsetsAndFrames_VAT_full as cls
+        from .constants import N_BINS, MAX_MIDI, MIN_MIDI
+        model = cls(N_BINS, MAX_MIDI - MIN_MIDI + 1, model_complexity=model_complexity, log=log, mode=mode, spec=spec, XI=XI, eps=eps)
+    else:
+        cls = UNet_Onset if onset_script else UNet
+        model = cls(ds_ksize, ds_stride, log=log, reconstruction=reconstruction, mode=mode, spec=spec, device=device, XI=XI, eps=eps)
     if resume_iteration is not None:
         sd = torch.load(os.path.join(logdir, f'model-{resume_iteration}.pt'), map_location='cpu')
         model.load_state_dict(sd)
@@ -168,7 +194,7 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
         with torch.no_grad():
             loader = DataLoader(val_set, 1, shuffle=False)
             metrics = evaluate_wo_velocity((b for i, b in enumerate(loader) if i < 4), model, reconstruction=reconstruction,
-                                           onset=onset_script, VAT=True)
+                                           onset=bool(onset_script), VAT=True)
         for key, values in sorted(metrics.items()):
             if key.startswith('metric/') and values:
                 writer.add_scalar('validation/' + key, float(np.mean(values)), epoches)

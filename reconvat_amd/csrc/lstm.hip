@@ -233,8 +233,9 @@ extern "C" int rv_lstm_bwd(const float* dout, const float* whh_fwd, const float*
 
 // ---------------------------------------------------------------------------------------------
 // MaxPool2d((1,2)) over the frequency axis of an NHWC tensor fused with the Dropout that follows it, and a plain
-// Dropout.  keep-mask from a counter hash of (seed, element index): the backward pass recomputes nothing, it reads the
-// one-byte code the forward wrote (bit 0: the odd column won the max, bit 1: kept).
+// Dropout.  keep-mask from a counter hash of (seed, *epoch, element index): the backward pass recomputes nothing, it reads
+// the one-byte code the forward wrote (bit 0: the odd column won the max, bit 1: kept).  `epoch` (nullable) is a DEVICE
+// counter the training step bumps once per iteration, so a launch replayed from a hipGraph still draws a new mask.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned hash32(unsigned x, unsigned seed) {
     x ^= seed; x *= 0x9E3779B1u; x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
@@ -246,7 +247,8 @@ __device__ __forceinline__ bool keep_draw(long idx, unsigned seed, float p) {
 }
 
 __global__ __launch_bounds__(256) void pool_drop_fwd_k(const float* x, float* y, unsigned char* code, long rows, int W, int Wo, int C,
-                                                       float p, float scale, unsigned seed) {
+                                                       float p, float scale, unsigned seed, const long* epoch) {
+    if (epoch) seed ^= (unsigned)(*epoch) * 0x9E3779B1u;
     const long n = rows * Wo * C;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const int c = (int)(i % C);
@@ -282,7 +284,8 @@ __global__ __launch_bounds__(256) void pool_drop_bwd_k(const float* dy, const un
 }
 
 __global__ __launch_bounds__(256) void dropout_k(const float* x, float* y, unsigned char* code, const unsigned char* code_in, long n,
-                                                 float p, float scale, unsigned seed) {
+                                                 float p, float scale, unsigned seed, const long* epoch) {
+    if (epoch) seed ^= (unsigned)(*epoch) * 0x9E3779B1u;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const bool keep = code_in ? (code_in[i] != 0) : (p <= 0.f || keep_draw(i, seed, p));
         y[i] = keep ? x[i] * scale : 0.f;
@@ -294,11 +297,11 @@ static inline int ew_grid(long n) { long g = (n + 255) / 256; return (int)(g > 8
 
 // x [rows, W, C] -> y [rows, W/2, C]; p: drop probability of the Dropout behind the pool (0 = none)
 extern "C" int rv_maxpool_w2_dropout_fwd(const float* x, float* y, unsigned char* code, long rows, int W, int C, float p, unsigned seed,
-                                         hipStream_t st) {
+                                         const long* epoch, hipStream_t st) {
     RV_CHECK_ARG(x && y && code && rows >= 0 && W >= 2 && C >= 1 && p >= 0.f && p < 1.f, "rv_maxpool_w2_dropout_fwd: bad arguments");
     const int Wo = W / 2;
     if (rows == 0) return RV_OK;
-    hipLaunchKernelGGL(pool_drop_fwd_k, dim3(ew_grid(rows * Wo * C)), dim3(256), 0, st, x, y, code, rows, W, Wo, C, p, 1.0f / (1.0f - p), seed);
+    hipLaunchKernelGGL(pool_drop_fwd_k, dim3(ew_grid(rows * Wo * C)), dim3(256), 0, st, x, y, code, rows, W, Wo, C, p, 1.0f / (1.0f - p), seed, epoch);
     RV_LAUNCH_CHECK("pool_drop_fwd");
     return RV_OK;
 }
@@ -314,10 +317,10 @@ extern "C" int rv_maxpool_w2_dropout_bwd(const float* dy, const unsigned char* c
 
 // forward: code_out receives the keep mask; backward: pass the saved mask as code_in (seed is then ignored) and dy as x
 extern "C" int rv_dropout(const float* x, float* y, unsigned char* code_out, const unsigned char* code_in, long n, float p, unsigned seed,
-                          hipStream_t st) {
+                          const long* epoch, hipStream_t st) {
     RV_CHECK_ARG(x && y && n >= 0 && p >= 0.f && p < 1.f, "rv_dropout: bad arguments");
     if (n == 0) return RV_OK;
-    hipLaunchKernelGGL(dropout_k, dim3(ew_grid(n)), dim3(256), 0, st, x, y, code_out, code_in, n, p, 1.0f / (1.0f - p), seed);
+    hipLaunchKernelGGL(dropout_k, dim3(ew_grid(n)), dim3(256), 0, st, x, y, code_out, code_in, n, p, 1.0f / (1.0f - p), seed, epoch);
     RV_LAUNCH_CHECK("dropout");
     return RV_OK;
 }

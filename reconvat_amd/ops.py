@@ -161,7 +161,7 @@ SIDE_GRADS = [None]
 
 
 def _grad_buf(t):
-    if not (_DIRECT[0] and t is not None and t.requires_grad and t.grad is not None):
+    if not (_DIRECT[0] and t is not None and t.is_leaf and t.requires_grad and t.grad is not None):
         return None
     sg = SIDE_GRADS[0]
     if sg is not None and DUAL_STREAM[0]:
@@ -985,6 +985,23 @@ def seed_dropout(seed):
     _SEED[0] = int(seed) & 0xFFFFFFFF
 
 
+_DROP_EPOCH = {}
+
+
+def drop_epoch(device):
+    """Device-resident step counter mixed into every dropout draw: TrainStep bumps it inside the (possibly graph-captured)
+    step, so replays of a captured dropout launch draw new masks."""
+    key = (device.type, device.index)
+    t = _DROP_EPOCH.get(key)
+    if t is None:
+        t = _DROP_EPOCH[key] = torch.zeros(1, dtype=torch.int64, device=device)
+    return t
+
+
+def bump_drop_epoch(device):
+    call('rv_counter_add', ptr(drop_epoch(device)), 1, stream())
+
+
 class BiLstmFn(Function):
     """nn.LSTM(I, H, batch_first=True, bidirectional=True)(x)[0] with zero initial state
     (model/onset_frame_VAT.py:614; Onset_Stack.forward_LSTM :370-381, Combine_Stack.forward_LSTM :401-410).
@@ -1056,7 +1073,7 @@ class PoolDropFn(Function):
         y = torch.empty((bb, hh, w // 2, c), device=x.device, dtype=torch.float32)
         code = torch.empty((bb, hh, w // 2, c), device=x.device, dtype=torch.uint8)
         p = float(p) if training else 0.0
-        call('rv_maxpool_w2_dropout_fwd', ptr(x), ptr(y), ptr(code), bb * hh, w, c, p, next_seed(), stream())
+        call('rv_maxpool_w2_dropout_fwd', ptr(x), ptr(y), ptr(code), bb * hh, w, c, p, next_seed(), ptr(drop_epoch(x.device)), stream())
         ctx.p, ctx.xshape = p, tuple(x.shape)
         ctx.save_for_backward(code)
         return y
@@ -1079,7 +1096,7 @@ class DropoutFn(Function):
         x = x.contiguous()
         y = torch.empty_like(x)
         code = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
-        call('rv_dropout', ptr(x), ptr(y), ptr(code), None, x.numel(), float(p), next_seed(), stream())
+        call('rv_dropout', ptr(x), ptr(y), ptr(code), None, x.numel(), float(p), next_seed(), ptr(drop_epoch(x.device)), stream())
         ctx.p = float(p)
         ctx.save_for_backward(code)
         return y
@@ -1089,7 +1106,7 @@ class DropoutFn(Function):
         code, = ctx.saved_tensors
         dy = dy.contiguous()
         dx = torch.empty_like(dy)
-        call('rv_dropout', ptr(dy), ptr(dx), None, ptr(code), dy.numel(), ctx.p, 0, stream())
+        call('rv_dropout', ptr(dy), ptr(dx), None, ptr(code), dy.numel(), ctx.p, 0, None, stream())
         return dx, None
 
 

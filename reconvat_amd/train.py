@@ -182,6 +182,7 @@ class TrainStep:
     def _fwd_bwd(self):
         self.opt.zero_grad()
         ops.ARENA.begin_step(self.opt.flat_grad.device)
+        ops.bump_drop_epoch(self.opt.flat_grad.device)
         prev_dual, prev_side = ops.DUAL_STREAM[0], ops.SIDE_GRADS[0]
         dual = self.dual_stream and self._dual_ready and self.batch_ul is not None and self.VAT
         ops.DUAL_STREAM[0] = dual

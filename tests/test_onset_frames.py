@@ -213,3 +213,62 @@ def test_training_mode_dropout_runs(dev):
     g = gold()
     assert torch.isfinite(lo['loss/train_frame'])
     assert abs(float(lo['loss/train_frame']) - g['rob_v0_t1_losses'][0]) > 1e-6
+
+
+@pytest.mark.gpu
+def test_train_step_graph_equals_eager(dev):
+    """TrainStep (FlatAdam bucket, direct parameter gradients, VAT on both groups) captured into a hipGraph gives the
+    losses and gradients of the eager step (dropout off: deterministic); compared before the optimiser step."""
+    import reconvat_amd as ra
+    from oracle import fixture as fx
+    bl = {k: v.to(dev) for k, v in _batch(2, 64, 'L').items()}
+    bul = {k: v.to(dev) for k, v in _batch(2, 64, 'UL').items()}
+    res = []
+    for graph in (False, True):
+        m = build(dev, True)
+        opt = ra.FlatAdam(m.parameters(), lr=5e-4)
+        d = [fx.fixture_noise((2, 64, 229), 'onf_d0_ul').to(dev), fx.fixture_noise((2, 64, 229), 'onf_d0_l').to(dev)]
+        state = {'i': 0}
+
+        def noise(t, d=d, state=state):
+            state['i'] += 1
+            return d[state['i'] % 2].clone()
+        m.vat_loss.noise = noise
+        step = ra.TrainStep(m, opt, bl, bul, VAT=True, graph=graph, dual_stream=False)
+        if graph:
+            step.capture()
+            step.graph.replay()
+        else:
+            m.train()
+            step._fwd_bwd()
+            step._fwd_bwd()
+        torch.cuda.synchronize()
+        res.append((float(step.loss), {k: float(v) for k, v in step.losses.items()}, opt.flat_grad.clone()))
+    (l0, ls0, g0), (l1, ls1, g1) = res
+    assert set(ls0) == {'loss/train_frame', 'loss/train_onset', 'loss/train_LDS_l', 'loss/train_LDS_ul', 'loss/train_r_norm_l',
+                        'loss/train_r_norm_ul'}
+    for k in ls0:
+        assert abs(ls0[k] - ls1[k]) <= (5e-3 if 'r_norm' in k else 1e-4) * max(abs(ls0[k]), 1e-6), (k, ls0[k], ls1[k])
+    assert torch.isfinite(g0).all() and g0.abs().max() > 0
+    assert rel_err(g1, g0) < 3e-2       # BN running statistics differ by the warm-up count; ReLU/pool mask flips (see above)
+
+
+@pytest.mark.gpu
+def test_graph_replay_draws_new_dropout_masks(dev):
+    """The dropout seed is a launch argument frozen at capture time; the device-side epoch counter TrainStep bumps inside
+    the captured step keeps the masks changing from replay to replay."""
+    import reconvat_amd as ra
+    from oracle import onset_frames as oo
+    from reconvat_amd.onset_frames import OnsetsAndFrames_VAT_full
+    m = OnsetsAndFrames_VAT_full(229, 88).to(dev)
+    m.load_state_dict(oo.fixture_params())
+    bl = {k: v.to(dev) for k, v in _batch(2, 64, 'L').items()}
+    opt = ra.FlatAdam(m.parameters(), lr=0.0)           # frozen weights: only the masks can change the loss
+    step = ra.TrainStep(m, opt, bl, None, VAT=False, graph=True, dual_stream=False)
+    step.capture()
+    seen = []
+    for _ in range(3):
+        step.graph.replay()
+        torch.cuda.synchronize()
+        seen.append(float(step.losses['loss/train_frame']))
+    assert len(set(seen)) == 3, seen
