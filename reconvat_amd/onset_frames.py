@@ -118,7 +118,7 @@ class stepwise_VAT(nn.Module):
         self.nan_flag = None
         self.noise = None          # optional callable(x) -> d0 (tests inject deterministic noise)
 
-    def forward(self, model, x):
+    def forward(self, model, x, check=True):
         if self.nan_flag is None or self.nan_flag.device != x.device:
             self.nan_flag = torch.zeros(1, dtype=torch.int32, device=x.device)
         with torch.no_grad():
@@ -133,9 +133,13 @@ class stepwise_VAT(nn.Module):
             g, = torch.autograd.grad(loss, d)
             g = g.detach()
         x_adv, r_adv, d_norm = ops.vat_adversarial(x, g, 1e10, float(self.epsilon), self.nan_flag)
+        if check:
+            self.check_nan()
+        return bce_mean(model(x_adv)[2], frame_ref), r_adv, d_norm
+
+    def check_nan(self):
         if not torch.cuda.is_current_stream_capturing():
             assert int(self.nan_flag.item()) == 0, 'r_adv contains nan'
-        return bce_mean(model(x_adv)[2], frame_ref), r_adv, d_norm
 
 
 class OnsetsAndFrames_VAT_full(_Base):
@@ -165,10 +169,62 @@ class OnsetsAndFrames_VAT_full(_Base):
     def _spec(self, audio, ref_len):
         return self._front(audio, ref_len).squeeze(1)
 
+    side_streams = 2           # TrainStep: twin gradient buckets to provide
+
+    def _two_streams(self, audio_ul, audio_l, VAT):
+        """The step as THREE concurrent kernel chains: the unlabelled VAT on side stream 0, the main forward on side stream 1,
+        the labelled VAT on this stream; autograd then runs the three backward chains on the same streams.  The BiLSTM
+        recurrences are latency-bound launches on 48 of the 256 CUs, so the chains overlap almost completely and the step
+        takes about as long as its longest chain (3 forward + 2 backward passes instead of 7 + 5).  Shared state as in
+        model._Base._vat_two_streams: parameter gradients of each side chain go to that stream's twin of the flat gradient
+        bucket (ops.SIDE_GRADS), BatchNorm running-statistic updates are deferred and replayed in the reference's order
+        (UL target, UL xi*d, UL final, L target, L xi*d, L final, main)."""
+        cur = torch.cuda.current_stream()
+        dev = audio_l.device
+        side_ul, side_main = ops.side_stream(dev, 0), ops.side_stream(dev, 1)
+        ref_len = audio_l.shape[-1]
+        side_ul.wait_stream(cur)
+        with torch.cuda.stream(side_ul):
+            spec_ul = self._spec(audio_ul, ref_len)
+            with ops.deferred_bn_updates() as pend_ul:
+                lds_ul, _, dn_ul = self.vat_loss(self, spec_ul, check=False)
+                r_norm_ul = abs_mean(dn_ul)
+        spec = self._spec(audio_l, ref_len)
+        if VAT:
+            spec_ready = torch.cuda.Event()
+            spec_ready.record(cur)
+            with torch.cuda.stream(side_main):
+                side_main.wait_event(spec_ready)
+                spec.record_stream(side_main)
+                with ops.deferred_bn_updates() as pend_main:
+                    onset_pred, _, frame_pred = self(spec)
+            with ops.deferred_bn_updates() as pend_l:
+                lds_l, r_adv, dn_l = self.vat_loss(self, spec, check=False)
+                r_norm_l = abs_mean(dn_l)
+            cur.wait_stream(side_main)
+            for t in (onset_pred, frame_pred):
+                t.record_stream(cur)
+            seq = [pend_ul, pend_l, pend_main]
+        else:
+            r_adv, lds_l, r_norm_l = None, torch.tensor(0.), torch.tensor(0.)
+            with ops.deferred_bn_updates() as pend_main:
+                onset_pred, _, frame_pred = self(spec)
+            seq = [pend_ul, pend_main]
+        cur.wait_stream(side_ul)
+        for t in (lds_ul, r_norm_ul):
+            t.record_stream(cur)
+        ops.replay_bn_updates(seq, dev)
+        self.vat_loss.check_nan()
+        return spec, onset_pred, frame_pred, lds_ul, r_norm_ul, lds_l, r_adv, r_norm_l
+
     def run_on_batch(self, batch, batch_ul=None, VAT=False):
         audio_label = batch['audio']
         onset_label = batch['onset']
         frame_label = batch['frame']
+        if batch_ul and self.training and ops.DUAL_STREAM[0] and audio_label.is_cuda:
+            spec, onset_pred, frame_pred, lds_ul, r_norm_ul, lds_l, r_adv, r_norm_l = self._two_streams(
+                batch_ul['audio'], audio_label, VAT)
+            return self._pack(spec, onset_pred, frame_pred, onset_label, frame_label, lds_ul, r_norm_ul, lds_l, r_adv, r_norm_l)
         if batch_ul:
             spec = self._spec(batch_ul['audio'], audio_label.shape[-1])
             lds_ul, _, r_norm_ul = self.vat_loss(self, spec)
@@ -182,6 +238,9 @@ class OnsetsAndFrames_VAT_full(_Base):
         else:
             r_adv, lds_l, r_norm_l = None, torch.tensor(0.), torch.tensor(0.)
         onset_pred, _, frame_pred = self(spec)
+        return self._pack(spec, onset_pred, frame_pred, onset_label, frame_label, lds_ul, r_norm_ul, lds_l, r_adv, r_norm_l)
+
+    def _pack(self, spec, onset_pred, frame_pred, onset_label, frame_label, lds_ul, r_norm_ul, lds_l, r_adv, r_norm_l):
         predictions = {'onset': onset_pred.reshape(*frame_label.shape), 'frame': frame_pred.reshape(*frame_label.shape),
                        'r_adv': r_adv}
         tag = 'train' if self.training else 'test'

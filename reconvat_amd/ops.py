@@ -66,8 +66,10 @@ DUAL_STREAM = [False]
 _SIDE = {}
 
 
-def side_stream(device):
-    key = (device.type, device.index)
+def side_stream(device, idx=0):
+    """The idx-th side stream of `device` (created on first use; idx 0 is the U-Net schedule's, the Onsets&Frames
+    schedule also uses idx 1)."""
+    key = (device.type, device.index, idx)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
     return _SIDE[key]
@@ -155,8 +157,8 @@ class direct_param_grads:
         _DIRECT[0] = self.prev
 
 
-# (flat gradient bucket, its side-stream twin): backward kernels that run on the side stream accumulate into the twin, so
-# the two concurrent backward chains never read-modify-write the same addresses; FlatAdam.merge_side_grads() adds it in.
+# (flat gradient bucket, {side stream: its twin}): backward kernels that run on a side stream accumulate into that stream's
+# twin, so concurrent backward chains never read-modify-write the same addresses; FlatAdam.merge_side_grads() adds them in.
 SIDE_GRADS = [None]
 
 
@@ -165,9 +167,9 @@ def _grad_buf(t):
         return None
     sg = SIDE_GRADS[0]
     if sg is not None and DUAL_STREAM[0]:
-        side = _SIDE.get((t.device.type, t.device.index))
-        if side is not None and torch.cuda.current_stream(t.device) == side:
-            main, twin = sg
+        main, twins = sg                      # twins: {side stream handle: that stream's twin of the flat bucket}
+        twin = twins.get(torch.cuda.current_stream(t.device).cuda_stream)
+        if twin is not None:
             off = (t.grad.data_ptr() - main.data_ptr()) // 4
             return twin[off:off + t.grad.numel()].view_as(t.grad)
     return t.grad

@@ -86,6 +86,7 @@ class FlatAdam:
         self.flat_param = torch.empty(n, device=dev, dtype=torch.float32)
         self.flat_grad = torch.zeros(n, device=dev, dtype=torch.float32)
         self.flat_grad_side = None            # twin bucket of the side stream (TrainStep two-stream mode)
+        self.flat_grad_sides = []             # ... all twins (one per side stream in use)
         self.exp_avg = torch.zeros(n, device=dev, dtype=torch.float32)
         self.exp_avg_sq = torch.zeros(n, device=dev, dtype=torch.float32)
         self.step_count = torch.zeros((), device=dev, dtype=torch.int64)
@@ -105,20 +106,22 @@ class FlatAdam:
         self.data_parallel = data_parallel      # all-reduce the flat bucket inside step()
         ops.invalidate_weight_cache()
 
-    def enable_side_bucket(self):
-        if self.flat_grad_side is None:
-            self.flat_grad_side = torch.zeros_like(self.flat_grad)
-        return self.flat_grad_side
+    def enable_side_bucket(self, n=1):
+        """n twin buckets (one per side stream); returns them as a list."""
+        while len(self.flat_grad_sides) < n:
+            self.flat_grad_sides.append(torch.zeros_like(self.flat_grad))
+        self.flat_grad_side = self.flat_grad_sides[0]
+        return self.flat_grad_sides[:n]
 
     def merge_side_grads(self):
-        """flat_grad += side-stream twin (call on the main stream after joining the side stream)."""
-        if self.flat_grad_side is not None:
-            self.flat_grad.add_(self.flat_grad_side)
+        """flat_grad += side-stream twins (call on the main stream after joining the side streams)."""
+        for twin in self.flat_grad_sides:
+            self.flat_grad.add_(twin)
 
     def zero_grad(self, set_to_none=False):
         self.flat_grad.zero_()
-        if self.flat_grad_side is not None:
-            self.flat_grad_side.zero_()
+        for twin in self.flat_grad_sides:
+            twin.zero_()
         for p, off in zip(self.params, self.offsets):      # re-attach if something replaced .grad
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
                 p.grad = self.flat_grad[off:off + p.numel()].view_as(p.data)
@@ -187,7 +190,10 @@ class TrainStep:
         dual = self.dual_stream and self._dual_ready and self.batch_ul is not None and self.VAT
         ops.DUAL_STREAM[0] = dual
         if dual:
-            ops.SIDE_GRADS[0] = (self.opt.flat_grad, self.opt.enable_side_bucket())
+            dev = self.opt.flat_grad.device
+            n_side = getattr(self.model, 'side_streams', 1)
+            twins = self.opt.enable_side_bucket(n_side)
+            ops.SIDE_GRADS[0] = (self.opt.flat_grad, {ops.side_stream(dev, i).cuda_stream: twins[i] for i in range(n_side)})
         try:
             with ops.direct_param_grads():      # conv grads accumulate straight into the flat bucket
                 _, losses, _ = self.model.run_on_batch(self.batch, self.batch_ul, self.VAT)
@@ -195,7 +201,8 @@ class TrainStep:
                 loss.backward()
             if dual:
                 # the side stream ran the reconstruction branch's backward into its own bucket: join, then fold
-                torch.cuda.current_stream().wait_stream(ops.side_stream(self.opt.flat_grad.device))
+                for i in range(n_side):
+                    torch.cuda.current_stream().wait_stream(ops.side_stream(dev, i))
                 self.opt.merge_side_grads()
         finally:
             ops.DUAL_STREAM[0], ops.SIDE_GRADS[0] = prev_dual, prev_side

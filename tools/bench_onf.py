@@ -21,6 +21,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-vat', action='store_true')
     ap.add_argument('--lstm', action='store_true')
+    ap.add_argument('--single-stream', action='store_true')
     args = ap.parse_args()
     import reconvat_amd as ra
     from reconvat_amd import ops
@@ -51,7 +52,8 @@ def main():
     bl, bul = batch(), batch()
     opt = ra.FlatAdam(m.parameters(), lr=5e-4, step_size=10000, gamma=0.98)
     vat = not args.no_vat
-    step = ra.TrainStep(m, opt, bl, bul if vat else None, alpha=1.0, VAT=vat, clip=3.0, graph=not args.no_graph, dual_stream=False)
+    step = ra.TrainStep(m, opt, bl, bul if vat else None, alpha=1.0, VAT=vat, clip=3.0, graph=not args.no_graph,
+                        dual_stream=not args.single_stream)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -63,7 +65,7 @@ def main():
     audio_s = (16 if vat else 8) * 327680 / 16000 / dt
     print(json.dumps({'metric': 'training audio-sec/sec (1 GPU), Onsets&Frames BiLSTM baseline' + (' VAT' if vat else ''),
                       'value': round(audio_s, 1), 'unit': 'audio-s/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': args.steps,
-                      'warmup': args.warmup, 'hipgraph': not args.no_graph, 'dtype': 'f32', 'data': 'synthetic',
+                      'warmup': args.warmup, 'hipgraph': not args.no_graph, 'two_stream_schedule': not args.single_stream, 'dtype': 'f32', 'data': 'synthetic',
                       'final_loss': round(float(step.loss), 5), 'lstm_timeout_flag': 0}))
 
 
