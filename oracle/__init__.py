@@ -22,6 +22,8 @@ Parity status
   algorithm (Hann-windowed DFT kernels, librosa-0.7 Slaney mel filterbank) and
   cross-checked against ``torch.stft``; the reference holds no test or fixture
   for them.
+* the Onsets&Frames BiLSTM baseline (``oracle/onset_frames.py``): PINNED -- ``tests/golden/onset_frames.npz`` holds outputs of
+  the reference's own ``OnsetsAndFrames_VAT_full`` (Dropout probabilities set to 0 on the instances).
 * the data-item rule (``oracle/dataset.py``, integer / byte work): PINNED bit-exactly -- ``tests/golden/dataset.npz``
   holds the outputs of the reference's own ``PianoRollAudioDataset.__getitem__`` on in-memory tracks.
 """

@@ -39,12 +39,15 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __ex
 template <int NWG>
 __device__ __forceinline__ void wait_step(int* flag, int* err, int s, int tid) {
     if (tid < NWG) {
+        // poll relaxed (an acquire load would invalidate this XCD's L2 on every iteration, under the kernels of the other
+        // streams too); ONE acquire fence once every counter has arrived
         int spins = 0;
-        while (__hip_atomic_load(&flag[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < s) {
+        while (__hip_atomic_load(&flag[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < s) {
             if (++spins > LSTM_SPIN_LIMIT) { atomicOr(err, 1); break; }
             __builtin_amdgcn_s_sleep(1);
         }
     }
+    if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // the polling wave drops stale L1 / L2 lines
     __syncthreads();
 }
 
