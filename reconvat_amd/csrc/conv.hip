@@ -1084,19 +1084,22 @@ __global__ __launch_bounds__(256) void wgrad_small_k(WgradArgs a) {
         for (int ky = 0; ky < KH; ++ky)
 #pragma unroll
             for (int kx = 0; kx < KW; ++kx) {
+                // branch-free taps (out-of-image taps read pixel 0 and select zero): the loads of all taps of a pixel can be in
+                // flight together -- this kernel is bound by the loads in flight per wave (1->16: 67 -> 43 us).  The forward
+                // kernel conv_small_k measured slower this way and keeps its early-outs.
                 int iy = y * S - P + ky, ix = x * S - P + kx;
-                if ((unsigned)iy >= (unsigned)a.Hu || (unsigned)ix >= (unsigned)a.Wu) continue;
-                const float* up = a.U + (((long)b * a.Hu + iy) * a.Wu + ix) * a.u_ld + a_off;
+                const bool inside = (unsigned)iy < (unsigned)a.Hu && (unsigned)ix < (unsigned)a.Wu;
+                const float* up = a.U + (inside ? (((long)b * a.Hu + iy) * a.Wu + ix) * a.u_ld : 0L) + a_off;
                 float u[CAL];
                 if (CAL % 4 == 0 && uvec) {
 #pragma unroll
                     for (int c = 0; c < CAL; c += 4) {
                         const f32x4 q = *reinterpret_cast<const f32x4*>(up + c);
-                        u[c] = q[0]; u[c + 1] = q[1]; u[c + 2] = q[2]; u[c + 3] = q[3];
+                        u[c] = inside ? q[0] : 0.f; u[c + 1] = inside ? q[1] : 0.f; u[c + 2] = inside ? q[2] : 0.f; u[c + 3] = inside ? q[3] : 0.f;
                     }
                 } else {
 #pragma unroll
-                    for (int ca = 0; ca < CAL; ++ca) u[ca] = up[ca];
+                    for (int ca = 0; ca < CAL; ++ca) u[ca] = inside ? up[ca] : 0.f;
                 }
 #pragma unroll
                 for (int ca = 0; ca < CAL; ++ca)

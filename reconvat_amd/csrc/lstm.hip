@@ -20,6 +20,13 @@
 #include "common.h"
 
 #define LSTM_SPIN_LIMIT (1 << 22)
+#ifndef RV_LSTM_STAGE
+#define RV_LSTM_STAGE 1   // forward: stage h_{t-1} through LDS (measured faster than per-lane fragment loads from L2)
+#endif
+#ifndef RV_LSTM_KS
+#define RV_LSTM_KS 4      // K slices per tile for H = 384: 16 waves per workgroup, 24 MFMAs per wave and step
+#endif
+
 
 struct LstmArgs {
     const float* xg;        // fwd: [B,T,2,4H] gate pre-activations from the input GEMM; bwd: unused
@@ -51,27 +58,35 @@ __device__ __forceinline__ void wait_step(int* flag, int* err, int s, int tid) {
     __syncthreads();
 }
 
-template <int H>
-__global__ __launch_bounds__(256) void lstm_fwd_k(LstmArgs a) {
-    constexpr int NC = H / 16, NWG = H / 16, LDH = H + 4;
-    static_assert(NWG <= 64, "one polling lane per workgroup");
+// Forward.  Workgroup (d, j): hidden units [16j, 16j+16) of direction d as four 16-row MFMA tiles (row <-> (unit, gate), so
+// that a lane of the accumulator holds the four gates of one (unit, batch) cell).  4*KS waves: wave w works on tile w & 3 and
+// on the K slice (w >> 2) of the H-long reduction, with its part of W_hh in registers for the whole sequence; its B
+// fragments (h_{t-1}, batch on the N side) are loaded straight from L2, the KS partial tiles are added through LDS.
+template <int H, int KS>
+__global__ __launch_bounds__(256 * KS) void lstm_fwd_k(LstmArgs a) {
+    constexpr int KW = H / KS, NC = KW / 16, NWG = H / 16;
+    static_assert(KW % 16 == 0 && NWG <= 64, "K slice must be whole 16-chunks; one polling lane per workgroup");
     const int d = blockIdx.x / NWG, j = blockIdx.x - d * NWG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+    const int tile = wave & 3, kpart = wave >> 2;
     const int B = a.B, T = a.T;
-    __shared__ __attribute__((aligned(16))) float hs[8][LDH];
+    __shared__ f32x4 part[KS > 1 ? KS - 1 : 1][4][64];
+#if RV_LSTM_STAGE
+    __shared__ __attribute__((aligned(16))) float hs[8][H + 4];
+#endif
     int* flag = a.flags + d * NWG;
     int* err = a.flags + 2 * NWG;
 
-    // A operand: row li <-> (unit ubase + li/4, gate li%4); lane holds k = 16c + 4g + {0..3} of that row
-    const int ubase = j * 16 + wave * 4;
+    const int ubase = j * 16 + tile * 4;
     f32x4 wreg[NC];
     {
-        const float* wrow = a.whh[d] + ((long)(li & 3) * H + ubase + (li >> 2)) * H + 4 * g;
+        const float* wrow = a.whh[d] + ((long)(li & 3) * H + ubase + (li >> 2)) * H + kpart * KW + 4 * g;
 #pragma unroll
         for (int c = 0; c < NC; ++c) wreg[c] = *reinterpret_cast<const f32x4*>(wrow + 16 * c);
     }
     const int unit = ubase + g, b = li;
-    const bool cell = b < B;
+    const bool cell = kpart == 0 && b < B;
+    const int brow = (li & 7) < B ? (li & 7) : 0;      // lanes beyond the batch duplicate row 0 (their columns are unused)
     float cstate = 0.f;
     for (int s = 0; s < T; ++s) {
         const int t = d ? T - 1 - s : s;
@@ -84,23 +99,38 @@ __global__ __launch_bounds__(256) void lstm_fwd_k(LstmArgs a) {
         if (s > 0) {
             wait_step<NWG>(flag, err, s, tid);
             const int tp = d ? t + 1 : t - 1;
-            for (int idx = tid; idx < B * (H / 4); idx += 256) {
+            f32x4 hb[NC];
+#if RV_LSTM_STAGE
+            // h_{t-1} (B x H) once per workgroup through LDS: one 16-byte load per thread instead of NC per lane
+            for (int idx = tid; idx < B * (H / 4); idx += 256 * KS) {
                 const int bb = idx / (H / 4), k4 = idx - bb * (H / 4);
                 *reinterpret_cast<f32x4*>(&hs[bb][4 * k4]) =
                     *reinterpret_cast<const f32x4*>(a.out + ((long)bb * T + tp) * 2 * H + d * H + 4 * k4);
             }
             __syncthreads();
-            f32x4 acc[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < NC; ++c) hb[c] = *reinterpret_cast<const f32x4*>(&hs[brow][kpart * KW + 16 * c + 4 * g]);
+#else
+            const float* hp = a.out + ((long)brow * T + tp) * 2 * H + d * H + kpart * KW + 4 * g;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const f32x4 hb = *reinterpret_cast<const f32x4*>(&hs[li & 7][16 * c + 4 * g]);
+            for (int c = 0; c < NC; ++c) hb[c] = *reinterpret_cast<const f32x4*>(hp + 16 * c);
+#endif
+            f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[c][q], hb[q], acc[q], 0, 0, 0);
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[c][q], hb[c][q], acc[q & 1], 0, 0, 0);
+            f32x4 sum = acc[0] + acc[1];
+            if constexpr (KS > 1) {
+                if (kpart > 0) part[kpart - 1][tile][lane] = sum;
+                __syncthreads();
+                if (kpart == 0) {
+#pragma unroll
+                    for (int k = 1; k < KS; ++k) sum += part[k - 1][tile][lane];
+                }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pre[i] += (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
+            for (int i = 0; i < 4; ++i) pre[i] += sum[i];
         }
         if (cell) {
             const float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), gg = tanhf(pre[2]), go = sigmoidf_(pre[3]);
@@ -118,30 +148,32 @@ __global__ __launch_bounds__(256) void lstm_fwd_k(LstmArgs a) {
 }
 
 // Backward through time.  Step s handles t = (d ? s : T-1-s); the recurrent term of dh_t is W_hh^T dpre_{t'} with t' the
-// step handled just before.  Wave w reduces over gate block w (k = w*H .. w*H+H-1); the four partial 16x16 tiles are
-// added through LDS and threads 0..127 (unit, batch) do the cell arithmetic.
-template <int H>
-__global__ __launch_bounds__(256) void lstm_bwd_k(LstmArgs a) {
-    constexpr int NC = H / 16, NWG = H / 16, LDD = 4 * H + 4;
+// step handled just before (read from dxg, the exchange buffer).  Workgroup (d, j): units [16j, 16j+16) = the 16 rows of
+// ONE tile; its 4*KS waves split the K = 4H reduction (W_hh^T slices in registers, B fragments straight from L2); the
+// partial tiles are added through LDS and threads 0..127 (unit, batch) do the cell arithmetic.
+template <int H, int KS>
+__global__ __launch_bounds__(256 * KS) void lstm_bwd_k(LstmArgs a) {
+    constexpr int NW = 4 * KS, KW = 4 * H / NW, NC = KW / 16, NWG = H / 16;
+    static_assert(KW % 16 == 0, "K slice must be whole 16-chunks");
     const int d = blockIdx.x / NWG, j = blockIdx.x - d * NWG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
     const int B = a.B, T = a.T;
-    __shared__ __attribute__((aligned(16))) float ds[8][LDD];
-    __shared__ float part[4][16][8];
+    __shared__ float part[NW][16][8];
     int* flag = a.flags + d * NWG;
     int* err = a.flags + 2 * NWG;
 
-    // A operand: row li <-> unit 16j + li; k <-> W_hh row w*H + 16c + 4g + {0..3}
+    // A operand: row li <-> unit 16j + li; k <-> W_hh row wave*KW + 16c + 4g + {0..3}
     float wreg[NC][4];
     {
-        const float* wcol = a.whh[d] + ((long)wave * H + 4 * g) * H + j * 16 + li;
+        const float* wcol = a.whh[d] + ((long)wave * KW + 4 * g) * H + j * 16 + li;
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int q = 0; q < 4; ++q) wreg[c][q] = wcol[(long)(16 * c + q) * H];
     }
-    const int unit = j * 16 + (tid >> 3), b = tid & 7;
+    const int unit = j * 16 + ((tid >> 3) & 15), b = tid & 7;
     const bool cell = tid < 128 && b < B;
+    const int brow = (li & 7) < B ? (li & 7) : 0;
     float dc_carry = 0.f;
     for (int s = 0; s < T; ++s) {
         const int t = d ? s : T - 1 - s;
@@ -157,27 +189,26 @@ __global__ __launch_bounds__(256) void lstm_bwd_k(LstmArgs a) {
         if (s > 0) {
             wait_step<NWG>(flag, err, s, tid);
             const int tn = d ? t - 1 : t + 1;        // handled in the previous iteration
-            for (int idx = tid; idx < B * H; idx += 256) {
-                const int bb = idx / H, k4 = idx - bb * H;
-                *reinterpret_cast<f32x4*>(&ds[bb][4 * k4]) =
-                    *reinterpret_cast<const f32x4*>(a.dxg + (((long)bb * T + tn) * 2 + d) * 4 * H + 4 * k4);
-            }
-            __syncthreads();
-            f32x4 acc[4];
+            const float* dp = a.dxg + (((long)brow * T + tn) * 2 + d) * 4 * H + wave * KW + 4 * g;
+            f32x4 db[NC];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < NC; ++c) db[c] = *reinterpret_cast<const f32x4*>(dp + 16 * c);
+            f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const f32x4 db = *reinterpret_cast<const f32x4*>(&ds[li & 7][wave * H + 16 * c + 4 * g]);
+            for (int c = 0; c < NC; ++c)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[c][q], db[q], acc[q], 0, 0, 0);
-            }
+                for (int q = 0; q < 4; ++q) acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[c][q], db[c][q], acc[q & 1], 0, 0, 0);
             if (li < 8) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) part[wave][4 * g + i][li] = (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
+                for (int i = 0; i < 4; ++i) part[wave][4 * g + i][li] = acc[0][i] + acc[1][i];
             }
             __syncthreads();
-            if (cell) dh += (part[0][tid >> 3][b] + part[1][tid >> 3][b]) + (part[2][tid >> 3][b] + part[3][tid >> 3][b]);
+            if (cell) {
+                float r = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) r += part[w][(tid >> 3) & 15][b];
+                dh += r;
+            }
         }
         if (cell) {
             const float th = tanhf(ct);
@@ -212,9 +243,9 @@ extern "C" int rv_lstm_fwd(const float* xg, const float* whh_fwd, const float* w
     LstmArgs a = {};
     a.xg = xg; a.whh[0] = whh_fwd; a.whh[1] = whh_rev; a.out = out; a.gates = gates; a.cs = cs; a.flags = flags; a.B = B; a.T = T;
     if (hipMemsetAsync(flags, 0, rv_lstm_flag_bytes(H), st) != hipSuccess) { rv_set_error("rv_lstm_fwd: memset failed"); return RV_ELAUNCH; }
-    dim3 grid(2 * (H / 16)), blk(256);
-    if (H == 384) hipLaunchKernelGGL((lstm_fwd_k<384>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((lstm_fwd_k<32>), grid, blk, 0, st, a);
+    dim3 grid(2 * (H / 16));
+    if (H == 384) hipLaunchKernelGGL((lstm_fwd_k<384, RV_LSTM_KS>), grid, dim3(256 * RV_LSTM_KS), 0, st, a);
+    else hipLaunchKernelGGL((lstm_fwd_k<32, 2>), grid, dim3(512), 0, st, a);
     RV_LAUNCH_CHECK("lstm_fwd");
     return RV_OK;
 }
@@ -227,9 +258,9 @@ extern "C" int rv_lstm_bwd(const float* dout, const float* whh_fwd, const float*
     a.dout = dout; a.whh[0] = whh_fwd; a.whh[1] = whh_rev; a.gates = const_cast<float*>(gates); a.cs = const_cast<float*>(cs);
     a.dxg = dxg; a.flags = flags; a.B = B; a.T = T;
     if (hipMemsetAsync(flags, 0, rv_lstm_flag_bytes(H), st) != hipSuccess) { rv_set_error("rv_lstm_bwd: memset failed"); return RV_ELAUNCH; }
-    dim3 grid(2 * (H / 16)), blk(256);
-    if (H == 384) hipLaunchKernelGGL((lstm_bwd_k<384>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((lstm_bwd_k<32>), grid, blk, 0, st, a);
+    dim3 grid(2 * (H / 16));
+    if (H == 384) hipLaunchKernelGGL((lstm_bwd_k<384, RV_LSTM_KS>), grid, dim3(256 * RV_LSTM_KS), 0, st, a);
+    else hipLaunchKernelGGL((lstm_bwd_k<32, 2>), grid, dim3(512), 0, st, a);
     RV_LAUNCH_CHECK("lstm_bwd");
     return RV_OK;
 }
