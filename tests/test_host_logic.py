@@ -74,6 +74,33 @@ def test_state_dict_surface_matches_reference_keys():
     assert sum(p.numel() for p in m.parameters()) == 3639256         # flat gradient bucket size
 
 
+def test_baseline_script_config_and_state_dict_surface():
+    """train_baseline_onset_frame_VAT.py: config scope of the reference script (:25-73) and the state_dict surface of
+    OnsetsAndFrames_VAT_full (constructed on CPU; its forward is GPU-only)."""
+    from reconvat_amd.sacred_lite import parse_cli, Experiment
+    from reconvat_amd.cli import baseline_config
+    import reconvat_amd as ra
+    from oracle import onset_frames as oo
+    ex = Experiment('t')
+    ex.config(baseline_config)
+    cfg = ex.build_config(parse_cli(['with', 'VAT=True', 'root=my_runs']))
+    assert cfg['learning_rate'] == 5e-4 and cfg['learning_rate_decay_steps'] == 10000 and cfg['XI'] == 1e-6 and cfg['eps'] == 1e-1
+    assert cfg['model_complexity'] == 48 and cfg['train_on'] == 'String' and cfg['small'] is True and cfg['VAT'] is True
+    assert cfg['batch_size'] == cfg['train_batch_size'] == 8 and cfg['sequence_length'] == cfg['validation_length'] == 327680
+    assert cfg['logdir'].startswith('my_runs/baseline_Onset_Frame-')
+    with pytest.raises(NotImplementedError):
+        baseline_config({'model_name': 'frame'})
+    m = ra.OnsetsAndFrames_VAT_full(229, 88, model_complexity=48, log=True, mode='imagewise', spec='Mel', XI=1e-6, eps=1e-1)
+    sd = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    want = dict(oo.param_shapes())
+    want.update({'spectrogram.mel_basis': (229, 1025), 'spectrogram.stft.wsin': (1025, 1, 2048),
+                 'spectrogram.stft.wcos': (1025, 1, 2048), 'spectrogram.stft.window_mask': (1, 2048, 1)})
+    assert sd == want
+    m.load_state_dict(oo.fixture_params())                             # strict
+    with pytest.raises(RuntimeError, match='HIP device only'):
+        m(torch.zeros(1, 4, 229))                                      # no CPU fallback
+
+
 DP_WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
