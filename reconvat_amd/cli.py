@@ -179,6 +179,9 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
         else:
             _, losses, optimizer = train_VAT_model(model, iteration, ep, l_loader, ul_loader if VAT else None, optimizer,
                                                    scheduler, clip_gradient_norm, alpha, VAT, VAT_start)
+        if onset_script == 'baseline' and str(device).startswith('cuda'):
+            from . import ops
+            ops.lstm_check(torch.device(device))          # a timed-out recurrence launch invalidates the epoch: fail loudly
         if rank == 0:
             for key, value in losses.items():
                 writer.add_scalar(key, float(value), ep)

@@ -1004,6 +1004,27 @@ def bump_drop_epoch(device):
     call('rv_counter_add', ptr(drop_epoch(device)), 1, stream())
 
 
+_LSTM_ERR = {}
+
+
+def _lstm_err(device):
+    key = (device.type, device.index)
+    t = _LSTM_ERR.get(key)
+    if t is None:
+        t = _LSTM_ERR[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
+def lstm_check(device):
+    """Raise if any BiLSTM launch since the last call gave up waiting for a neighbour workgroup (its workgroups were
+    not co-resident): the results of that launch are invalid.  Synchronises; call it once per step / epoch, not per op."""
+    t = _lstm_err(torch.device(device))
+    if int(t.item()) != 0:
+        t.zero_()
+        raise RuntimeError('rv_lstm: a workgroup timed out waiting for its neighbours (launch not co-resident); '
+                           'the BiLSTM outputs of this step are invalid')
+
+
 class BiLstmFn(Function):
     """nn.LSTM(I, H, batch_first=True, bidirectional=True)(x)[0] with zero initial state
     (model/onset_frame_VAT.py:614; Onset_Stack.forward_LSTM :370-381, Combine_Stack.forward_LSTM :401-410).
@@ -1025,6 +1046,7 @@ class BiLstmFn(Function):
         flags = torch.empty(_lib.load().rv_lstm_flag_bytes(h) // 4, device=x.device, dtype=torch.int32)
         w_hh, w_hh_r = w_hh.contiguous(), w_hh_r.contiguous()
         call('rv_lstm_fwd', ptr(xg), ptr(w_hh), ptr(w_hh_r), ptr(out), ptr(gates), ptr(cs), ptr(flags), bb, t, h, stream())
+        _lstm_err(x.device).bitwise_or_(flags[-1:])          # sticky time-out flag, read by ops.lstm_check()
         ctx.params = (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
         ctx.save_for_backward(x2, out, gates, cs, w_ih, w_hh, w_ih_r, w_hh_r)
         ctx.dims = (bb, t, i, h)
@@ -1038,6 +1060,7 @@ class BiLstmFn(Function):
         dout = dout.contiguous()
         dxg = torch.empty((bb * t, 2, 4 * h), device=dout.device, dtype=torch.float32)
         call('rv_lstm_bwd', ptr(dout), ptr(w_hh), ptr(w_hh_r), ptr(gates), ptr(cs), ptr(dxg), ptr(ctx.flags), bb, t, h, stream())
+        _lstm_err(dout.device).bitwise_or_(ctx.flags[-1:])
         # h_{prev} of every step: the output shifted by one step along each direction's own time arrow
         hprev = torch.zeros((bb, t, 2, h), device=dout.device, dtype=torch.float32)
         o4 = out.view(bb, t, 2, h)

@@ -53,6 +53,7 @@ def test_bilstm_fwd_bwd(dev, b, t, i, h):
     with torch.no_grad():
         y2 = ops.BiLstmFn.apply(xg.detach(), *[p.detach() for p in pg])
     assert torch.equal(y2, y.detach())
+    ops.lstm_check(dev)          # no workgroup timed out
 
 
 def test_bilstm_rejects_unsupported(dev):

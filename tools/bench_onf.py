@@ -62,6 +62,7 @@ def main():
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    ops.lstm_check(dev)              # raises if any recurrence launch timed out
     audio_s = (16 if vat else 8) * 327680 / 16000 / dt
     print(json.dumps({'metric': 'training audio-sec/sec (1 GPU), Onsets&Frames BiLSTM baseline' + (' VAT' if vat else ''),
                       'value': round(audio_s, 1), 'unit': 'audio-s/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': args.steps,
