@@ -280,8 +280,36 @@ __device__ __forceinline__ bool keep_draw(long idx, unsigned seed, float p) {
     return (h >> 8) * (1.0f / 16777216.0f) >= p;
 }
 
+// one thread = four consecutive channels of one output pixel (C % 4 == 0): 16-byte loads / stores, one packed code word
 __global__ __launch_bounds__(256) void pool_drop_fwd_k(const float* x, float* y, unsigned char* code, long rows, int W, int Wo, int C,
                                                        float p, float scale, unsigned seed, const long* epoch) {
+    if (epoch) seed ^= (unsigned)(*epoch) * 0x9E3779B1u;
+    const int C4 = C >> 2;
+    const long n = rows * Wo * C4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        const long rw = i / C4;
+        const int wo = (int)(rw % Wo);
+        const long r = rw / Wo;
+        const float* src = x + ((r * W + 2 * wo) * (long)C + 4 * c4);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + C);
+        const long o = rw * C + 4 * c4;
+        f32x4 out;
+        unsigned packed = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool odd = v1[q] > v0[q];
+            const bool keep = p <= 0.f || keep_draw(o + q, seed, p);
+            out[q] = keep ? (odd ? v1[q] : v0[q]) * scale : 0.f;
+            packed |= (unsigned)((odd ? 1 : 0) | (keep ? 2 : 0)) << (8 * q);
+        }
+        *reinterpret_cast<f32x4*>(y + o) = out;
+        *reinterpret_cast<unsigned*>(code + o) = packed;
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_drop_fwd_scalar_k(const float* x, float* y, unsigned char* code, long rows, int W, int Wo,
+                                                              int C, float p, float scale, unsigned seed, const long* epoch) {
     if (epoch) seed ^= (unsigned)(*epoch) * 0x9E3779B1u;
     const long n = rows * Wo * C;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -298,8 +326,36 @@ __global__ __launch_bounds__(256) void pool_drop_fwd_k(const float* x, float* y,
     }
 }
 
+// one thread = four consecutive channels of one OUTPUT pixel: writes both input columns (and zeroes the odd tail column)
 __global__ __launch_bounds__(256) void pool_drop_bwd_k(const float* dy, const unsigned char* code, float* dx, long rows, int W, int Wo,
                                                        int C, float scale) {
+    const int C4 = C >> 2;
+    const long n = rows * Wo * C4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        const long rw = i / C4;
+        const int wo = (int)(rw % Wo);
+        const long r = rw / Wo;
+        const long o = rw * C + 4 * c4;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+        const unsigned packed = *reinterpret_cast<const unsigned*>(code + o);
+        f32x4 d0, d1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned cd = (packed >> (8 * q)) & 0xFF;
+            const float v = (cd & 2) ? g[q] * scale : 0.f;
+            d0[q] = (cd & 1) ? 0.f : v;
+            d1[q] = (cd & 1) ? v : 0.f;
+        }
+        float* dst = dx + ((r * W + 2 * wo) * (long)C + 4 * c4);
+        *reinterpret_cast<f32x4*>(dst) = d0;
+        *reinterpret_cast<f32x4*>(dst + C) = d1;
+        if ((W & 1) && wo == Wo - 1) *reinterpret_cast<f32x4*>(dst + 2 * C) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_drop_bwd_scalar_k(const float* dy, const unsigned char* code, float* dx, long rows, int W,
+                                                              int Wo, int C, float scale) {
     const long n = rows * W * C;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const int c = (int)(i % C);
@@ -335,7 +391,9 @@ extern "C" int rv_maxpool_w2_dropout_fwd(const float* x, float* y, unsigned char
     RV_CHECK_ARG(x && y && code && rows >= 0 && W >= 2 && C >= 1 && p >= 0.f && p < 1.f, "rv_maxpool_w2_dropout_fwd: bad arguments");
     const int Wo = W / 2;
     if (rows == 0) return RV_OK;
-    hipLaunchKernelGGL(pool_drop_fwd_k, dim3(ew_grid(rows * Wo * C)), dim3(256), 0, st, x, y, code, rows, W, Wo, C, p, 1.0f / (1.0f - p), seed, epoch);
+    const bool vec = (C & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0 && (((uintptr_t)code) & 3) == 0;
+    if (vec) hipLaunchKernelGGL(pool_drop_fwd_k, dim3(ew_grid(rows * Wo * (C / 4))), dim3(256), 0, st, x, y, code, rows, W, Wo, C, p, 1.0f / (1.0f - p), seed, epoch);
+    else hipLaunchKernelGGL(pool_drop_fwd_scalar_k, dim3(ew_grid(rows * Wo * C)), dim3(256), 0, st, x, y, code, rows, W, Wo, C, p, 1.0f / (1.0f - p), seed, epoch);
     RV_LAUNCH_CHECK("pool_drop_fwd");
     return RV_OK;
 }
@@ -344,7 +402,9 @@ extern "C" int rv_maxpool_w2_dropout_bwd(const float* dy, const unsigned char* c
                                          hipStream_t st) {
     RV_CHECK_ARG(dy && dx && code && rows >= 0 && W >= 2 && C >= 1 && p >= 0.f && p < 1.f, "rv_maxpool_w2_dropout_bwd: bad arguments");
     if (rows == 0) return RV_OK;
-    hipLaunchKernelGGL(pool_drop_bwd_k, dim3(ew_grid(rows * W * C)), dim3(256), 0, st, dy, code, dx, rows, W, W / 2, C, 1.0f / (1.0f - p));
+    const bool vec = (C & 3) == 0 && ((((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0 && (((uintptr_t)code) & 3) == 0;
+    if (vec) hipLaunchKernelGGL(pool_drop_bwd_k, dim3(ew_grid(rows * (W / 2) * (C / 4))), dim3(256), 0, st, dy, code, dx, rows, W, W / 2, C, 1.0f / (1.0f - p));
+    else hipLaunchKernelGGL(pool_drop_bwd_scalar_k, dim3(ew_grid(rows * W * C)), dim3(256), 0, st, dy, code, dx, rows, W, W / 2, C, 1.0f / (1.0f - p));
     RV_LAUNCH_CHECK("pool_drop_bwd");
     return RV_OK;
 }
