@@ -116,3 +116,42 @@ def test_unet_batch_permutation_full_size(dev):
     assert rel_err(roll_p, roll[perm]) < 1e-4 and rel_err(onset_p, onset[perm]) < 1e-4
     assert abs(float(roll.double().sum() - roll_p.double().sum())) < 1e-4 * float(roll.double().sum())
     assert roll.shape == (B, T, 88) and att.shape == (B, T, 6, 31)
+
+
+def _lstm_params(i, h, dev, seed):
+    k = 1.0 / h ** 0.5
+    shapes = [(4 * h, i), (4 * h, h), (4 * h,), (4 * h,)] * 2
+    return [(_rand(*s, seed=seed + n, dev=dev) * k).requires_grad_(True) for n, s in enumerate(shapes)]
+
+
+@pytest.mark.parametrize('i', [768, 176])
+def test_bilstm_time_reversal_and_batch_permutation_full_size(dev, i):
+    """The Onsets&Frames recurrences at their real size (B = 8, T = 640, H = 384).  A bidirectional LSTM run on the
+    time-reversed input with the two directions' weights swapped returns the time-reversed output with its halves
+    swapped -- forward and backward kernels of direction 0 are checked against those of direction 1; and permuting the
+    batch permutes the output (rows of the MFMA N side are independent).  Gradients obey the same symmetries."""
+    from reconvat_amd import ops
+    h = 384
+    x = _rand(B, T, i, seed=11, dev=dev).requires_grad_(True)
+    ps = _lstm_params(i, h, dev, 20)
+    gy = _rand(B, T, 2 * h, seed=12, dev=dev)
+    y = ops.BiLstmFn.apply(x, *ps)
+    y.backward(gy)
+    gx, gps = x.grad.clone(), [p.grad.clone() for p in ps]
+    # swapped directions on the reversed sequence
+    xr = x.detach().flip(1).requires_grad_(True)
+    ps_sw = [p.detach().clone().requires_grad_(True) for p in ps[4:] + ps[:4]]
+    gyr = torch.cat([gy[..., h:], gy[..., :h]], dim=-1).flip(1)
+    yr = ops.BiLstmFn.apply(xr, *ps_sw)
+    yr.backward(gyr)
+    want = torch.cat([y[..., h:], y[..., :h]], dim=-1).flip(1)
+    assert rel_err(yr, want) < 1e-5
+    assert rel_err(xr.grad.flip(1), gx) < 1e-4
+    for a, b_ in zip(ps_sw, gps[4:] + gps[:4]):
+        assert rel_err(a.grad, b_) < 1e-4
+    # batch permutation
+    perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device=dev)
+    with torch.no_grad():
+        yp = ops.BiLstmFn.apply(x.detach()[perm].contiguous(), *[p.detach() for p in ps])
+    assert torch.equal(yp, y.detach()[perm])
+    ops.lstm_check(dev)
