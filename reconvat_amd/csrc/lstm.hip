@@ -20,6 +20,9 @@
 #include "common.h"
 
 #define LSTM_SPIN_LIMIT (1 << 22)
+#ifndef RV_LSTM_ABL
+#define RV_LSTM_ABL 0       // timing ablations (wrong results): 1 no cross-workgroup wait, 2 no h staging loads, 4 no xg/gates traffic
+#endif
 #ifndef RV_LSTM_STAGE
 #define RV_LSTM_STAGE 1   // forward: stage h_{t-1} through LDS (measured faster than per-lane fragment loads from L2)
 #endif
@@ -45,7 +48,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __ex
 // wait until every workgroup of this direction has published step >= s; wave 0 polls, one counter per lane
 template <int NWG>
 __device__ __forceinline__ void wait_step(int* flag, int* err, int s, int tid) {
-    if (tid < NWG) {
+    if ((RV_LSTM_ABL & 1) == 0 && tid < NWG) {
         // poll relaxed (an acquire load would invalidate this XCD's L2 on every iteration, under the kernels of the other
         // streams too); ONE acquire fence once every counter has arrived
         int spins = 0;
@@ -54,7 +57,7 @@ __device__ __forceinline__ void wait_step(int* flag, int* err, int s, int tid) {
             __builtin_amdgcn_s_sleep(1);
         }
     }
-    if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // the polling wave drops stale L1 / L2 lines
+    if ((RV_LSTM_ABL & 1) == 0 && tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // the polling wave drops stale L1 / L2 lines
     __syncthreads();
 }
 
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256 * KS) void lstm_fwd_k(LstmArgs a) {
         const int t = d ? T - 1 - s : s;
         const long cellbase = (((long)b * T + t) * 2 + d) * 4 * H + unit;
         float pre[4] = {0.f, 0.f, 0.f, 0.f};
-        if (cell) {
+        if (cell && (RV_LSTM_ABL & 4) == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) pre[i] = a.xg[cellbase + (long)i * H];
         }
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256 * KS) void lstm_fwd_k(LstmArgs a) {
             f32x4 hb[NC];
 #if RV_LSTM_STAGE
             // h_{t-1} (B x H) once per workgroup through LDS: one 16-byte load per thread instead of NC per lane
-            for (int idx = tid; idx < B * (H / 4); idx += 256 * KS) {
+            for (int idx = tid; (RV_LSTM_ABL & 2) == 0 && idx < B * (H / 4); idx += 256 * KS) {
                 const int bb = idx / (H / 4), k4 = idx - bb * (H / 4);
                 *reinterpret_cast<f32x4*>(&hs[bb][4 * k4]) =
                     *reinterpret_cast<const f32x4*>(a.out + ((long)bb * T + tp) * 2 * H + d * H + 4 * k4);
@@ -137,13 +140,13 @@ __global__ __launch_bounds__(256 * KS) void lstm_fwd_k(LstmArgs a) {
             cstate = fmaf(gf, cstate, gi * gg);
             const float h = go * tanhf(cstate);
             a.out[((long)b * T + t) * 2 * H + d * H + unit] = h;
-            if (a.gates) {
+            if (a.gates && (RV_LSTM_ABL & 4) == 0) {
                 a.gates[cellbase] = gi; a.gates[cellbase + H] = gf; a.gates[cellbase + 2 * H] = gg; a.gates[cellbase + 3 * H] = go;
                 a.cs[(((long)b * T + t) * 2 + d) * H + unit] = cstate;
             }
         }
         __syncthreads();      // every wave's h_t stores are issued and complete (workgroup-scope release) ...
-        if (tid == 0) __hip_atomic_store(&flag[j], s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... and published
+        if (tid == 0) __hip_atomic_store(&flag[j], s + 1, (RV_LSTM_ABL & 1) ? __ATOMIC_RELAXED : __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... and published
     }
 }
 
