@@ -146,7 +146,7 @@ int rv_crop_segments(const short* audio, const unsigned char* label, const unsig
  * out [B,T,2H] (forward half | reverse half, as nn.LSTM returns it); gates [B,T,2,4,H] (activated) and cs [B,T,2,H]
  * are saved for the backward pass (both NULL = inference).  flags: rv_lstm_flag_bytes(H) bytes of device scratch, reset by
  * the call itself; the last int is non-zero afterwards if a workgroup gave up waiting (co-residency violated).
- * B <= 8; H in {384, 32}.  rv_lstm_bwd: dout [B,T,2H] -> dxg [B,T,2,4H]; dW_ih, dW_hh, db and dx are GEMMs / column sums
+ * B <= 16 (the batch is the N side of one 16-wide MFMA tile); H in {384, 32}.  rv_lstm_bwd: dout [B,T,2H] -> dxg [B,T,2,4H]; dW_ih, dW_hh, db and dx are GEMMs / column sums
  * of dxg done by the caller. */
 long rv_lstm_flag_bytes(int H);
 int rv_lstm_fwd(const float* xg, const float* whh_fwd, const float* whh_rev, float* out, float* gates, float* cs, int* flags,

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256 * KS) void lstm_fwd_k(LstmArgs a) {
     const int B = a.B, T = a.T;
     __shared__ f32x4 part[KS > 1 ? KS - 1 : 1][4][64];
 #if RV_LSTM_STAGE
-    __shared__ __attribute__((aligned(16))) float hs[8][H + 4];
+    __shared__ __attribute__((aligned(16))) float hs[16][H + 4];
 #endif
     int* flag = a.flags + d * NWG;
     int* err = a.flags + 2 * NWG;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256 * KS) void lstm_fwd_k(LstmArgs a) {
     }
     const int unit = ubase + g, b = li;
     const bool cell = kpart == 0 && b < B;
-    const int brow = (li & 7) < B ? (li & 7) : 0;      // lanes beyond the batch duplicate row 0 (their columns are unused)
+    const int brow = li < B ? li : 0;      // lanes beyond the batch duplicate row 0 (their columns are unused)
     float cstate = 0.f;
     for (int s = 0; s < T; ++s) {
         const int t = d ? T - 1 - s : s;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256 * KS) void lstm_fwd_k(LstmArgs a) {
 // Backward through time.  Step s handles t = (d ? s : T-1-s); the recurrent term of dh_t is W_hh^T dpre_{t'} with t' the
 // step handled just before (read from dxg, the exchange buffer).  Workgroup (d, j): units [16j, 16j+16) = the 16 rows of
 // ONE tile; its 4*KS waves split the K = 4H reduction (W_hh^T slices in registers, B fragments straight from L2); the
-// partial tiles are added through LDS and threads 0..127 (unit, batch) do the cell arithmetic.
+// partial tiles are added through LDS and threads 0..255 (unit, batch) do the cell arithmetic.
 template <int H, int KS>
 __global__ __launch_bounds__(256 * KS) void lstm_bwd_k(LstmArgs a) {
     constexpr int NW = 4 * KS, KW = 4 * H / NW, NC = KW / 16, NWG = H / 16;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256 * KS) void lstm_bwd_k(LstmArgs a) {
     const int d = blockIdx.x / NWG, j = blockIdx.x - d * NWG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
     const int B = a.B, T = a.T;
-    __shared__ float part[NW][16][8];
+    __shared__ float part[NW][16][16];
     int* flag = a.flags + d * NWG;
     int* err = a.flags + 2 * NWG;
 
@@ -174,9 +174,9 @@ __global__ __launch_bounds__(256 * KS) void lstm_bwd_k(LstmArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) wreg[c][q] = wcol[(long)(16 * c + q) * H];
     }
-    const int unit = j * 16 + ((tid >> 3) & 15), b = tid & 7;
-    const bool cell = tid < 128 && b < B;
-    const int brow = (li & 7) < B ? (li & 7) : 0;
+    const int unit = j * 16 + ((tid >> 4) & 15), b = tid & 15;
+    const bool cell = tid < 256 && b < B;
+    const int brow = li < B ? li : 0;
     float dc_carry = 0.f;
     for (int s = 0; s < T; ++s) {
         const int t = d ? s : T - 1 - s;
@@ -201,15 +201,13 @@ __global__ __launch_bounds__(256 * KS) void lstm_bwd_k(LstmArgs a) {
             for (int c = 0; c < NC; ++c)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[c][q], db[c][q], acc[q & 1], 0, 0, 0);
-            if (li < 8) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) part[wave][4 * g + i][li] = acc[0][i] + acc[1][i];
-            }
+            for (int i = 0; i < 4; ++i) part[wave][4 * g + i][li] = acc[0][i] + acc[1][i];
             __syncthreads();
             if (cell) {
                 float r = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) r += part[w][(tid >> 3) & 15][b];
+                for (int w = 0; w < NW; ++w) r += part[w][(tid >> 4) & 15][b];
                 dh += r;
             }
         }
@@ -232,7 +230,7 @@ __global__ __launch_bounds__(256 * KS) void lstm_bwd_k(LstmArgs a) {
 extern "C" long rv_lstm_flag_bytes(int H) { return (long)(2 * (H / 16) + 1) * sizeof(int); }
 
 static int lstm_check(int B, int T, int H) {
-    RV_CHECK_ARG(B >= 1 && B <= 8, "rv_lstm: batch %d not in 1..8 (one 16-wide MFMA column tile, 8 staged rows)", B);
+    RV_CHECK_ARG(B >= 1 && B <= 16, "rv_lstm: batch %d not in 1..16 (one 16-wide MFMA column tile)", B);
     RV_CHECK_ARG(T >= 1, "rv_lstm: T=%d", T);
     RV_CHECK_ARG(H == 384 || H == 32, "rv_lstm: hidden size %d not instantiated (384, 32)", H);
     return RV_OK;

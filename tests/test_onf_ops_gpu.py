@@ -24,7 +24,7 @@ def lstm_params(i, h, seed):
     return [rnd(*s, seed=seed + n, scale=k) for n, s in enumerate(shapes)]
 
 
-@pytest.mark.parametrize('b,t,i,h', [(2, 5, 24, 32), (3, 17, 40, 32), (8, 33, 176, 384), (1, 1, 16, 32), (8, 640, 768, 384)])
+@pytest.mark.parametrize('b,t,i,h', [(2, 5, 24, 32), (3, 17, 40, 32), (8, 33, 176, 384), (1, 1, 16, 32), (8, 640, 768, 384), (16, 9, 24, 32), (13, 21, 176, 384)])
 def test_bilstm_fwd_bwd(dev, b, t, i, h):
     from reconvat_amd import ops
     x = rnd(b, t, i, seed=1)
@@ -60,7 +60,7 @@ def test_bilstm_rejects_unsupported(dev):
     from reconvat_amd import ops
     ps = [p.to(dev) for p in lstm_params(8, 32, 1)]
     with pytest.raises(RuntimeError, match='batch'):
-        ops.BiLstmFn.apply(torch.zeros(9, 4, 8, device=dev), *ps)
+        ops.BiLstmFn.apply(torch.zeros(17, 4, 8, device=dev), *ps)
     ps = [p.to(dev) for p in lstm_params(8, 48, 1)]
     with pytest.raises(RuntimeError, match='hidden size'):
         ops.BiLstmFn.apply(torch.zeros(2, 4, 8, device=dev), *ps)
