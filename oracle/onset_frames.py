@@ -68,11 +68,33 @@ def param_shapes(model_complexity=48):
     return s
 
 
-def fixture_params(model_complexity=48, with_frontend=True, tag='onf:'):
+def param_shapes_frame(model_complexity=48):
+    """Frame_stack_VAT (model/onset_frame_VAT.py:417-443): module order combined_stack, frame_stack."""
+    ms = model_complexity * 16
+    s = {}
+    _lstm_shapes(s, 'combined_stack.sequence_model', N_KEYS, ms // 2)
+    s['combined_stack.linear.weight'] = (N_KEYS, ms); s['combined_stack.linear.bias'] = (N_KEYS,)
+    _convstack_shapes(s, 'frame_stack.0', ms)
+    s['frame_stack.1.weight'] = (N_KEYS, ms); s['frame_stack.1.bias'] = (N_KEYS,)
+    return s
+
+
+def param_shapes_onset(model_complexity=48):
+    """Onset_stack_VAT (model/onset_frame_VAT.py:516-532)."""
+    ms = model_complexity * 16
+    s = {}
+    _convstack_shapes(s, 'onset_stack.convstack', ms)
+    _lstm_shapes(s, 'onset_stack.sequence_model', ms, ms // 2)
+    s['onset_stack.linear.weight'] = (N_KEYS, ms); s['onset_stack.linear.bias'] = (N_KEYS,)
+    return s
+
+
+def fixture_params(model_complexity=48, with_frontend=True, tag='onf:', kind='onset_frame'):
     """Deterministic parameters: conv / linear ~ U(+-sqrt(3/fan_in)), LSTM ~ U(+-1/sqrt(H)) (PyTorch's own range),
     BatchNorm affine near (1, 0), running stats at their defaults."""
     out = {}
-    for k, shp in param_shapes(model_complexity).items():
+    shapes = {'onset_frame': param_shapes, 'frame': param_shapes_frame, 'onset': param_shapes_onset}[kind](model_complexity)
+    for k, shp in shapes.items():
         name = tag + k
         if k.endswith('num_batches_tracked'):
             out[k] = torch.zeros((), dtype=torch.long)
@@ -201,3 +223,64 @@ def run_on_batch(params, training, batch, batch_ul=None, VAT=False, xi=1e-5, eps
     if training:
         losses['loss/train_r_norm_ul'] = r_norm_ul.abs().mean()
     return predictions, losses, spec
+
+
+# ---------------------------------------------------------------------------------------------
+# the two single-stack variants of the baseline script (model_name = 'frame' / 'onset')
+# ---------------------------------------------------------------------------------------------
+def forward_frame_stack(params, training, spec, detach=False):
+    """Frame_stack_VAT.forward (model/onset_frame_VAT.py:445-450) -> (activation, frame)."""
+    net = Net(params, training, detach)
+    act = torch.sigmoid(net.linear(conv_stack(net, spec, 'frame_stack.0'), 'frame_stack.1'))
+    frame = torch.sigmoid(net.linear(bilstm(net, act, 'combined_stack.sequence_model'), 'combined_stack.linear'))
+    return act, frame
+
+
+def vat_frame_stack(params, training, x, xi, eps, d0, mode='all'):
+    """stepwise_VAT_frame_stack.forward (model/onset_frame_VAT.py:221-269): distance = BCE(frame) [+ MSE(activation)],
+    d = d.grad * 1e20.  Returns (vat_loss, r_adv, d.grad)."""
+    def dist(act, frame, act_ref, frame_ref):
+        terms = {'activation': F.mse_loss(act, act_ref), 'frame': F.binary_cross_entropy(frame, frame_ref)}
+        return terms[mode] if mode != 'all' else terms['frame'] + terms['activation']
+    with torch.no_grad():
+        act_ref, frame_ref = forward_frame_stack(params, training, x)
+    d = d0.clone().requires_grad_(True)
+    act, frame = forward_frame_stack(params, training, (x + xi * l2_normalise(d)).clamp(0, 1), detach=True)
+    g, = torch.autograd.grad(dist(act, frame, act_ref, frame_ref), d)
+    r_adv = eps * l2_normalise(g.detach() * 1e20)
+    act, frame = forward_frame_stack(params, training, (x + r_adv).clamp(0, 1))
+    return dist(act, frame, act_ref, frame_ref), r_adv, g
+
+
+def run_on_batch_frame_stack(params, training, batch, VAT=False, xi=1e-5, eps=10.0, d0_l=None, mode='all'):
+    """Frame_stack_VAT.run_on_batch (model/onset_frame_VAT.py:453-503) without an unlabelled batch (with one AND VAT=True
+    the reference feeds a [B, 229, 640] tensor to the ConvStack and fails in its Linear, :466)."""
+    spec = _spec(params, batch['audio'])
+    if VAT:
+        lds_l, r_adv = vat_frame_stack(params, training, spec, xi, eps, d0_l, mode)[:2]
+    else:
+        r_adv, lds_l = None, torch.tensor(0.)
+    _, frame = forward_frame_stack(params, training, spec)
+    predictions = {'onset': frame, 'frame': frame.reshape(*batch['frame'].shape), 'r_adv': r_adv}
+    if training:
+        losses = {'loss/train_frame': F.binary_cross_entropy(predictions['frame'], batch['frame']),
+                  'loss/train_LDS': (torch.tensor(0.) + lds_l) / 2}
+    else:
+        losses = {'loss/test_frame': F.binary_cross_entropy(predictions['frame'], batch['frame']), 'loss/test_LDS': lds_l}
+    return predictions, losses, spec
+
+
+def run_on_batch_onset_stack(params, training, batch):
+    """Onset_stack_VAT.run_on_batch with VAT=False (model/onset_frame_VAT.py:539-589; VAT=True hits undefined names at
+    :305-306)."""
+    spec = _spec(params, batch['audio'])
+    net = Net(params, training)
+    x = bilstm(net, conv_stack(net, spec, 'onset_stack.convstack'), 'onset_stack.sequence_model')
+    onset = torch.sigmoid(net.linear(x, 'onset_stack.linear'))
+    label = batch['onset']
+    accuracy = (label == (onset > 0.5)).float().sum() / label.flatten(0).shape[0]
+    tag = 'train' if training else 'test'
+    lds = torch.tensor(0.)
+    losses = {f'loss/{tag}_onset': F.binary_cross_entropy(onset, label), f'metric/{tag}_accuracy': accuracy,
+              f'loss/{tag}_LDS': torch.mean(torch.stack((lds, lds)), dim=0) if training else lds}
+    return {'onset': onset, 'r_adv': None}, losses, spec

@@ -6,6 +6,7 @@ Public surface mirrors the reference's ``model`` package for this path:
 """
 from .constants import *  # noqa: F401,F403
 from .model import UNet_Onset, UNet, UNet_VAT, MutliHeadAttention1D, Spec2Roll, Roll2Spec, Encoder, Decoder  # noqa: F401
-from .onset_frames import OnsetsAndFrames_VAT_full, stepwise_VAT, ConvStack, Onset_Stack, Combine_Stack  # noqa: F401
+from .onset_frames import (OnsetsAndFrames_VAT_full, Frame_stack_VAT, Onset_stack_VAT, stepwise_VAT,  # noqa: F401
+                           stepwise_VAT_frame_stack, ConvStack, Onset_Stack, Combine_Stack)
 from .frontend import MelSpectrogram, Normalization  # noqa: F401
 from .train import train_VAT_model, FlatAdam, TrainStep, weighted_loss, cycle  # noqa: F401

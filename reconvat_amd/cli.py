@@ -75,8 +75,8 @@ def baseline_config(o):
         graph=True, fused_optimizer=True, saving_freq=saving_freq, device_feed=True,
     )
     c.update(o)
-    if c['model_name'] != 'onset_frame':
-        raise NotImplementedError("only model_name='onset_frame' (OnsetsAndFrames_VAT_full) is built for MI355X")
+    if c['model_name'] not in ('onset_frame', 'frame', 'onset'):
+        raise NotImplementedError("model_name must be 'onset_frame', 'frame' or 'onset' (the 'attention' variant is not built)")
     if 'validation_length' not in o:
         c['validation_length'] = c['sequence_length']
     if 'logdir' not in o:
@@ -106,7 +106,8 @@ class ScalarLog:
 def run_training(onset_script, spec, resume_iteration, train_on, batch_size, sequence_length, small, supersmall,
                  train_batch_size, learning_rate, learning_rate_decay_steps, learning_rate_decay_rate, alpha,
                  clip_gradient_norm, validation_length, refresh, device, epoches, logdir, log, iteration, VAT_start, VAT,
-                 XI, eps, reconstruction, graph, fused_optimizer, saving_freq, device_feed=True, model_complexity=48, **_unused):
+                 XI, eps, reconstruction, graph, fused_optimizer, saving_freq, device_feed=True, model_complexity=48, model_name='onset_frame', VAT_mode='all',
+                 **_unused):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if world > 1:
@@ -132,9 +133,11 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
 
     torch.manual_seed(0)                                   # identical initial weights on every rank
     if onset_script == 'baseline':
-        from .onset_frames import OnsetsAndFrames_VAT_full as cls
+        from . import onset_frames as onf
         from .constants import N_BINS, MAX_MIDI, MIN_MIDI
-        model = cls(N_BINS, MAX_MIDI - MIN_MIDI + 1, model_complexity=model_complexity, log=log, mode=mode, spec=spec, XI=XI, eps=eps)
+        cls = {'onset_frame': onf.OnsetsAndFrames_VAT_full, 'frame': onf.Frame_stack_VAT, 'onset': onf.Onset_stack_VAT}[model_name]
+        model = cls(N_BINS, MAX_MIDI - MIN_MIDI + 1, model_complexity=model_complexity, log=log, mode=mode, spec=spec, XI=XI, eps=eps,
+                    VAT_mode=VAT_mode)
     else:
         cls = UNet_Onset if onset_script else UNet
         model = cls(ds_ksize, ds_stride, log=log, reconstruction=reconstruction, mode=mode, spec=spec, device=device, XI=XI, eps=eps)

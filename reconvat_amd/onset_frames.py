@@ -253,3 +253,115 @@ class OnsetsAndFrames_VAT_full(_Base):
         if self.training:
             losses['loss/train_r_norm_ul'] = r_norm_ul
         return predictions, losses, spec
+
+
+class stepwise_VAT_frame_stack(nn.Module):
+    """model/onset_frame_VAT.py:209-269: distance = BCE(frame) and / or MSE(activation) by `VAT_mode`, d = d.grad * 1e20;
+    returns (vat_loss, r_adv).  Weights detached for the power-iteration pass (see stepwise_VAT)."""
+
+    def __init__(self, XI, epsilon, n_power, VAT_mode):
+        super().__init__()
+        if VAT_mode not in ('activation', 'frame', 'all'):
+            raise ValueError(f'VAT_mode {VAT_mode!r}')
+        self.n_power, self.XI, self.epsilon, self.VAT_mode = n_power, XI, epsilon, VAT_mode
+        self.nan_flag = None
+        self.noise = None
+
+    def _dist(self, act, frame, act_ref, frame_ref):
+        if self.VAT_mode == 'activation':
+            return ops.mse_mean(act, act_ref)
+        if self.VAT_mode == 'frame':
+            return bce_mean(frame, frame_ref)
+        return bce_mean(frame, frame_ref) + ops.mse_mean(act, act_ref)
+
+    def forward(self, model, x):
+        if self.nan_flag is None or self.nan_flag.device != x.device:
+            self.nan_flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+        with torch.no_grad():
+            act_ref, frame_ref = model(x)
+        d = (self.noise(x) if self.noise is not None else torch.randn_like(x)).requires_grad_(True)
+        g = None
+        for it in range(self.n_power):
+            if it > 0:
+                d = (g * 1e20).requires_grad_(True)
+            act, frame = model(VatPerturbFn.apply(x, d, float(self.XI)), detach=True)
+            g, = torch.autograd.grad(self._dist(act, frame, act_ref, frame_ref), d)
+            g = g.detach()
+        x_adv, r_adv, _ = ops.vat_adversarial(x, g, 1e20, float(self.epsilon), self.nan_flag)
+        if not torch.cuda.is_current_stream_capturing():
+            assert int(self.nan_flag.item()) == 0, 'r_adv exploded, please debug tune down the XI for VAT'
+        act, frame = model(x_adv)
+        return self._dist(act, frame, act_ref, frame_ref), r_adv
+
+
+class Frame_stack_VAT(_Base):
+    """model/onset_frame_VAT.py:417-514 (`model_name='frame'` of the baseline script): ConvStack -> Linear -> sigmoid ->
+    BiLSTM(88 -> 768) -> Linear -> sigmoid."""
+
+    def __init__(self, input_features, output_features, model_complexity=48, log=True, mode='imagewise', spec='Mel', XI=1e-5,
+                 eps=10, VAT_mode='all'):
+        super().__init__(log, False, mode, spec, XI, eps)
+        model_size = model_complexity * 16
+        self.vat_loss = stepwise_VAT_frame_stack(XI, eps, 1, VAT_mode)
+        self.combined_stack = Combine_Stack(model_size, output_features,
+                                            nn.LSTM(output_features, model_size // 2, batch_first=True, bidirectional=True))
+        self.frame_stack = nn.Sequential(ConvStack(input_features, model_size), nn.Linear(model_size, output_features), nn.Sigmoid())
+
+    def forward(self, spec, detach=False):
+        b, t, _ = spec.shape
+        act = _linear(self.frame_stack[1], self.frame_stack[0](spec, detach), 1, detach).view(b, t, -1)
+        return act, self.combined_stack(act, detach).view(b, t, -1)
+
+    def run_on_batch(self, batch, batch_ul=None, VAT=False):
+        audio_label, frame_label = batch['audio'], batch['frame']
+        spec = self._front(audio_label, audio_label.shape[-1]).squeeze(1)
+        if batch_ul and VAT:
+            # the reference transposes the LABELLED spectrogram a second time here (model/onset_frame_VAT.py:466) and fails
+            # in the ConvStack's Linear (640 "bins"); there is no behaviour to reproduce
+            raise RuntimeError('Frame_stack_VAT.run_on_batch: the unlabelled VAT branch of the reference is not executable '
+                               '(shape error at model/onset_frame_VAT.py:466-467); pass batch_ul=None')
+        lds_ul = torch.tensor(0.)
+        if VAT:
+            lds_l, r_adv = self.vat_loss(self, spec)
+        else:
+            r_adv, lds_l = None, torch.tensor(0.)
+        _, frame_pred = self(spec)
+        predictions = {'onset': frame_pred, 'frame': frame_pred.reshape(*frame_label.shape), 'r_adv': r_adv}
+        if self.training:
+            losses = {'loss/train_frame': bce_mean(predictions['frame'], frame_label),
+                      'loss/train_LDS': (lds_ul.to(lds_l.device) + lds_l) / 2}
+        else:
+            losses = {'loss/test_frame': bce_mean(predictions['frame'], frame_label), 'loss/test_LDS': lds_l}
+        return predictions, losses, spec
+
+
+class Onset_stack_VAT(_Base):
+    """model/onset_frame_VAT.py:516-601 (`model_name='onset'`): the onset stack alone.  Its VAT branch references undefined
+    names in the reference (stepwise_VAT_onset_stack, :305-306), so only VAT=False exists."""
+
+    def __init__(self, input_features, output_features, model_complexity=48, log=True, mode='imagewise', spec='Mel', XI=1e-5,
+                 eps=10, VAT_mode='all'):
+        super().__init__(log, False, mode, spec, XI, eps)
+        model_size = model_complexity * 16
+        self.vat_loss = None
+        self.onset_stack = Onset_Stack(input_features, model_size, output_features,
+                                       nn.LSTM(model_size, model_size // 2, batch_first=True, bidirectional=True))
+
+    def forward(self, spec, detach=False):
+        b, t, _ = spec.shape
+        return self.onset_stack(spec, detach).view(b, t, -1)
+
+    def run_on_batch(self, batch, batch_ul=None, VAT=False):
+        if VAT:
+            raise NotImplementedError("Onset_stack_VAT: the reference's VAT branch raises NameError "
+                                      '(model/onset_frame_VAT.py:305-306); only VAT=False is defined')
+        audio_label, onset_label = batch['audio'], batch['onset']
+        spec = self._front(audio_label, audio_label.shape[-1]).squeeze(1)
+        onset_pred = self(spec)
+        accuracy = (onset_label == (onset_pred.detach() > 0.5)).float().sum() / onset_label.flatten(0).shape[0]
+        tag = 'train' if self.training else 'test'
+        lds = torch.tensor(0.)
+        losses = {f'loss/{tag}_onset': bce_mean(onset_pred.reshape(*onset_label.shape), onset_label),
+                  f'metric/{tag}_accuracy': accuracy,
+                  f'loss/{tag}_LDS': torch.mean(torch.stack((lds, lds)), dim=0) if self.training else lds}
+        return {'onset': onset_pred, 'r_adv': None}, losses, spec

@@ -511,6 +511,50 @@ def g_onset_frames():
             out[key + '_keys'] = np.array(list(lr.keys()))
             out[key + '_frame'] = digest(pr['frame'], 256)
             out[key + '_onset'] = digest(pr['onset'], 256)
+    # the single-stack variants of the baseline script (model_name = 'frame' / 'onset')
+    def zero_dropout(net):
+        for m in net.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+    for vat in (False, True):
+        for training in (True, False):
+            net = ref.Frame_stack_VAT(229, 88, model_complexity=48, log=True, mode='imagewise', spec='Mel', XI=1e-1, eps=2.0, VAT_mode='all')
+            params = oo.fixture_params(kind='frame')
+            net.load_state_dict(params, strict=True); zero_dropout(net); net.train(training)
+            bl = _batch(2, 64, 'L')
+            d0 = fx.fixture_noise((2, 64, 229), 'onf_fs_d0')
+            torch.randn_like = lambda t, **kw: (d0.clone().requires_grad_(True) if kw.get('requires_grad') else d0.clone())
+            try:
+                pr, lr, sr = net.run_on_batch(bl, None, vat)
+            finally:
+                torch.randn_like = real_randn_like
+            po, lo, so = oo.run_on_batch_frame_stack(fx.clone_params(params), training, bl, vat, 1e-1, 2.0, d0_l=d0)
+            assert list(lo.keys()) == list(lr.keys())
+            key = f'fs_v{int(vat)}_t{int(training)}'
+            for k in lr:
+                close(lo[k], lr[k], 1e-3 if 'LDS' in k else 2e-5, key + k)
+            close(po['frame'], pr['frame'], 2e-5, 'fs frame')
+            if vat:
+                close(po['r_adv'], pr['r_adv'], 1e-3, 'fs r_adv')
+                out[key + '_radv'] = digest(pr['r_adv'], 256)
+            out[key + '_losses'] = np.array([v.item() for v in lr.values()])
+            out[key + '_keys'] = np.array(list(lr.keys()))
+            out[key + '_frame'] = digest(pr['frame'], 256)
+    for training in (True, False):
+        net = ref.Onset_stack_VAT(229, 88, model_complexity=48, log=True, mode='imagewise', spec='Mel', XI=1e-5, eps=10, VAT_mode='all')
+        params = oo.fixture_params(kind='onset')
+        net.load_state_dict(params, strict=True); zero_dropout(net); net.train(training)
+        bl = _batch(2, 64, 'L')
+        pr, lr, sr = net.run_on_batch(bl, None, False)
+        po, lo, so = oo.run_on_batch_onset_stack(fx.clone_params(params), training, bl)
+        assert list(lo.keys()) == list(lr.keys())
+        key = f'os_t{int(training)}'
+        for k in lr:
+            close(lo[k], lr[k], 2e-5, key + k)
+        close(po['onset'], pr['onset'], 2e-5, 'os onset')
+        out[key + '_losses'] = np.array([v.item() for v in lr.values()])
+        out[key + '_keys'] = np.array(list(lr.keys()))
+        out[key + '_onset'] = digest(pr['onset'], 256)
     save('onset_frames', **out)
 
 

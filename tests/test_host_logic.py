@@ -89,7 +89,7 @@ def test_baseline_script_config_and_state_dict_surface():
     assert cfg['batch_size'] == cfg['train_batch_size'] == 8 and cfg['sequence_length'] == cfg['validation_length'] == 327680
     assert cfg['logdir'].startswith('my_runs/baseline_Onset_Frame-')
     with pytest.raises(NotImplementedError):
-        baseline_config({'model_name': 'frame'})
+        baseline_config({'model_name': 'attention'})
     m = ra.OnsetsAndFrames_VAT_full(229, 88, model_complexity=48, log=True, mode='imagewise', spec='Mel', XI=1e-6, eps=1e-1)
     sd = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     want = dict(oo.param_shapes())

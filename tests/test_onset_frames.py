@@ -286,3 +286,75 @@ def test_graph_replay_draws_new_dropout_masks(dev):
         torch.cuda.synchronize()
         seen.append(float(step.losses['loss/train_frame']))
     assert len(set(seen)) == 3, seen
+
+
+# ------------------------------------------------------------------------------------------------
+# single-stack variants of the baseline script (model_name = 'frame' / 'onset')
+# ------------------------------------------------------------------------------------------------
+def test_oracle_single_stack_variants():
+    from oracle import fixture as fx, onset_frames as oo
+    g = gold()
+    bl = _batch(2, 64, 'L')
+    d0 = fx.fixture_noise((2, 64, 229), 'onf_fs_d0')
+    for vat in (False, True):
+        pr, lo, _ = oo.run_on_batch_frame_stack(oo.fixture_params(kind='frame'), True, bl, vat, 1e-1, 2.0, d0_l=d0)
+        assert list(lo.keys()) == list(g[f'fs_v{int(vat)}_t1_keys'])
+        for k, v in zip(lo, g[f'fs_v{int(vat)}_t1_losses']):
+            assert abs(lo[k].item() - v) <= 1e-3 * abs(v) + 1e-12, k
+    pr, lo, _ = oo.run_on_batch_onset_stack(oo.fixture_params(kind='onset'), True, bl)
+    assert list(lo.keys()) == list(g['os_t1_keys'])
+    for k, v in zip(lo, g['os_t1_losses']):
+        assert abs(lo[k].item() - v) <= 2e-5 * abs(v) + 1e-12, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('vat,training', [(False, True), (False, False), (True, True), (True, False)])
+def test_frame_stack_vat_golden(dev, vat, training):
+    from oracle import fixture as fx, onset_frames as oo
+    from reconvat_amd import Frame_stack_VAT
+    g = gold()
+    m = Frame_stack_VAT(229, 88, model_complexity=48, log=True, mode='imagewise', spec='Mel', XI=1e-1, eps=2.0, VAT_mode='all')
+    m.load_state_dict(oo.fixture_params(kind='frame'))
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m.to(dev).train(training)
+    d0 = fx.fixture_noise((2, 64, 229), 'onf_fs_d0').to(dev)
+    m.vat_loss.noise = lambda t: d0.clone()
+    bl = {k: v.to(dev) for k, v in _batch(2, 64, 'L').items()}
+    pr, lo, spec = m.run_on_batch(bl, None, vat)
+    key = f'fs_v{int(vat)}_t{int(training)}'
+    assert list(lo.keys()) == list(g[key + '_keys'])
+    for k, v in zip(lo, g[key + '_losses']):
+        assert abs(float(lo[k].detach()) - v) <= 1e-3 * abs(v) + 1e-12, (k, float(lo[k].detach()), v)
+    close_digest(pr['frame'], g[key + '_frame'], 1e-3, 256)
+    if vat:
+        close_digest(pr['r_adv'], g[key + '_radv'], 3e-3, 256)
+    if training:
+        sum(lo.values()).backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    with pytest.raises(RuntimeError, match='not executable'):
+        m.run_on_batch(bl, bl, True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('training', [True, False])
+def test_onset_stack_golden(dev, training):
+    from oracle import onset_frames as oo
+    from reconvat_amd import Onset_stack_VAT
+    g = gold()
+    m = Onset_stack_VAT(229, 88, model_complexity=48, log=True, mode='imagewise', spec='Mel')
+    m.load_state_dict(oo.fixture_params(kind='onset'))
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m.to(dev).train(training)
+    bl = {k: v.to(dev) for k, v in _batch(2, 64, 'L').items()}
+    pr, lo, spec = m.run_on_batch(bl, None, False)
+    key = f'os_t{int(training)}'
+    assert list(lo.keys()) == list(g[key + '_keys'])
+    for k, v in zip(lo, g[key + '_losses']):
+        assert abs(float(lo[k].detach()) - v) <= 1e-3 * abs(v) + 1e-12, (k, float(lo[k].detach()), v)
+    close_digest(pr['onset'], g[key + '_onset'], 1e-3, 256)
+    with pytest.raises(NotImplementedError):
+        m.run_on_batch(bl, None, True)
