@@ -26,6 +26,14 @@
 #ifndef RV_LSTM_STAGE
 #define RV_LSTM_STAGE 1   // forward: stage h_{t-1} through LDS (measured faster than per-lane fragment loads from L2)
 #endif
+#ifndef RV_LSTM_XCD
+#define RV_LSTM_XCD 0     // 1: exchange h_t / dpre_t inside one XCD's L2 with the data as its own ready flag (see below).
+                          // Functional (all operator tests pass), measured 4.8 instead of 5.3 us per forward step but 10.5
+                          // instead of 6.6 us per backward step (16 waves polling dwords), and it pins every launch to XCDs
+                          // 0 and 1, so concurrent launches of the multi-stream step do not fit (32 CUs per XCD) and time
+                          // out.  Kept as an experiment knob; the counter protocol is the shipped path.
+#endif
+#define LSTM_SENTINEL 0xFFFFFFFFu      // "not written yet" bit pattern of the exchange tensors (a NaN no kernel here produces)
 #ifndef RV_LSTM_KS
 #define RV_LSTM_KS 4      // K slices per tile for H = 384: 16 waves per workgroup, 24 MFMAs per wave and step
 #endif
@@ -44,6 +52,23 @@ struct LstmArgs {
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// XCD-local exchange (RV_LSTM_XCD).  The dispatcher places workgroup b of a 1-D grid on XCD b % 8 (tools/xcc_probe.hip reads
+// XCC_ID: no exception over grids of 48..2048 workgroups), so the kernels run direction d on the workgroups with b % 8 == d
+// and retire the others at once: all workgroups that exchange data then share ONE L2, which is the coherence point --
+// plain dword stores (the vector L1 is write-through) and L1-bypassing dword loads (relaxed agent-scope atomics, sc1) that
+// hit the freshly written lines in that L2.  The exchange tensor is pre-filled with a sentinel and every word is written
+// exactly once, so the data is its own ready flag: a reader polls the words it needs until none is the sentinel.  No
+// counters, no fences, no L2 write-back / invalidate on the per-step critical path; if the placement assumption ever
+// failed, readers would time out (flags[last] set, checked by the host) -- never compute on stale values.
+__device__ __forceinline__ void xstore(float* p, float v) {
+#if RV_LSTM_XCD
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ float xload(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // wait until every workgroup of this direction has published step >= s; wave 0 polls, one counter per lane
 template <int NWG>
@@ -69,16 +94,24 @@ template <int H, int KS>
 __global__ __launch_bounds__(256 * KS) void lstm_fwd_k(LstmArgs a) {
     constexpr int KW = H / KS, NC = KW / 16, NWG = H / 16;
     static_assert(KW % 16 == 0 && NWG <= 64, "K slice must be whole 16-chunks; one polling lane per workgroup");
+#if RV_LSTM_XCD
+    const int d = blockIdx.x & 7, j = blockIdx.x >> 3;      // direction d lives on XCD d
+    if (d >= 2) return;
+#else
     const int d = blockIdx.x / NWG, j = blockIdx.x - d * NWG;
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
     const int tile = wave & 3, kpart = wave >> 2;
     const int B = a.B, T = a.T;
     __shared__ f32x4 part[KS > 1 ? KS - 1 : 1][4][64];
-#if RV_LSTM_STAGE
+#if RV_LSTM_STAGE || RV_LSTM_XCD
     __shared__ __attribute__((aligned(16))) float hs[16][H + 4];
 #endif
     int* flag = a.flags + d * NWG;
     int* err = a.flags + 2 * NWG;
+    int spins = 0;
+    bool dead = false;          // set (block-uniformly) after a time-out: stop polling, results are flagged invalid
+    (void)flag; (void)spins; (void)dead;
 
     const int ubase = j * 16 + tile * 4;
     f32x4 wreg[NC];
@@ -100,10 +133,27 @@ __global__ __launch_bounds__(256 * KS) void lstm_fwd_k(LstmArgs a) {
             for (int i = 0; i < 4; ++i) pre[i] = a.xg[cellbase + (long)i * H];
         }
         if (s > 0) {
-            wait_step<NWG>(flag, err, s, tid);
             const int tp = d ? t + 1 : t - 1;
             f32x4 hb[NC];
-#if RV_LSTM_STAGE
+#if RV_LSTM_XCD
+            // poll h_{t-1} (B x H) into LDS until no word is the sentinel (all threads load, block-wide vote)
+            while (true) {
+                bool ok = true;
+                for (int idx = tid; idx < B * (H / 4); idx += 256 * KS) {
+                    const int bb = idx / (H / 4), k4 = idx - bb * (H / 4);
+                    const float* src = a.out + ((long)bb * T + tp) * 2 * H + d * H + 4 * k4;
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { v[i] = xload(src + i); ok &= (__float_as_uint(v[i]) != LSTM_SENTINEL); }
+                    *reinterpret_cast<f32x4*>(&hs[bb][4 * k4]) = v;
+                }
+                if (__syncthreads_and(ok || dead)) break;
+                if (++spins > LSTM_SPIN_LIMIT) { dead = true; if (tid == 0) atomicOr(err, 1); }     // block-uniform
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) hb[c] = *reinterpret_cast<const f32x4*>(&hs[brow][kpart * KW + 16 * c + 4 * g]);
+#elif RV_LSTM_STAGE
+            wait_step<NWG>(flag, err, s, tid);
             // h_{t-1} (B x H) once per workgroup through LDS: one 16-byte load per thread instead of NC per lane
             for (int idx = tid; (RV_LSTM_ABL & 2) == 0 && idx < B * (H / 4); idx += 256 * KS) {
                 const int bb = idx / (H / 4), k4 = idx - bb * (H / 4);
@@ -114,6 +164,7 @@ __global__ __launch_bounds__(256 * KS) void lstm_fwd_k(LstmArgs a) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) hb[c] = *reinterpret_cast<const f32x4*>(&hs[brow][kpart * KW + 16 * c + 4 * g]);
 #else
+            wait_step<NWG>(flag, err, s, tid);
             const float* hp = a.out + ((long)brow * T + tp) * 2 * H + d * H + kpart * KW + 4 * g;
 #pragma unroll
             for (int c = 0; c < NC; ++c) hb[c] = *reinterpret_cast<const f32x4*>(hp + 16 * c);
@@ -139,14 +190,16 @@ __global__ __launch_bounds__(256 * KS) void lstm_fwd_k(LstmArgs a) {
             const float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), gg = tanhf(pre[2]), go = sigmoidf_(pre[3]);
             cstate = fmaf(gf, cstate, gi * gg);
             const float h = go * tanhf(cstate);
-            a.out[((long)b * T + t) * 2 * H + d * H + unit] = h;
+            xstore(&a.out[((long)b * T + t) * 2 * H + d * H + unit], h);
             if (a.gates && (RV_LSTM_ABL & 4) == 0) {
                 a.gates[cellbase] = gi; a.gates[cellbase + H] = gf; a.gates[cellbase + 2 * H] = gg; a.gates[cellbase + 3 * H] = go;
                 a.cs[(((long)b * T + t) * 2 + d) * H + unit] = cstate;
             }
         }
+#if !RV_LSTM_XCD
         __syncthreads();      // every wave's h_t stores are issued and complete (workgroup-scope release) ...
         if (tid == 0) __hip_atomic_store(&flag[j], s + 1, (RV_LSTM_ABL & 1) ? __ATOMIC_RELAXED : __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... and published
+#endif
     }
 }
 
@@ -158,12 +211,20 @@ template <int H, int KS>
 __global__ __launch_bounds__(256 * KS) void lstm_bwd_k(LstmArgs a) {
     constexpr int NW = 4 * KS, KW = 4 * H / NW, NC = KW / 16, NWG = H / 16;
     static_assert(KW % 16 == 0, "K slice must be whole 16-chunks");
+#if RV_LSTM_XCD
+    const int d = blockIdx.x & 7, j = blockIdx.x >> 3;      // direction d lives on XCD d
+    if (d >= 2) return;
+#else
     const int d = blockIdx.x / NWG, j = blockIdx.x - d * NWG;
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
     const int B = a.B, T = a.T;
-    __shared__ float part[NW][16][16];
+    __shared__ float part[2][NW][16][16];       // double-buffered by step parity (no barrier between read and next write)
     int* flag = a.flags + d * NWG;
     int* err = a.flags + 2 * NWG;
+    int spins = 0;
+    bool dead = false;          // wave-uniform: set after a time-out
+    (void)flag; (void)spins; (void)dead;
 
     // A operand: row li <-> unit 16j + li; k <-> W_hh row wave*KW + 16c + 4g + {0..3}
     float wreg[NC][4];
@@ -190,24 +251,36 @@ __global__ __launch_bounds__(256 * KS) void lstm_bwd_k(LstmArgs a) {
             dh = a.dout[((long)b * T + t) * 2 * H + d * H + unit];
         }
         if (s > 0) {
-            wait_step<NWG>(flag, err, s, tid);
             const int tn = d ? t - 1 : t + 1;        // handled in the previous iteration
             const float* dp = a.dxg + (((long)brow * T + tn) * 2 + d) * 4 * H + wave * KW + 4 * g;
             f32x4 db[NC];
+#if RV_LSTM_XCD
+            while (true) {                            // every wave polls its own K slice of dpre_{t'}
+                bool ok = true;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { db[c][q] = xload(dp + 16 * c + q); ok &= (__float_as_uint(db[c][q]) != LSTM_SENTINEL); }
+                if (__all(ok) || dead) break;
+                if (++spins > LSTM_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(err, 1); }
+            }
+#else
+            wait_step<NWG>(flag, err, s, tid);
 #pragma unroll
             for (int c = 0; c < NC; ++c) db[c] = *reinterpret_cast<const f32x4*>(dp + 16 * c);
+#endif
             f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int c = 0; c < NC; ++c)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[c][q], db[c][q], acc[q & 1], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) part[wave][4 * g + i][li] = acc[0][i] + acc[1][i];
+            for (int i = 0; i < 4; ++i) part[s & 1][wave][4 * g + i][li] = acc[0][i] + acc[1][i];
             __syncthreads();
             if (cell) {
                 float r = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) r += part[w][(tid >> 4) & 15][b];
+                for (int w = 0; w < NW; ++w) r += part[s & 1][w][(tid >> 4) & 15][b];
                 dh += r;
             }
         }
@@ -217,13 +290,15 @@ __global__ __launch_bounds__(256 * KS) void lstm_bwd_k(LstmArgs a) {
             const float dc = fmaf(dh * go, 1.f - th * th, dc_carry);
             const float d_i = dc * gg, d_g = dc * gi, d_f = dc * cp;
             dc_carry = dc * gf;
-            a.dxg[cellbase] = d_i * gi * (1.f - gi);
-            a.dxg[cellbase + H] = d_f * gf * (1.f - gf);
-            a.dxg[cellbase + 2 * H] = d_g * (1.f - gg * gg);
-            a.dxg[cellbase + 3 * H] = d_o * go * (1.f - go);
+            xstore(&a.dxg[cellbase], d_i * gi * (1.f - gi));
+            xstore(&a.dxg[cellbase + H], d_f * gf * (1.f - gf));
+            xstore(&a.dxg[cellbase + 2 * H], d_g * (1.f - gg * gg));
+            xstore(&a.dxg[cellbase + 3 * H], d_o * go * (1.f - go));
         }
+#if !RV_LSTM_XCD
         __syncthreads();
         if (tid == 0) __hip_atomic_store(&flag[j], s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     }
 }
 
@@ -244,7 +319,12 @@ extern "C" int rv_lstm_fwd(const float* xg, const float* whh_fwd, const float* w
     LstmArgs a = {};
     a.xg = xg; a.whh[0] = whh_fwd; a.whh[1] = whh_rev; a.out = out; a.gates = gates; a.cs = cs; a.flags = flags; a.B = B; a.T = T;
     if (hipMemsetAsync(flags, 0, rv_lstm_flag_bytes(H), st) != hipSuccess) { rv_set_error("rv_lstm_fwd: memset failed"); return RV_ELAUNCH; }
+#if RV_LSTM_XCD
+    if (hipMemsetAsync(out, 0xFF, (size_t)B * T * 2 * H * sizeof(float), st) != hipSuccess) { rv_set_error("rv_lstm_fwd: memset failed"); return RV_ELAUNCH; }
+    dim3 grid(8 * (H / 16));      // workgroup b -> XCD b % 8; only b % 8 < 2 (one XCD per direction) do work
+#else
     dim3 grid(2 * (H / 16));
+#endif
     if (H == 384) hipLaunchKernelGGL((lstm_fwd_k<384, RV_LSTM_KS>), grid, dim3(256 * RV_LSTM_KS), 0, st, a);
     else hipLaunchKernelGGL((lstm_fwd_k<32, 2>), grid, dim3(512), 0, st, a);
     RV_LAUNCH_CHECK("lstm_fwd");
@@ -259,7 +339,12 @@ extern "C" int rv_lstm_bwd(const float* dout, const float* whh_fwd, const float*
     a.dout = dout; a.whh[0] = whh_fwd; a.whh[1] = whh_rev; a.gates = const_cast<float*>(gates); a.cs = const_cast<float*>(cs);
     a.dxg = dxg; a.flags = flags; a.B = B; a.T = T;
     if (hipMemsetAsync(flags, 0, rv_lstm_flag_bytes(H), st) != hipSuccess) { rv_set_error("rv_lstm_bwd: memset failed"); return RV_ELAUNCH; }
+#if RV_LSTM_XCD
+    if (hipMemsetAsync(dxg, 0xFF, (size_t)B * T * 8 * H * sizeof(float), st) != hipSuccess) { rv_set_error("rv_lstm_bwd: memset failed"); return RV_ELAUNCH; }
+    dim3 grid(8 * (H / 16));
+#else
     dim3 grid(2 * (H / 16));
+#endif
     if (H == 384) hipLaunchKernelGGL((lstm_bwd_k<384, RV_LSTM_KS>), grid, dim3(256 * RV_LSTM_KS), 0, st, a);
     else hipLaunchKernelGGL((lstm_bwd_k<32, 2>), grid, dim3(512), 0, st, a);
     RV_LAUNCH_CHECK("lstm_bwd");
