@@ -66,6 +66,19 @@ long rv_conv_wgrad_workspace_bytes(int taps, int B, int Hv, int Ca, int Cb);
 int rv_conv_wgrad(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, const float* V, int v_ld, int Hv, int Wv,
                   int Cb, int B, float* dw, long s_a, long s_b, int flip, float* dbias, int accumulate, void* workspace,
                   long workspace_bytes, void* stream);
+/* Deferred weight-gradient reductions: rv_conv_wgrad_deferred launches only the partial-sum kernel of rv_conv_wgrad and
+ * writes the pending reduction (which ADDS into dw / dbias, fp32 atomics) to *entry_host (rv_wgrad_table_entry_bytes() bytes
+ * of HOST memory); it returns the number of workgroups that reduction needs (> 0) or a negative status.  After the last
+ * entry, rv_wgrad_table_finalize(table_host, count) turns the counts into block offsets and returns the total; a DEVICE copy
+ * of the table then runs every reduction of a backward pass in ONE launch (rv_wgrad_reduce_table).  Workspaces must stay
+ * untouched until then.  (One reduction launch per layer is launch-latency bound: 161 launches of ~5 us per step.) */
+long rv_conv_wgrad_deferred(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, const float* V, int v_ld, int Hv, int Wv,
+                            int Cb, int B, float* dw, long s_a, long s_b, int flip, float* dbias, void* workspace,
+                            long workspace_bytes, void* entry_host, void* stream);
+long rv_wgrad_table_entry_bytes(void);
+long rv_wgrad_table_finalize(void* table_host, int count);
+int rv_wgrad_reduce_table(const void* table_dev, int count, long total_blocks, void* stream);
+
 
 /* ---- BatchNorm2d(momentum=0.1) + leaky_relu (+ residual) (model/UNet_onset.py:183,196-199,221-223) --
  * coef [5C] = mean, invstd, scale, shift, unbiased batch variance (saved for backward).  training: 0 eval, 1 train,

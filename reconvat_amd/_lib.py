@@ -31,6 +31,10 @@ SIGNATURES = {
     'rv_conv_fwd': (I, [I, P, I, I, I, I, I, P, I, I, I, I, P, P, I, I, P, P, I, P, F, P]),
     'rv_conv_wgrad_workspace_bytes': (L, [I, I, I, I, I]),
     'rv_conv_wgrad': (I, [I, P, I, I, I, I, P, I, I, I, I, I, P, L, L, I, P, I, P, L, P]),
+    'rv_conv_wgrad_deferred': (L, [I, P, I, I, I, I, P, I, I, I, I, I, P, L, L, I, P, P, L, P, P]),
+    'rv_wgrad_table_entry_bytes': (L, []),
+    'rv_wgrad_table_finalize': (L, [P, I]),
+    'rv_wgrad_reduce_table': (I, [P, I, L, P]),
     'rv_bn_workspace_bytes': (L, [I]),
     'rv_bn_lrelu_fwd': (I, [P, I, L, I, P, P, P, P, P, F, F, I, F, P, I, P, I, P, P, I, P]),
     'rv_bn_running_update': (I, [P, P, P, P, I, F, P]),

@@ -1143,13 +1143,12 @@ struct WreduceArgs {
 // EL output elements x (256 / EL) partial lanes per workgroup.  The host picks EL so that the grid fills the chip:
 // the small-channel layers have few outputs but hundreds of partials, and with 64 elements per workgroup their
 // reduction was a handful of workgroups walking long dependent load chains (38 us for 144 outputs).
-template <int EL>
-__global__ __launch_bounds__(256) void wgrad_reduce_k(WreduceArgs a) {
+template <int EL, bool ATOMIC>
+__device__ __forceinline__ void wgrad_reduce_body(const WreduceArgs& a, long block, float* sh) {
     constexpr int PL = 256 / EL;
-    __shared__ float sh[256];
     const long nel = (long)a.taps * a.Ca * a.Cb + (a.dbias ? a.Cb : 0);
     const int el = threadIdx.x % EL, pl = threadIdx.x / EL;
-    const long e = (long)blockIdx.x * EL + el;
+    const long e = block * EL + el;
     float s0 = 0.f, s1 = 0.f;
     if (e < nel) {
         const float* p = a.part + e;
@@ -1177,11 +1176,46 @@ __global__ __launch_bounds__(256) void wgrad_reduce_k(WreduceArgs a) {
         int tap = (int)(t / a.Ca);
         int tt = a.flip ? (a.taps - 1 - tap) : tap;
         float* d = a.dw + (long)aa * a.s_a + (long)bb * a.s_b + tt;
-        *d = a.accumulate ? *d + s : s;
+        if (ATOMIC) atomicAdd(d, s);
+        else *d = a.accumulate ? *d + s : s;
     } else {
         float* d = a.dbias + (e - nw);
-        *d = a.accumulate ? *d + s : s;
+        if (ATOMIC) atomicAdd(d, s);
+        else *d = a.accumulate ? *d + s : s;
     }
+}
+
+template <int EL>
+__global__ __launch_bounds__(256) void wgrad_reduce_k(WreduceArgs a) {
+    __shared__ float sh[256];
+    wgrad_reduce_body<EL, false>(a, blockIdx.x, sh);
+}
+
+// All deferred reductions of a backward pass in ONE launch (rv_wgrad_reduce_table): a workgroup finds its entry by
+// bisection over the block prefix.  Several entries may target the same gradient (the same layer in several passes of the
+// step), so the final add is an fp32 atomic.
+struct WreduceEntry {
+    WreduceArgs a;
+    long block0;      // nblocks until rv_wgrad_table_finalize turns it into the exclusive prefix
+    int el;           // elements per workgroup: 4, 16 or 64
+    int pad;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_table_k(const WreduceEntry* tab, int count) {
+    __shared__ WreduceEntry ent;
+    __shared__ float sh[256];
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = count - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tab[mid].block0 <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        ent = tab[lo];
+    }
+    __syncthreads();
+    const long block = (long)blockIdx.x - ent.block0;
+    if (ent.el == 64) wgrad_reduce_body<64, true>(ent.a, block, sh);
+    else if (ent.el == 16) wgrad_reduce_body<16, true>(ent.a, block, sh);
+    else wgrad_reduce_body<4, true>(ent.a, block, sh);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1585,13 +1619,58 @@ long rv_conv_wgrad_workspace_bytes(int taps, int B, int Hv, int Ca, int Cb) {
 // G[tap][a][b] = sum_p U[f(p,tap)][a] * V[p][b], db[b] = sum_p V[p][b]; results scattered to
 //   dw[a*s_a + b*s_b + (flip ? taps-1-tap : tap)],  dbias[b]
 // mode: 0 = 3x3 s1 p1 (U = conv input, V = dY), 1 = 1x1, 2 = 2x2 s2 (U gathered at 2p+tap)
+static int conv_wgrad_impl(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, const float* V, int v_ld, int Hv, int Wv,
+                           int Cb, int B, float* dw, long s_a, long s_b, int flip, float* dbias, int accumulate, void* workspace,
+                           long workspace_bytes, void* stream, WreduceEntry* defer);
+
 int rv_conv_wgrad(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, const float* V, int v_ld, int Hv, int Wv,
                   int Cb, int B, float* dw, long s_a, long s_b, int flip, float* dbias, int accumulate, void* workspace,
                   long workspace_bytes, void* stream) {
+    return conv_wgrad_impl(mode, U, u_ld, Hu, Wu, Ca, V, v_ld, Hv, Wv, Cb, B, dw, s_a, s_b, flip, dbias, accumulate, workspace,
+                           workspace_bytes, stream, nullptr);
+}
+
+// Deferred form: launches only the partial-sum kernel and writes the description of the pending reduction (which ADDS into
+// dw / dbias) to *entry_host (rv_wgrad_table_entry_bytes() bytes of host memory).  The workspace must stay untouched until
+// rv_wgrad_reduce_table has run.  Returns the number of workgroups the reduction needs (> 0) or a negative status.
+long rv_conv_wgrad_deferred(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, const float* V, int v_ld, int Hv, int Wv,
+                            int Cb, int B, float* dw, long s_a, long s_b, int flip, float* dbias, void* workspace,
+                            long workspace_bytes, void* entry_host, void* stream) {
+    if (!entry_host) { rv_set_error("rv_conv_wgrad_deferred: null entry"); return RV_EINVAL; }
+    WreduceEntry* e = (WreduceEntry*)entry_host;
+    const int rc = conv_wgrad_impl(mode, U, u_ld, Hu, Wu, Ca, V, v_ld, Hv, Wv, Cb, B, dw, s_a, s_b, flip, dbias, 1, workspace,
+                                   workspace_bytes, stream, e);
+    return rc != RV_OK ? (long)rc : e->block0;
+}
+
+long rv_wgrad_table_entry_bytes(void) { return (long)sizeof(WreduceEntry); }
+
+// in place: per-entry workgroup counts -> exclusive prefix; returns the total number of workgroups
+long rv_wgrad_table_finalize(void* table_host, int count) {
+    WreduceEntry* tab = (WreduceEntry*)table_host;
+    long total = 0;
+    for (int i = 0; i < count; ++i) { const long n = tab[i].block0; tab[i].block0 = total; total += n; }
+    return total;
+}
+
+// table_dev: DEVICE copy of a finalized table
+int rv_wgrad_reduce_table(const void* table_dev, int count, long total_blocks, void* stream) {
+    if (count <= 0 || total_blocks <= 0) return RV_OK;
+    RV_CHECK_ARG(table_dev, "rv_wgrad_reduce_table: null table");
+    hipLaunchKernelGGL(wgrad_reduce_table_k, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const WreduceEntry*)table_dev, count);
+    RV_LAUNCH_CHECK("rv_wgrad_reduce_table");
+    return RV_OK;
+}
+
+static int conv_wgrad_impl(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, const float* V, int v_ld, int Hv, int Wv,
+                           int Cb, int B, float* dw, long s_a, long s_b, int flip, float* dbias, int accumulate, void* workspace,
+                           long workspace_bytes, void* stream, WreduceEntry* defer) {
     hipStream_t st = (hipStream_t)stream;
     RV_CHECK_ARG(mode >= 0 && mode <= 2, "rv_conv_wgrad: bad mode %d", mode);
     const int taps = mode == 0 ? 9 : (mode == 1 ? 1 : 4);
     if (wgrad_sliced(taps, Ca, Cb)) {
+        if (defer) { rv_set_error("rv_conv_wgrad_deferred: the sliced 1 -> %d channel case has no deferred form", Cb); return RV_EUNSUPPORTED; }
         for (int c0 = 0; c0 < Cb; c0 += 16) {
             const int rc = rv_conv_wgrad(mode, U, u_ld, Hu, Wu, Ca, V + c0, v_ld, Hv, Wv, 16, B, dw + c0 * s_b, s_a, s_b, flip,
                                          dbias ? dbias + c0 : nullptr, accumulate, workspace, workspace_bytes, stream);
@@ -1663,13 +1742,19 @@ int rv_conv_wgrad(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, co
     }
 reduce:
     RV_LAUNCH_CHECK("rv_conv_wgrad");
-    {
+    static const int skip_reduce = getenv("RV_ABL_SKIP_WREDUCE") ? atoi(getenv("RV_ABL_SKIP_WREDUCE")) : 0;   // timing ablation (wrong results)
+    if (!skip_reduce) {
         WreduceArgs r;
         r.part = a.part; r.pstride = a.pstride; r.nparts = a.nparts; r.taps = taps; r.Ca = Ca; r.Cb = Cb;
         r.dw = dw; r.s_a = s_a; r.s_b = s_b; r.flip = flip; r.dbias = dbias; r.accumulate = accumulate;
         long nel = (long)taps * Ca * Cb + (dbias ? Cb : 0);
-        if (cdiv(nel, 64) >= 256 || a.nparts <= 8) hipLaunchKernelGGL(wgrad_reduce_k<64>, dim3(cdiv(nel, 64)), dim3(256), 0, st, r);
-        else if (cdiv(nel, 16) >= 256 || a.nparts <= 32) hipLaunchKernelGGL(wgrad_reduce_k<16>, dim3(cdiv(nel, 16)), dim3(256), 0, st, r);
+        const int el = (cdiv(nel, 64) >= 256 || a.nparts <= 8) ? 64 : ((cdiv(nel, 16) >= 256 || a.nparts <= 32) ? 16 : 4);
+        if (defer) {
+            defer->a = r; defer->block0 = cdiv(nel, el); defer->el = el; defer->pad = 0;
+            return RV_OK;
+        }
+        if (el == 64) hipLaunchKernelGGL(wgrad_reduce_k<64>, dim3(cdiv(nel, 64)), dim3(256), 0, st, r);
+        else if (el == 16) hipLaunchKernelGGL(wgrad_reduce_k<16>, dim3(cdiv(nel, 16)), dim3(256), 0, st, r);
         else hipLaunchKernelGGL(wgrad_reduce_k<4>, dim3(cdiv(nel, 4)), dim3(256), 0, st, r);
         RV_LAUNCH_CHECK("rv_conv_wgrad(reduce)");
     }

@@ -428,11 +428,92 @@ def conv_wgrad(kind, x, dy, w, want_bias=True, dw_acc=None, db_acc=None):
         bias_ptr = ptr(db)
     nbytes = lib.rv_conv_wgrad_workspace_bytes(taps, bb, hv, ca, cb)
     ws = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
-    call('rv_conv_wgrad', mode, ptr(u), uld, hu, wu, ca, ptr(v), vld, hv, wv, cb, bb, ptr(dw), s_a, s_b, flip,
-         bias_ptr, acc, ptr(ws), nbytes, stream())
+    tables = _WGRAD_DEFER[0]
+    if tables is not None and acc and not (taps == 9 and ca == 1 and cb > 16):
+        cur = torch.cuda.current_stream(w.device)
+        tab = tables.get(cur.cuda_stream)
+        if tab is None:
+            tab = tables[cur.cuda_stream] = _WgradTable(w.device, cur)
+        rc = lib.rv_conv_wgrad_deferred(mode, ptr(u), uld, hu, wu, ca, ptr(v), vld, hv, wv, cb, bb, ptr(dw), s_a, s_b, flip,
+                                        bias_ptr, ptr(ws), nbytes, tab.slot(), cur.cuda_stream)
+        if rc <= 0:
+            raise RuntimeError(f'rv_conv_wgrad_deferred failed ({rc}): {_lib.last_error()}')
+        tab.n += 1
+        tab.keep.append(ws)
+    else:
+        call('rv_conv_wgrad', mode, ptr(u), uld, hu, wu, ca, ptr(v), vld, hv, wv, cb, bb, ptr(dw), s_a, s_b, flip,
+             bias_ptr, acc, ptr(ws), nbytes, stream())
     if kind == 'up' and want_bias:
         call('rv_colsum', ptr(dy), yld, bb * ho * wo, cout, ptr(db), acc, stream())
     return (None, None) if acc else (dw, db)
+
+
+# --------------------------------------------------------------------------------------------
+# deferred weight-gradient reductions: one table-driven launch per stream and backward pass
+# --------------------------------------------------------------------------------------------
+_WGRAD_DEFER = [None]
+_WGRAD_POOL = []           # pre-allocated pinned host tables for hipGraph capture (never recycled once captured)
+_WGRAD_KEEP = []
+_WGRAD_MAX = 512           # entries per table
+
+
+def prepare_wgrad_tables(n=3):
+    """Pinned host tables for deferred_wgrad_reductions under hipGraph capture (call outside capture)."""
+    eb = _lib.load().rv_wgrad_table_entry_bytes()
+    while len(_WGRAD_POOL) < n:
+        _WGRAD_POOL.append(torch.empty(_WGRAD_MAX * eb, dtype=torch.uint8).pin_memory())
+
+
+class _WgradTable:
+    def __init__(self, device, torch_stream):
+        self.eb = _lib.load().rv_wgrad_table_entry_bytes()
+        self.device, self.stream, self.n, self.keep = device, torch_stream, 0, []
+        if torch.cuda.is_current_stream_capturing():
+            if not _WGRAD_POOL:
+                raise RuntimeError('deferred_wgrad_reductions: no pinned table left for hipGraph capture')
+            self.host = _WGRAD_POOL.pop()
+            _WGRAD_KEEP.append(self.host)
+            self.pinned = True
+        else:
+            self.host = torch.empty(_WGRAD_MAX * self.eb, dtype=torch.uint8)
+            self.pinned = False
+
+    def slot(self):
+        if self.n >= _WGRAD_MAX:
+            raise RuntimeError('deferred_wgrad_reductions: table full')
+        return self.host.data_ptr() + self.n * self.eb
+
+    def flush(self):
+        if self.n == 0:
+            return
+        lib = _lib.load()
+        total = lib.rv_wgrad_table_finalize(self.host.data_ptr(), self.n)
+        used = self.host[:self.n * self.eb]
+        with torch.cuda.stream(self.stream):
+            src = used if self.pinned else used.pin_memory()
+            table = src.to(self.device, non_blocking=True)
+            call('rv_wgrad_reduce_table', ptr(table), self.n, total, self.stream.cuda_stream)
+            table.record_stream(self.stream)
+        self.n, self.keep = 0, []
+
+
+class deferred_wgrad_reductions:
+    """While active, conv weight-gradient calls that accumulate into param.grad launch only their partial-sum kernel; the
+    reductions of ALL layers run as one launch per stream at ``flush()`` (call it after backward, before the gradients are
+    read).  One reduction launch per layer is launch-latency bound (161 launches of ~5 us per step)."""
+
+    def __enter__(self):
+        self.prev = _WGRAD_DEFER[0]
+        self.tables = {}
+        _WGRAD_DEFER[0] = self.tables
+        return self
+
+    def __exit__(self, *exc):
+        _WGRAD_DEFER[0] = self.prev
+
+    def flush(self):
+        for t in self.tables.values():
+            t.flush()
 
 
 def _out_hw(kind, h, w, size):

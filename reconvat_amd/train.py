@@ -6,6 +6,9 @@ over flat parameter / gradient buffers (the same flat gradient buffer is what ge
 in data-parallel runs).  ``TrainStep`` runs one optimiser step -- optionally captured ONCE into a
 hipGraph and replayed, which removes the ~1.5-2 k kernel launches per step from the host critical path.
 """
+import contextlib
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -181,6 +184,8 @@ class TrainStep:
         self._dual_ready = False              # ... from the second step on: the first one packs weights and autotunes
         if dual_stream and self.batch['audio'].is_cuda:
             ops.prepare_replay_pool()
+        if graph and self.batch['audio'].is_cuda:
+            ops.prepare_wgrad_tables(len(ops._WGRAD_POOL) + 3)
 
     def _fwd_bwd(self):
         self.opt.zero_grad()
@@ -195,10 +200,14 @@ class TrainStep:
             twins = self.opt.enable_side_bucket(n_side)
             ops.SIDE_GRADS[0] = (self.opt.flat_grad, {ops.side_stream(dev, i).cuda_stream: twins[i] for i in range(n_side)})
         try:
-            with ops.direct_param_grads():      # conv grads accumulate straight into the flat bucket
+            defer = os.environ.get('RV_DEFER_WGRAD', '1') != '0' and getattr(self.model, 'defer_wgrad_reductions', True)
+            with ops.direct_param_grads(), (ops.deferred_wgrad_reductions() if defer else contextlib.nullcontext()) as pending:
+                # conv grads accumulate straight into the flat bucket; their partial sums are folded by ONE launch per stream
                 _, losses, _ = self.model.run_on_batch(self.batch, self.batch_ul, self.VAT)
                 loss = weighted_loss(losses, self.alpha)
                 loss.backward()
+                if pending is not None:
+                    pending.flush()
             if dual:
                 # the side stream ran the reconstruction branch's backward into its own bucket: join, then fold
                 for i in range(n_side):
