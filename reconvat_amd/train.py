@@ -22,14 +22,28 @@ def cycle(iterable):
             yield item
 
 
+_WEIGHTS = {}
+
+
 def weighted_loss(losses, alpha):
-    """model/helper_functions.py:589-595: every 'loss/train_LDS*' key weighs alpha/2, all others 1."""
+    """model/helper_functions.py:589-595: every 'loss/train_LDS*' key weighs alpha/2, all others 1.  Device-resident
+    terms are summed as ONE stacked dot product (a handful of launches instead of ~30 scalar kernels forward + backward)."""
+    weight = lambda key: alpha / 2 if key.startswith('loss/train_LDS') else 1.0
+    dev = [(k, v) for k, v in losses.items() if torch.is_tensor(v) and v.is_cuda]
     loss = 0
-    for key in losses.keys():
-        if key.startswith('loss/train_LDS'):
-            loss = loss + alpha * losses[key] / 2
-        else:
-            loss = loss + losses[key]
+    for key, v in losses.items():
+        if not (torch.is_tensor(v) and v.is_cuda):
+            loss = loss + weight(key) * v if key.startswith('loss/train_LDS') else loss + v
+    if len(dev) == 1:
+        key, v = dev[0]
+        loss = loss + (alpha * v / 2 if key.startswith('loss/train_LDS') else v)
+    elif dev:
+        ws = tuple(float(weight(k)) for k, _ in dev)
+        ck = (ws, dev[0][1].device)
+        w = _WEIGHTS.get(ck)
+        if w is None:
+            w = _WEIGHTS[ck] = torch.tensor(ws, dtype=torch.float32, device=dev[0][1].device)
+        loss = loss + torch.dot(torch.stack([v.reshape(()) for _, v in dev]), w)
     return loss
 
 
