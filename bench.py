@@ -64,11 +64,20 @@ def measure_conv_phase(step_fn, device):
 
     import reconvat_amd.ops as ops
     ops.call = spy
+    # the recorded step runs the weight gradients in their immediate form (partial sums + per-layer reduction) so that every
+    # conv launch goes through the spied entry points; the timed step batches those reductions into one launch per chain,
+    # i.e. the conv-phase time below is (slightly) conservative
+    prev_defer = os.environ.get('RV_DEFER_WGRAD')
+    os.environ['RV_DEFER_WGRAD'] = '0'
     try:
         step_fn()
         torch.cuda.synchronize()
     finally:
         ops.call = real_call
+        if prev_defer is None:
+            del os.environ['RV_DEFER_WGRAD']
+        else:
+            os.environ['RV_DEFER_WGRAD'] = prev_defer
     # group identical launches by their shape signature (pointers and stream excluded)
     groups = {}
     for name, a in records:
