@@ -20,7 +20,7 @@ import torch.nn.init as init
 from . import ops
 from .constants import N_BINS
 from .frontend import MelSpectrogram, Normalization
-from .ops import (ARENA, BnLink, ConvFn, UpCatFn, BnActFn, LinearFn, OnsetHeadsFn, LocalAttnFn, VatPerturbFn, SLOPE, bce_mean,
+from .ops import (ARENA, BnLink, GradShare, ConvFn, UpCatFn, BnActFn, LinearFn, OnsetHeadsFn, LocalAttnFn, VatPerturbFn, SLOPE, bce_mean,
                   mse_mean, abs_mean)
 
 batchNorm_momentum = 0.1
@@ -30,17 +30,17 @@ def _p(t, detach):
     return t.detach() if (detach and t is not None) else t
 
 
-def _conv(m, x, kind, detach, size=None):
-    return ConvFn.apply(x, _p(m.weight, detach), _p(m.bias, detach), kind, size)
+def _conv(m, x, kind, detach, size=None, share=None):
+    return ConvFn.apply(x, _p(m.weight, detach), _p(m.bias, detach), kind, size, None, None, share)
 
 
-def _conv_bn(conv, bn, x, kind, res, detach, bn_in=None, link=None):
+def _conv_bn(conv, bn, x, kind, res, detach, bn_in=None, link=None, share=None):
     """lrelu(bn(conv(x))) (+ res).  In training mode the conv leaves the batch statistics of its output in a
     zeroed fp64 slice (fused epilogue) and the BatchNorm skips its own statistics pass.  ``link`` (a fresh
     ops.BnLink) is handed to the ONE conv that consumes the result as ``bn_in``: that conv's input-gradient kernel
     then also produces this BatchNorm's backward reduction."""
     stats = ARENA.take(ops.bn_ws_doubles(bn.num_features), x.device) if bn.training else None
-    z = ConvFn.apply(x, _p(conv.weight, detach), _p(conv.bias, detach), kind, None, stats, bn_in)
+    z = ConvFn.apply(x, _p(conv.weight, detach), _p(conv.bias, detach), kind, None, stats, bn_in, share)
     return BnActFn.apply(z, _p(bn.weight, detach), _p(bn.bias, detach), bn.running_mean, bn.running_var,
                          bn.num_batches_tracked, res, bn.training, SLOPE, stats, link)
 
@@ -57,10 +57,12 @@ class block(nn.Module):
         self.skip = nn.Conv2d(inp, out, kernel_size=1, padding=0)
         self.ds = nn.Conv2d(out, out, kernel_size=ds_ksize, stride=ds_stride, padding=0)
 
-    def forward(self, x, detach=False):
+    def forward(self, x, detach=False, share=None):
+        """share: the GradShare of x (x feeds conv1 and skip here, and -- for the inner blocks -- a decoder skip conv)."""
+        share = share if share is not None else GradShare()
         l1 = BnLink()                                                          # a1 feeds conv2 only
-        a1 = _conv_bn(self.conv1, self.bn1, x, 'c3', None, detach, link=l1)
-        sk = _conv(self.skip, x, 'c1', detach)
+        a1 = _conv_bn(self.conv1, self.bn1, x, 'c3', None, detach, link=l1, share=share)
+        sk = _conv(self.skip, x, 'c1', detach, share=share)
         a2 = _conv_bn(self.conv2, self.bn2, a1, 'c3', sk, detach, bn_in=l1)     # lrelu(bn2(.)) + skip(x)
         xp = _conv(self.ds, a2, 'down', detach)
         return xp, (a2.shape[1], a2.shape[2])
@@ -81,12 +83,12 @@ class d_block(nn.Module):
             self.us = nn.ConvTranspose2d(inp, inp, kernel_size=ds_ksize, stride=ds_stride)
         self.isLast = isLast
 
-    def forward(self, x, size, skip_src=None, skip_conv=None, detach=False):
+    def forward(self, x, size, skip_src=None, skip_conv=None, detach=False, share=None):
         if self.isLast:
             x = _conv(self.us, x, 'up', detach, size)
         else:
             x = UpCatFn.apply(x, _p(self.us.weight, detach), _p(self.us.bias, detach), skip_src,
-                              _p(skip_conv.weight, detach), _p(skip_conv.bias, detach), size)
+                              _p(skip_conv.weight, detach), _p(skip_conv.bias, detach), size, share)
         l2 = BnLink()                                                          # the bn2d output feeds conv1d only
         x = _conv_bn(self.conv2d, self.bn2d, x, 't3', None, detach, link=l2)
         if self.isLast:
@@ -108,11 +110,12 @@ class Encoder(nn.Module):
     def forward(self, x, detach=False):
         """x: NHWC [B, T, bins, 1].  Returns (x4, sizes, skip sources); the skip convs conv1..3
         (model/UNet_onset.py:244-246) are evaluated by the decoder straight into its concat buffers."""
+        g1, g2, g3 = GradShare(), GradShare(), GradShare()      # x1..x3 feed the next block (conv1 + skip) and a decoder skip conv
         x1, s1 = self.block1(x, detach)
-        x2, s2 = self.block2(x1, detach)
-        x3, s3 = self.block3(x2, detach)
-        x4, s4 = self.block4(x3, detach)
-        return x4, [s1, s2, s3, s4], [(x3, self.conv1), (x2, self.conv2), (x1, self.conv3)]
+        x2, s2 = self.block2(x1, detach, g1)
+        x3, s3 = self.block3(x2, detach, g2)
+        x4, s4 = self.block4(x3, detach, g3)
+        return x4, [s1, s2, s3, s4], [(x3, self.conv1, g3), (x2, self.conv2, g2), (x1, self.conv3, g1)]
 
 
 class Decoder(nn.Module):
@@ -124,9 +127,9 @@ class Decoder(nn.Module):
         self.d_block4 = d_block(16, num_instruments, True, (3, 3), (1, 1), ds_ksize, ds_stride)
 
     def forward(self, x, s, c, detach=False):
-        x = self.d_block1(x, s[3], c[0][0], c[0][1], detach)
-        x = self.d_block2(x, s[2], c[1][0], c[1][1], detach)
-        x = self.d_block3(x, s[1], c[2][0], c[2][1], detach)
+        x = self.d_block1(x, s[3], c[0][0], c[0][1], detach, c[0][2])
+        x = self.d_block2(x, s[2], c[1][0], c[1][1], detach, c[1][2])
+        x = self.d_block3(x, s[1], c[2][0], c[2][1], detach, c[2][2])
         return self.d_block4(x, s[0], None, None, detach)
 
 

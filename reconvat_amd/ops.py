@@ -307,14 +307,14 @@ _algo_cache = {}
 AUTOTUNE = True
 
 
-def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias, stats=None, bnbwd=None):
+def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias, stats=None, bnbwd=None, accumulate=False):
     """rv_conv_fwd with a per-shape choice between the LDS-free and the LDS/DMA-pipelined 3x3 kernel.  The first
     eager call of a shape times both (HIP events on the launch stream) and caches the winner; under hipGraph
     capture an untuned shape uses the library default.  ``stats`` (fp64 [2*cout], zeroed): the conv also leaves the
     BatchNorm batch statistics of its output there (fused epilogue of the persistent kernel, else a statistics pass
     -- the tuner times whichever the candidate implies).  ``bnbwd`` = (z, coef, slope): the call is an input gradient
     and ``stats`` receives the backward reduction of the BatchNorm whose output gradient is being produced."""
-    args = (mode, ptr(x), ild, bb, h, wd, cin, ptr(out), old, ho, wo, cout, ptr(wpack), ptr(bias), 0)
+    args = (mode, ptr(x), ild, bb, h, wd, cin, ptr(out), old, ho, wo, cout, ptr(wpack), ptr(bias), 1 if accumulate else 0)
     if bnbwd is not None:
         bz, bcoef, bslope = bnbwd
         tail = (ptr(bz), _geom(bz)[4], ptr(bcoef), float(bslope))
@@ -335,6 +335,10 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
                 lib = _lib.load()
                 ntile_n = (4 * cout if mode == 3 else cout + 15) // 16
                 scratch = ptr(torch.zeros_like(stats)) if stats is not None else None
+                targs = args
+                if accumulate:          # the timing runs must not touch the buffer that is being accumulated into
+                    tmp_out = torch.empty(bb * ho * wo * old, device=out.device, dtype=torch.float32)
+                    targs = args[:7] + (ptr(tmp_out),) + args[8:14] + (0,)
                 cands = [1, 2] if mode == 0 else [0]
                 for nt in (1, 2, 3, 4):
                     if ntile_n % nt:
@@ -345,14 +349,14 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
                         cands += [0x300 | nt << 4 | mt for mt in (1, 2, 4)]
                         cands += [0x400 | nt << 4 | mt for mt in (1, 2, 4)]
                 for cand in cands:
-                    if lib.rv_conv_fwd(*args, cand, scratch, *tail, st.cuda_stream) != 0:
+                    if lib.rv_conv_fwd(*targs, cand, scratch, *tail, st.cuda_stream) != 0:
                         continue                                   # tile does not fit this shape
                     t = None
                     for _rep in range(2):                          # best of two bursts of three: less timing noise
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record(st)
                         for _ in range(3):
-                            lib.rv_conv_fwd(*args, cand, scratch, *tail, st.cuda_stream)
+                            lib.rv_conv_fwd(*targs, cand, scratch, *tail, st.cuda_stream)
                         e1.record(st)
                         e1.synchronize()
                         dt = e0.elapsed_time(e1)
@@ -371,17 +375,36 @@ def conv_forward_into(kind, x, w, b, out, stats=None):
     _conv_call(_FWD_MODE[kind], x, ild, bb, h, wd, cin, out, old, ho, wo, cout, _pack(kind, w, 'fwd'), b, stats)
 
 
-def conv_dgrad_into(kind, dy, w, dx, bn_link=None):
-    """dx (NHWC view) = input gradient of the conv given dy (NHWC view).  bn_link: the BnLink of the BatchNorm that
+def conv_dgrad_into(kind, dy, w, dx, bn_link=None, accumulate=False):
+    """dx (NHWC view) (+)= input gradient of the conv given dy (NHWC view).  bn_link: the BnLink of the BatchNorm that
     produced the conv's input -- its backward reduction is then computed in this kernel's epilogue."""
+    assert not (accumulate and bn_link is not None)
     bb, h, wd, c, ild = _geom(dy)
     _, ho, wo, co, old = _geom(dx)
     stats = bnbwd = None
     if bn_link is not None and bn_link.usable(dx):
         stats, bnbwd = bn_link.ws, (bn_link.z, bn_link.coef, bn_link.slope)
-    _conv_call(_DGRAD_MODE[kind], dy, ild, bb, h, wd, c, dx, old, ho, wo, co, _pack(kind, w, 'dgrad'), None, stats, bnbwd)
+    _conv_call(_DGRAD_MODE[kind], dy, ild, bb, h, wd, c, dx, old, ho, wo, co, _pack(kind, w, 'dgrad'), None, stats, bnbwd, accumulate)
     if stats is not None:
         bn_link.ready = True
+
+
+class GradShare:
+    """One activation consumed by several convs (a block's conv1 + skip, the decoder's skip conv): the first
+    input-gradient kernel to run writes the shared buffer and hands it to autograd, the others ACCUMULATE into it
+    (rv_conv_fwd accumulate=1) and hand autograd nothing -- no add kernel, no extra pass over the tensor.  Create one per
+    forward call and pass it to every consumer; all consumers must run on the same stream."""
+
+    def __init__(self):
+        self.buf = None
+
+    def dgrad(self, kind, dy, w, shape):
+        if self.buf is None:
+            self.buf = torch.empty(shape, device=dy.device, dtype=torch.float32)
+            conv_dgrad_into(kind, dy, w, self.buf)
+            return self.buf
+        conv_dgrad_into(kind, dy, w, self.buf, accumulate=True)
+        return None
 
 
 class BnLink:
@@ -528,7 +551,7 @@ class ConvFn(Function):
     """y = conv(x) for any of the five conv kinds (new contiguous NHWC tensor)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, kind, size, stats=None, bn_in=None):
+    def forward(ctx, x, w, b, kind, size, stats=None, bn_in=None, share=None):
         bb, h, wd, cin, _ = _geom(x)
         _, cout = _channels(kind, w)
         ho, wo = _out_hw(kind, h, wd, size)
@@ -537,6 +560,7 @@ class ConvFn(Function):
         ctx.kind = kind
         ctx.xshape = tuple(x.shape)
         ctx.bn_in = bn_in            # BnLink of the BatchNorm whose output is x (single consumer), or None
+        ctx.share = share            # GradShare of x (several conv consumers), or None
         ctx.save_for_backward(x if ctx.needs_input_grad[1] else None, w)
         ctx.params = (w, b)          # parameter objects (for direct gradient accumulation)
         return y
@@ -547,8 +571,11 @@ class ConvFn(Function):
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(ctx.xshape, device=dy.device, dtype=torch.float32)
-            conv_dgrad_into(ctx.kind, dy, w, dx, ctx.bn_in)
+            if ctx.share is not None and ctx.bn_in is None:
+                dx = ctx.share.dgrad(ctx.kind, dy, w, ctx.xshape)
+            else:
+                dx = torch.empty(ctx.xshape, device=dy.device, dtype=torch.float32)
+                conv_dgrad_into(ctx.kind, dy, w, dx, ctx.bn_in)
         if ctx.needs_input_grad[1]:
             pw, pb = ctx.params
             gw, gb = _grad_buf(pw), _grad_buf(pb)
@@ -556,7 +583,7 @@ class ConvFn(Function):
                 conv_wgrad(ctx.kind, x, dy, w, ctx.needs_input_grad[2], gw, gb)
             else:
                 dw, db = conv_wgrad(ctx.kind, x, dy, w, ctx.needs_input_grad[2])
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class UpCatFn(Function):
@@ -565,7 +592,7 @@ class UpCatFn(Function):
     model/UNet_onset.py:219-220, with the encoder's extra skip conv, :244-246, computed here)."""
 
     @staticmethod
-    def forward(ctx, x, w_up, b_up, s, w_skip, b_skip, size):
+    def forward(ctx, x, w_up, b_up, s, w_skip, b_skip, size, share=None):
         bb, h, wd, cin, _ = _geom(x)
         cu = w_up.shape[1]
         cs = w_skip.shape[0]
@@ -574,6 +601,7 @@ class UpCatFn(Function):
         conv_forward_into('up', x, w_up, b_up, cat[..., :cu])
         conv_forward_into('c3', s, w_skip, b_skip, cat[..., cu:])
         ctx.cu = cu
+        ctx.share = share            # GradShare of s (it also feeds the next encoder block)
         ctx.shapes = (tuple(x.shape), tuple(s.shape))
         need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[4]
         ctx.save_for_backward(x if need_w else None, s if need_w else None, w_up, w_skip)
@@ -591,8 +619,11 @@ class UpCatFn(Function):
             dx = torch.empty(ctx.shapes[0], device=dcat.device, dtype=torch.float32)
             conv_dgrad_into('up', d_up, w_up, dx)
         if ctx.needs_input_grad[3]:
-            ds = torch.empty(ctx.shapes[1], device=dcat.device, dtype=torch.float32)
-            conv_dgrad_into('c3', d_sk, w_skip, ds)
+            if ctx.share is not None:
+                ds = ctx.share.dgrad('c3', d_sk, w_skip, ctx.shapes[1])
+            else:
+                ds = torch.empty(ctx.shapes[1], device=dcat.device, dtype=torch.float32)
+                conv_dgrad_into('c3', d_sk, w_skip, ds)
         pwu, pbu, pws, pbs = ctx.params
         if ctx.needs_input_grad[1]:
             gw, gb = _grad_buf(pwu), _grad_buf(pbu)
@@ -606,7 +637,7 @@ class UpCatFn(Function):
                 conv_wgrad('c3', s, d_sk, w_skip, True, gw, gb)
             else:
                 dws, dbs = conv_wgrad('c3', s, d_sk, w_skip, True)
-        return dx, dwu, dbu, ds, dws, dbs, None
+        return dx, dwu, dbu, ds, dws, dbs, None, None
 
 
 # --------------------------------------------------------------------------------------------
