@@ -818,6 +818,7 @@ class OnsetHeadsFn(Function):
         gemm(y2[..., 1], wf.t(), cat[:, 88:], bf, act=0)
         ctx.params = (wo, bo, wf, bf)
         ctx.save_for_backward(y, wo, wf, onset)
+        ctx.set_materialize_grads(False)          # donset is None (not a zero tensor) when the onset output is unused
         return cat, onset
 
     @staticmethod
@@ -895,6 +896,7 @@ class LocalAttnFn(Function):
         ctx.params = (wq, wk, wv, rel)
         ctx.save_for_backward(x2, wq, wk, wv, rel, qkv, att)
         ctx.mark_non_differentiable(att)
+        ctx.set_materialize_grads(False)          # no zero-filled gradient tensor for the attention map
         return out, att
 
     @staticmethod

@@ -43,7 +43,7 @@ def weighted_loss(losses, alpha):
         w = _WEIGHTS.get(ck)
         if w is None:
             w = _WEIGHTS[ck] = torch.tensor(ws, dtype=torch.float32, device=dev[0][1].device)
-        loss = loss + torch.dot(torch.stack([v.reshape(()) for _, v in dev]), w)
+        loss = loss + (torch.stack([v.reshape(()) for _, v in dev]) * w).sum()
     return loss
 
 
