@@ -1742,7 +1742,11 @@ static int conv_wgrad_impl(int mode, const float* U, int u_ld, int Hu, int Wu, i
     }
 reduce:
     RV_LAUNCH_CHECK("rv_conv_wgrad");
+#ifdef RV_ABLATION
     static const int skip_reduce = getenv("RV_ABL_SKIP_WREDUCE") ? atoi(getenv("RV_ABL_SKIP_WREDUCE")) : 0;   // timing ablation (wrong results)
+#else
+    const int skip_reduce = 0;
+#endif
     if (!skip_reduce) {
         WreduceArgs r;
         r.part = a.part; r.pstride = a.pstride; r.nparts = a.nparts; r.taps = taps; r.Ca = Ca; r.Cb = Cb;
