@@ -31,6 +31,7 @@ struct GemmArgs {
     int a_vec, b_vec;   // 16-byte loads along the contiguous dimension are legal
     int batch;          // independent problems over blockIdx.z / splitk: A += z*bsa, B += z*bsb, C += z*bsc
     long bsa, bsb, bsc;
+    float* a_rowsum;    // optional: a_rowsum[m] += sum_k A[m][k] (fp32 atomics; the bias gradient riding on a weight-gradient GEMM)
 };
 
 // One operand tile: `rows` (m or n) x GBK.  KFAST: memory is contiguous along k -> LDS layout [row][k];
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a_in) {
 
     TileIO<AK> ta;
     TileIO<BK_> tb;
+    float rowsum = 0.f;
     if (k_begin < k_end) {
         ta.load(a.A, a.sam, a.sak, m0, a.M, k_begin, k_end, a.a_vec, tid);
         tb.load(a.B, a.sbn, a.sbk, n0, a.N, k_begin, k_end, a.b_vec, tid);
@@ -118,6 +120,10 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a_in) {
         if (k0 + GBK < k_end) {             // prefetch the next tile while this one is multiplied
             ta.load(a.A, a.sam, a.sak, m0, a.M, k0 + GBK, k_end, a.a_vec, tid);
             tb.load(a.B, a.sbn, a.sbk, n0, a.N, k0 + GBK, k_end, a.b_vec, tid);
+        }
+        if (a.a_rowsum && blockIdx.x == 0 && tid < GBM) {       // the first column of workgroups also sums the rows of A
+#pragma unroll
+            for (int kk = 0; kk < GBK; ++kk) rowsum += TileIO<AK>::at(As, tid, kk);      // (out-of-range elements are staged as 0)
         }
 #pragma unroll
         for (int ks = 0; ks < GBK; ks += 4) {
@@ -135,6 +141,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a_in) {
         }
     }
 
+    if (a.a_rowsum && blockIdx.x == 0 && tid < GBM && m0 + tid < a.M) atomicAdd(&a.a_rowsum[m0 + tid], rowsum);
     const bool vec_ok = a.scn == 1 && (a.scm & 3) == 0 && ((((uintptr_t)a.C) & 15) == 0) && a.splitk == 1 && !a.C2;
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -184,18 +191,21 @@ extern "C" {
 // with accumulate == 0 C is zeroed first, with accumulate != 0 the atomics add straight into C's contents (gradient
 // accumulation).  C2 (nullable) receives a second copy with its own strides.
 // batch > 1: `batch` independent problems of the same shape, problem z at A + z*bsa, B + z*bsb, C + z*bsc (C2 must be null).
+// a_rowsum (nullable, batch == 1): a_rowsum[m] += sum_k A[m][k] by fp32 atomics -- the bias gradient of a linear layer for free
+// on its weight-gradient GEMM (A = dY^T).
 int rv_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm, long scn, float* C2,
             long sc2m, long sc2n, const float* bias, int M, int N, int K, int act, int accumulate, int splitk, int batch,
-            long bsa, long bsb, long bsc, void* stream) {
+            long bsa, long bsb, long bsc, float* a_rowsum, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     RV_CHECK_ARG(M > 0 && N > 0 && K > 0, "rv_gemm: empty problem");
+    RV_CHECK_ARG(!a_rowsum || batch == 1, "rv_gemm: a_rowsum excludes batch");
     RV_CHECK_ARG(splitk >= 1, "rv_gemm: splitk must be >= 1");
     RV_CHECK_ARG(batch >= 1 && (batch == 1 || !C2) && (long)batch * splitk < 65536, "rv_gemm: bad batch %d", batch);
     if (splitk > 1) RV_CHECK_ARG(act == 0 && !C2, "rv_gemm: splitk excludes act/C2");
     GemmArgs a;
     a.A = A; a.sam = sam; a.sak = sak; a.B = B; a.sbk = sbk; a.sbn = sbn; a.C = C; a.scm = scm; a.scn = scn;
     a.C2 = C2; a.sc2m = sc2m; a.sc2n = sc2n; a.bias = bias; a.M = M; a.N = N; a.K = K; a.act = act;
-    a.accumulate = accumulate; a.splitk = splitk; a.batch = batch; a.bsa = bsa; a.bsb = bsb; a.bsc = bsc;
+    a.accumulate = accumulate; a.splitk = splitk; a.batch = batch; a.bsa = bsa; a.bsb = bsb; a.bsc = bsc; a.a_rowsum = a_rowsum;
     const bool a_kfast = (sak <= sam), b_kfast = (sbk <= sbn);
     // 16-byte loads need a unit stride along the fast dimension, a 16-byte multiple along the slow one and an
     // aligned base; K-split offsets are multiples of GBK so they preserve alignment

@@ -714,7 +714,7 @@ def _mat(t):
     return ptr(t), t.shape[0], t.shape[1], t.stride(0), t.stride(1)
 
 
-def gemm(a, b_kn, c, bias=None, act=0, accumulate=False, splitk=1, c2=None, batch=1, bstrides=(0, 0, 0)):
+def gemm(a, b_kn, c, bias=None, act=0, accumulate=False, splitk=1, c2=None, batch=1, bstrides=(0, 0, 0), a_rowsum=None):
     """c[m,n] (+)= act(sum_k a[m,k] * b_kn[k,n] + bias[n]) on arbitrary 2-D views.  batch > 1: `batch` problems of this
     shape, problem z offset by z * bstrides (elements) from a / b_kn / c."""
     need_gpu(a, b_kn, c)
@@ -727,7 +727,7 @@ def gemm(a, b_kn, c, bias=None, act=0, accumulate=False, splitk=1, c2=None, batc
     else:
         pc2, s2m, s2n = None, 0, 0
     call('rv_gemm', pa, sam, sak, pb, sbk, sbn, pc, scm, scn, pc2, s2m, s2n, ptr(bias), m, n, k, act,
-         1 if accumulate else 0, splitk, batch, bstrides[0], bstrides[1], bstrides[2], stream())
+         1 if accumulate else 0, splitk, batch, bstrides[0], bstrides[1], bstrides[2], ptr(a_rowsum), stream())
 
 
 def colsum(x2d, out=None, accumulate=False):
@@ -738,10 +738,17 @@ def colsum(x2d, out=None, accumulate=False):
     return out
 
 
-def _param_wgrad(a_t, b, param, splitk):
+def _param_wgrad(a_t, b, param, splitk, bias_param=None):
     """d(param) = a_t @ b.  Under direct_param_grads() the product is accumulated straight into param.grad (split-K
-    atomics add onto it: no zero fill, no temporary, no autograd add) and None is returned."""
+    atomics add onto it: no zero fill, no temporary, no autograd add) and None is returned.  bias_param: the layer's
+    bias -- its gradient (the row sums of a_t = dY^T) then rides on the same GEMM; returns (None, True) in that case."""
     g = _grad_buf(param)
+    if bias_param is not None:
+        gb = _grad_buf(bias_param)
+        if g is not None and gb is not None:
+            gemm(a_t, b, g.view(a_t.shape[0], b.shape[1]), accumulate=True, splitk=splitk, a_rowsum=gb)
+            return None, True
+        return _param_wgrad(a_t, b, param, splitk), False
     if g is not None:
         gemm(a_t, b, g.view(a_t.shape[0], b.shape[1]), accumulate=True, splitk=splitk)
         return None
@@ -794,9 +801,13 @@ class LinearFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((m, k), device=dy.device, dtype=torch.float32)
             gemm(dz, w, dx)
+        bias_done = False
         if ctx.needs_input_grad[1]:
-            dw = _param_wgrad(dz.t(), x, ctx.params[0], _splitk_for(n, k, m))
-        if ctx.needs_input_grad[2]:
+            if ctx.needs_input_grad[2]:
+                dw, bias_done = _param_wgrad(dz.t(), x, ctx.params[0], _splitk_for(n, k, m), ctx.params[1])
+            else:
+                dw = _param_wgrad(dz.t(), x, ctx.params[0], _splitk_for(n, k, m))
+        if ctx.needs_input_grad[2] and not bias_done:
             db = _param_bgrad(dz, ctx.params[1])
         return dx, dw, db, None
 
@@ -840,11 +851,13 @@ class OnsetHeadsFn(Function):
             gemm(dzf, wf, d2[..., 1])
         pwo, pbo, pwf, pbf = ctx.params
         if ctx.needs_input_grad[1]:
-            dwo = _param_wgrad(dzo.t(), y2[..., 0], pwo, _splitk_for(88, nb, m))
-            dbo = _param_bgrad(dzo, pbo)
+            dwo, done = _param_wgrad(dzo.t(), y2[..., 0], pwo, _splitk_for(88, nb, m), pbo)
+            if not done:
+                dbo = _param_bgrad(dzo, pbo)
         if ctx.needs_input_grad[3]:
-            dwf = _param_wgrad(dzf.t(), y2[..., 1], pwf, _splitk_for(88, nb, m))
-            dbf = _param_bgrad(dzf, pbf)
+            dwf, done = _param_wgrad(dzf.t(), y2[..., 1], pwf, _splitk_for(88, nb, m), pbf)
+            if not done:
+                dbf = _param_bgrad(dzf, pbf)
         return dy, dwo, dbo, dwf, dbf
 
 
@@ -1190,13 +1203,20 @@ class BiLstmFn(Function):
         for d, base in ((0, 1), (1, 5)):
             dz = dxg[:, d, :]
             p_ih, p_hh, p_bi, p_bh = ctx.params[base - 1:base + 3]
+            ih_bias = hh_bias = False
             if ctx.needs_input_grad[base]:
-                grads[base] = _param_wgrad(dz.t(), x2, p_ih, _splitk_for(4 * h, i, bb * t))
+                if ctx.needs_input_grad[base + 2]:
+                    grads[base], ih_bias = _param_wgrad(dz.t(), x2, p_ih, _splitk_for(4 * h, i, bb * t), p_bi)
+                else:
+                    grads[base] = _param_wgrad(dz.t(), x2, p_ih, _splitk_for(4 * h, i, bb * t))
             if ctx.needs_input_grad[base + 1]:
-                grads[base + 1] = _param_wgrad(dz.t(), hprev[:, d, :], p_hh, _splitk_for(4 * h, h, bb * t))
-            if ctx.needs_input_grad[base + 2]:
+                if ctx.needs_input_grad[base + 3]:
+                    grads[base + 1], hh_bias = _param_wgrad(dz.t(), hprev[:, d, :], p_hh, _splitk_for(4 * h, h, bb * t), p_bh)
+                else:
+                    grads[base + 1] = _param_wgrad(dz.t(), hprev[:, d, :], p_hh, _splitk_for(4 * h, h, bb * t))
+            if ctx.needs_input_grad[base + 2] and not ih_bias:
                 grads[base + 2] = _param_bgrad(dz, p_bi)
-            if ctx.needs_input_grad[base + 3]:
+            if ctx.needs_input_grad[base + 3] and not hh_bias:
                 grads[base + 3] = _param_bgrad(dz, p_bh)
         return tuple(grads)
 
