@@ -283,10 +283,15 @@ int rv_sigmoid_bwd(const float* g1, int ld1, const float* g2, int ld2, const flo
     return RV_OK;
 }
 
+__global__ void zero_floats_k(float* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
 // out[n] = sum_m x[m*ld + n]   (out is overwritten unless accumulate)
 int rv_colsum(const float* x, int ld, long M, int N, float* out, int accumulate, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * N, st);
+    if (!accumulate) hipLaunchKernelGGL(zero_floats_k, dim3(cdiv(N, 256)), dim3(256), 0, st, out, N);   // (a kernel: memset nodes proved unreliable across hipGraph replays)
     if ((N & 3) == 0 && N <= 256 && (ld & 3) == 0 && ((((uintptr_t)x) & 15) == 0) && M >= 1024) {
         // rows per thread: ~512 workgroups -- enough to fill the chip on the 5 120-row linear layers (32 rows per thread
         // left 15 workgroups there), few enough that the per-column atomics (serialised, ~23 ns each) stay a short tail

@@ -302,6 +302,13 @@ __global__ __launch_bounds__(256 * KS) void lstm_bwd_k(LstmArgs a) {
     }
 }
 
+// the step counters are zeroed by a kernel, not hipMemsetAsync: a memset node captured into a hipGraph was observed NOT to
+// be re-applied (or not in order) on later replays -- the counters and the error word then held stale data
+__global__ void lstm_zero_flags_k(int* flags, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = 0;
+}
+
 extern "C" long rv_lstm_flag_bytes(int H) { return (long)(2 * (H / 16) + 1) * sizeof(int); }
 
 static int lstm_check(int B, int T, int H) {
@@ -318,7 +325,7 @@ extern "C" int rv_lstm_fwd(const float* xg, const float* whh_fwd, const float* w
     RV_CHECK_ARG((gates == nullptr) == (cs == nullptr), "rv_lstm_fwd: gates and cs are saved together");
     LstmArgs a = {};
     a.xg = xg; a.whh[0] = whh_fwd; a.whh[1] = whh_rev; a.out = out; a.gates = gates; a.cs = cs; a.flags = flags; a.B = B; a.T = T;
-    if (hipMemsetAsync(flags, 0, rv_lstm_flag_bytes(H), st) != hipSuccess) { rv_set_error("rv_lstm_fwd: memset failed"); return RV_ELAUNCH; }
+    hipLaunchKernelGGL(lstm_zero_flags_k, dim3(1), dim3(256), 0, st, flags, (int)(rv_lstm_flag_bytes(H) / sizeof(int)));
 #if RV_LSTM_XCD
     if (hipMemsetAsync(out, 0xFF, (size_t)B * T * 2 * H * sizeof(float), st) != hipSuccess) { rv_set_error("rv_lstm_fwd: memset failed"); return RV_ELAUNCH; }
     dim3 grid(8 * (H / 16));      // workgroup b -> XCD b % 8; only b % 8 < 2 (one XCD per direction) do work
@@ -338,7 +345,7 @@ extern "C" int rv_lstm_bwd(const float* dout, const float* whh_fwd, const float*
     LstmArgs a = {};
     a.dout = dout; a.whh[0] = whh_fwd; a.whh[1] = whh_rev; a.gates = const_cast<float*>(gates); a.cs = const_cast<float*>(cs);
     a.dxg = dxg; a.flags = flags; a.B = B; a.T = T;
-    if (hipMemsetAsync(flags, 0, rv_lstm_flag_bytes(H), st) != hipSuccess) { rv_set_error("rv_lstm_bwd: memset failed"); return RV_ELAUNCH; }
+    hipLaunchKernelGGL(lstm_zero_flags_k, dim3(1), dim3(256), 0, st, flags, (int)(rv_lstm_flag_bytes(H) / sizeof(int)));
 #if RV_LSTM_XCD
     if (hipMemsetAsync(dxg, 0xFF, (size_t)B * T * 8 * H * sizeof(float), st) != hipSuccess) { rv_set_error("rv_lstm_bwd: memset failed"); return RV_ELAUNCH; }
     dim3 grid(8 * (H / 16));

@@ -358,3 +358,33 @@ def test_onset_stack_golden(dev, training):
     close_digest(pr['onset'], g[key + '_onset'], 1e-3, 256)
     with pytest.raises(NotImplementedError):
         m.run_on_batch(bl, None, True)
+
+
+@pytest.mark.gpu
+def test_graph_replays_track_eager_steps(dev):
+    """Four optimiser steps on changing batches: hipGraph replays give the eager loss trajectory and never raise the
+    recurrence time-out flag.  (Regression: the LSTM step counters used to be cleared by a hipMemsetAsync node, which is
+    not reliably re-applied on later replays of a captured graph -- the first replay was fine, later ones saw stale words.)"""
+    import reconvat_amd as ra
+    from oracle import onset_frames as oo
+    from reconvat_amd import ops
+    from reconvat_amd.onset_frames import Frame_stack_VAT
+    batches = [{k: v.to(dev) for k, v in _batch(2, 64, f'B{i}').items()} for i in range(4)]
+    traj = []
+    for graph in (False, True):
+        m = Frame_stack_VAT(229, 88, model_complexity=48, log=True, mode='imagewise', spec='Mel')
+        m.load_state_dict(oo.fixture_params(kind='frame'))
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        m.to(dev)
+        opt = ra.FlatAdam(m.parameters(), lr=1e-4)
+        step = ra.TrainStep(m, opt, batches[0], None, VAT=False, graph=graph)
+        losses = []
+        for b in batches:
+            step.load(b, None)
+            losses.append(float(step()))
+            ops.lstm_check(dev)
+        traj.append(losses)
+    for a, b in zip(*traj):
+        assert abs(a - b) <= 2e-3 * abs(a), traj
