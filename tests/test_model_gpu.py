@@ -419,3 +419,26 @@ def test_train_step_two_streams_equals_single_stream(dev, graph):
     assert rel_err(g1, g0) < 1e-4            # fp32 gradients of this network carry ~1e-5 (of the max) summation-order noise
     for k in s0:
         assert rel_err(s1[k], s0[k]) < 1e-6, k
+
+
+def test_graph_replays_track_eager_steps(dev):
+    """Three optimiser steps on changing batches without VAT (deterministic): hipGraph replays reproduce the eager loss
+    trajectory -- gradient zeroing, BatchNorm workspaces and weight repacking are all re-applied on every replay."""
+    import reconvat_amd as ra
+    from oracle import fixture as fx
+    batches = []
+    for i in range(3):
+        onset, frame = fx.fixture_labels(2, 64, f'R{i}')
+        batches.append({'audio': fx.fixture_audio(2, 64 * 512, f'R{i}').to(dev), 'onset': onset.to(dev), 'frame': frame.to(dev)})
+    traj = []
+    for graph in (False, True):
+        m = build('onset', True, dev)
+        opt = ra.FlatAdam(m.parameters(), lr=1e-4)
+        step = ra.TrainStep(m, opt, batches[0], None, VAT=False, graph=graph)
+        losses = []
+        for b in batches:
+            step.load(b, None)
+            losses.append(float(step()))
+        traj.append(losses)
+    for a, b in zip(*traj):
+        assert abs(a - b) <= 2e-3 * abs(a), traj
