@@ -140,6 +140,8 @@ def replay_bn_updates(pendings, device):
     table = host[:len(words)].to(device, non_blocking=True)
     call('rv_bn_running_update_table', ptr(table), len(order), BN_MOMENTUM, stream())
     table.record_stream(torch.cuda.current_stream(device))
+    if capturing:
+        _REPLAY_KEEP.append(table)             # keep the device copy's memory out of the graph pool's reuse
 
 
 
@@ -517,6 +519,8 @@ class _WgradTable:
             table = src.to(self.device, non_blocking=True)
             call('rv_wgrad_reduce_table', ptr(table), self.n, total, self.stream.cuda_stream)
             table.record_stream(self.stream)
+            if self.pinned:
+                _WGRAD_KEEP.append(table)      # captured: keep the device copy's memory out of the graph pool's reuse
         self.n, self.keep = 0, []
 
 
