@@ -442,3 +442,38 @@ def test_graph_replays_track_eager_steps(dev):
         traj.append(losses)
     for a, b in zip(*traj):
         assert abs(a - b) <= 2e-3 * abs(a), traj
+
+
+def test_two_stream_graph_replays_keep_running_statistics(dev):
+    """Three VAT steps (fixed injected noise, tiny learning rate): the two-stream hipGraph replays -- deferred BatchNorm
+    updates replayed by the captured table launch, weight-gradient reductions by the captured reduction table -- leave the
+    running statistics and the losses of the eager two-stream steps after EVERY replay, not only the first."""
+    import reconvat_amd as ra
+    from oracle import fixture as fx
+    bl, bul = _batches(dev)
+    res = []
+    for graph in (False, True):
+        m = build('onset', True, dev)
+        opt = ra.FlatAdam(m.parameters(), lr=1e-7)
+        d = [fx.fixture_noise((2, 1, 64, 229), 'd0_ul').to(dev), fx.fixture_noise((2, 1, 64, 229), 'd0_l').to(dev)]
+        state = {'i': 0}
+
+        def noise(t, d=d, state=state):
+            state['i'] += 1
+            return d[state['i'] % 2].clone()
+        m.vat_loss.noise = noise
+        step = ra.TrainStep(m, opt, bl, bul, graph=graph, dual_stream=True)
+        per_step = []
+        for _ in range(3 if graph else 5):       # capture = 2 warm-up steps + replays; eager runs the same number of steps
+            step()
+            torch.cuda.synchronize()
+            per_step.append(({k: float(v) for k, v in step.losses.items()},
+                             {k: v.clone() for k, v in m.state_dict().items() if 'running_mean' in k}))
+        res.append(per_step)
+    eager, graph = res[0][2:], res[1]            # steps 3..5 of the eager run line up with replays 1..3
+    for (le, se), (lg, sg) in zip(eager, graph):
+        for k in le:
+            if 'LDS' not in k and 'r_norm' not in k:
+                assert abs(le[k] - lg[k]) <= 2e-3 * max(abs(le[k]), 1e-6), (k, le[k], lg[k])
+        for k in se:
+            assert rel_err(sg[k], se[k]) < 1e-2, k      # the adversarial passes' batch means move with the (ill-conditioned) r_adv
