@@ -476,4 +476,4 @@ def test_two_stream_graph_replays_keep_running_statistics(dev):
             if 'LDS' not in k and 'r_norm' not in k:
                 assert abs(le[k] - lg[k]) <= 2e-3 * max(abs(le[k]), 1e-6), (k, le[k], lg[k])
         for k in se:
-            assert rel_err(sg[k], se[k]) < 1e-2, k      # the adversarial passes' batch means move with the (ill-conditioned) r_adv
+            assert rel_err(sg[k], se[k]) < 5e-2, k      # the adversarial passes (eps = 2 along an ill-conditioned direction) move the deep layers' batch means by a percent or two; stale or garbage tables would be O(1) off
