@@ -130,9 +130,10 @@ int rv_vat_perturb_bwd(const float* g, const float* x, const float* d, long rows
                        float* gd, void* stream);
 
 /* ---- losses (F.binary_cross_entropy / F.mse_loss / .abs().mean(), model/UNet_onset.py:136-137,
- * 157-158,471-483); kind 0 BCE, 1 MSE, 2 mean|p|, 3 sqrt(sum p^2).  workspace: rv_reduce_workspace_bytes(n). */
+ * 157-158,471-483); kind 0 BCE, 1 MSE, 2 mean|p|, 3 sqrt(sum p^2).  workspace: rv_reduce_workspace_bytes(n).  ticket (nullable): a
+ * zeroed device word (left zero): the last workgroup folds the partial sums itself -- one launch instead of two. */
 long rv_reduce_workspace_bytes(long n);
-int rv_reduce_mean(int kind, const float* p, const float* t, long n, float* out, void* workspace, void* stream);
+int rv_reduce_mean(int kind, const float* p, const float* t, long n, float* out, void* workspace, unsigned* ticket, void* stream);
 int rv_loss_bwd(int kind, const float* p, const float* t, long n, const float* gout, float* gp, void* stream);
 
 /* ---- optimiser (torch.optim.Adam + StepLR + clip_grad_norm_, train_UNet_Onset_VAT.py:113,124;

@@ -48,7 +48,7 @@ SIGNATURES = {
     'rv_vat_perturb_fwd': (I, [P, P, L, I, F, F, P, P, P, P, P]),
     'rv_vat_perturb_bwd': (I, [P, P, P, L, I, F, F, P, P]),
     'rv_reduce_workspace_bytes': (L, [L]),
-    'rv_reduce_mean': (I, [I, P, P, L, P, P, P]),
+    'rv_reduce_mean': (I, [I, P, P, L, P, P, P, P]),
     'rv_loss_bwd': (I, [I, P, P, L, P, P, P]),
     'rv_adam_step': (I, [P, P, P, P, L, P, F, L, F, F, F, F, F, P]),
     'rv_counter_add': (I, [P, L, P]),

@@ -83,9 +83,14 @@ __device__ __forceinline__ float red_term(float p, float t) {
     }
 }
 
+// ticket (nullable): a zeroed device word.  With it the LAST workgroup to finish also does the final fold (fixed order, so
+// the result does not depend on which workgroup that is) and re-zeroes the ticket: one launch per loss instead of two.
 template <int KIND>
-__global__ __launch_bounds__(256) void reduce_partial_k(const float* p, const float* t, long n, float* part) {
+__global__ __launch_bounds__(256) void reduce_partial_k(const float* p, const float* t, long n, float* part, unsigned* ticket,
+                                                        double denom, float* out, int sqrt_out) {
     __shared__ float sh[4];
+    __shared__ double shd[4];
+    __shared__ bool last;
     float s = 0.f;
     const long base = (long)blockIdx.x * 2048;
 #pragma unroll
@@ -97,6 +102,24 @@ __global__ __launch_bounds__(256) void reduce_partial_k(const float* p, const fl
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (!ticket) return;
+    if (threadIdx.x == 0) {
+        __threadfence();                                      // the partial is visible before the ticket is taken
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    double d = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) d += (double)__hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    d = wave_sum_d(d);
+    if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double v = ((shd[0] + shd[1]) + (shd[2] + shd[3])) / denom;
+        *out = (float)(sqrt_out ? sqrt(v) : v);
+        *ticket = 0u;
+    }
 }
 
 __global__ __launch_bounds__(256) void reduce_final_k(const float* part, int nparts, double denom, float* out, int sqrt_out) {
@@ -247,20 +270,23 @@ int rv_vat_perturb_bwd(const float* g, const float* x, const float* d, long rows
 long rv_reduce_workspace_bytes(long n) { return ((n + 2047) / 2048) * 4; }
 
 // kind: 0 = BCE mean (p vs soft/hard target t), 1 = MSE mean, 2 = mean |p|, 3 = sqrt(sum p^2) (L2 norm)
-int rv_reduce_mean(int kind, const float* p, const float* t, long n, float* out, void* workspace, void* stream) {
+// ticket (nullable): a ZEROED device word (left zero again): single-launch form, see reduce_partial_k
+int rv_reduce_mean(int kind, const float* p, const float* t, long n, float* out, void* workspace, unsigned* ticket, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int nparts = cdiv(n, 2048);
     float* part = (float*)workspace;
+    const double denom = kind == RED_SUMSQ ? 1.0 : (double)n;
+    const int sq = kind == RED_SUMSQ ? 1 : 0;
     switch (kind) {
-        case RED_BCE: hipLaunchKernelGGL(reduce_partial_k<RED_BCE>, dim3(nparts), dim3(256), 0, st, p, t, n, part); break;
-        case RED_MSE: hipLaunchKernelGGL(reduce_partial_k<RED_MSE>, dim3(nparts), dim3(256), 0, st, p, t, n, part); break;
-        case RED_ABS: hipLaunchKernelGGL(reduce_partial_k<RED_ABS>, dim3(nparts), dim3(256), 0, st, p, t, n, part); break;
-        case RED_SUMSQ: hipLaunchKernelGGL(reduce_partial_k<RED_SUMSQ>, dim3(nparts), dim3(256), 0, st, p, t, n, part); break;
+        case RED_BCE: hipLaunchKernelGGL(reduce_partial_k<RED_BCE>, dim3(nparts), dim3(256), 0, st, p, t, n, part, ticket, denom, out, sq); break;
+        case RED_MSE: hipLaunchKernelGGL(reduce_partial_k<RED_MSE>, dim3(nparts), dim3(256), 0, st, p, t, n, part, ticket, denom, out, sq); break;
+        case RED_ABS: hipLaunchKernelGGL(reduce_partial_k<RED_ABS>, dim3(nparts), dim3(256), 0, st, p, t, n, part, ticket, denom, out, sq); break;
+        case RED_SUMSQ: hipLaunchKernelGGL(reduce_partial_k<RED_SUMSQ>, dim3(nparts), dim3(256), 0, st, p, t, n, part, ticket, denom, out, sq); break;
         default: rv_set_error("rv_reduce_mean: bad kind %d", kind); return RV_EINVAL;
     }
     RV_LAUNCH_CHECK("rv_reduce_mean(partial)");
-    hipLaunchKernelGGL(reduce_final_k, dim3(1), dim3(256), 0, st, part, nparts, kind == RED_SUMSQ ? 1.0 : (double)n, out,
-                       kind == RED_SUMSQ ? 1 : 0);
+    if (ticket) return RV_OK;
+    hipLaunchKernelGGL(reduce_final_k, dim3(1), dim3(256), 0, st, part, nparts, denom, out, sq);
     RV_LAUNCH_CHECK("rv_reduce_mean(final)");
     return RV_OK;
 }

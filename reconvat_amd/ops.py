@@ -978,7 +978,8 @@ def _reduce(kind, p, t):
     n = p.numel()
     out = torch.empty((), device=p.device, dtype=torch.float32)
     ws = torch.empty((n + 2047) // 2048, device=p.device, dtype=torch.float32)
-    call('rv_reduce_mean', kind, ptr(p), ptr(t), n, ptr(out), ptr(ws), stream())
+    ticket = ARENA.take(1, p.device)          # zeroed word (fp64 slot): single-launch reduction
+    call('rv_reduce_mean', kind, ptr(p), ptr(t), n, ptr(out), ptr(ws), ptr(ticket), stream())
     return out
 
 

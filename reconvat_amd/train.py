@@ -154,7 +154,7 @@ class FlatAdam:
 
     def clip_grad_norm_(self, max_norm):
         ws = torch.empty((self.n + 2047) // 2048, device=self.flat_grad.device, dtype=torch.float32)
-        call('rv_reduce_mean', 3, ptr(self.flat_grad), None, self.n, ptr(self.norm_buf), ptr(ws), stream())
+        call('rv_reduce_mean', 3, ptr(self.flat_grad), None, self.n, ptr(self.norm_buf), ptr(ws), None, stream())
         call('rv_clip_scale', ptr(self.flat_grad), self.n, ptr(self.norm_buf), float(max_norm), stream())
         return self.norm_buf
 
