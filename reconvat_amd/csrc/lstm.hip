@@ -8,15 +8,17 @@
 //
 // The input projections x W_ih^T + b_ih + b_hh of all time steps are one MFMA GEMM (rv_gemm) done by the caller; the
 // kernels here run only the sequential part.  One persistent launch covers both directions and all T steps:
-//   * direction d, workgroup j owns hidden units [16 j, 16 j + 16).  Its slice of W_hh stays in VGPRs for the whole
-//     sequence (H/4 registers per lane), laid out as the A operand of v_mfma_f32_16x16x4_f32;
-//   * per step the workgroup stages h_{t-1} (B x H) into LDS, issues H/4 MFMAs per wave (batch on the N side), applies
-//     the gate non-linearities in the accumulator layout (a lane ends up with the four gates of one (unit, batch)
-//     cell), writes h_t into the output tensor -- which is also the exchange buffer for the next step -- and
-//     publishes a per-workgroup step counter;
-//   * workgroups of one direction synchronise through those counters (release/acquire at agent scope); nothing else
-//     is shared.  All 2*H/16 workgroups must be co-resident, which 256 CUs guarantee for H <= 1024.
-// The backward kernel is the same machine run over W_hh^T with the K = 4H reduction split over the four waves.
+//   * direction d, workgroup j owns hidden units [16 j, 16 j + 16) as 16-row MFMA tiles; its 4*KS waves (16 for H = 384)
+//     each keep one tile x one K slice of W_hh in VGPRs for the whole sequence (24 registers per lane), laid out as the A
+//     operand of v_mfma_f32_16x16x4_f32;
+//   * per step the workgroup stages h_{t-1} (B x H) into LDS, issues 24 MFMAs per wave (batch on the N side), adds the
+//     partial tiles through LDS, applies the gate non-linearities in the accumulator layout (a lane ends up with the four
+//     gates of one (unit, batch) cell), writes h_t into the output tensor -- which is also the exchange buffer for the
+//     next step -- and publishes a per-workgroup step counter;
+//   * workgroups of one direction synchronise through those counters (release at agent scope; relaxed polling and ONE
+//     acquire fence per step); nothing else is shared.  All 2*H/16 workgroups must be co-resident, which 256 CUs
+//     guarantee for H <= 1024; a workgroup that waits too long gives up and raises the error word (ops.lstm_check).
+// The backward kernel is the same machine run over W_hh^T with the K = 4H reduction split over the workgroup's waves.
 #include "common.h"
 
 #define LSTM_SPIN_LIMIT (1 << 22)
