@@ -773,7 +773,7 @@ def _splitk_for(m_out, n_out, k):
     blocks = ((m_out + 63) // 64) * ((n_out + 63) // 64)
     if blocks >= 256 or k < 512:
         return 1
-    return max(1, min(32, 512 // blocks, k // 128))
+    return max(1, min(16, 512 // blocks, k // 128))      # (tools/bench_gemm_splitk.py: beyond 16 slices the atomics cost more than they hide)
 
 
 class LinearFn(Function):
