@@ -3,6 +3,7 @@
 step (BASELINE.json metric) on N MI355X GPUs of one node, one process per GPU.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          (self-launching: spawns N fresh rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -128,28 +129,78 @@ def measure_conv_phase(step_fn, device):
     return total_ms, total_flops, per_kernel, len(records)
 
 
-def cpu_baseline(seconds_budget=30.0):
-    """The oracle (CPU restatement pinned to the reference) timed on this host: one labelled + one
-    unlabelled full-length segment per step, VAT+recon, Adam -- a bounded sample of the same workload."""
+def _cpu_steps(threads, budget_s, min_timed=3, max_timed=3):
+    """`min_timed`..`max_timed` oracle steps (after one warm-up) with torch.set_num_threads(threads)."""
     from oracle import fixture as fx, model as om
+    torch.set_num_threads(threads)
     torch.manual_seed(0)
     params = fx.fixture_params('onset', True)
     g = torch.Generator().manual_seed(1)
     bl, bul = synthetic_batch(1, g, 'cpu'), synthetic_batch(1, g, 'cpu')
     state, times = {}, []
     t_start = time.time()
-    for i in range(4):
+    for i in range(1 + max_timed):
         t0 = time.time()
         om.train_step(params, state, i, bl, bul, om.run_on_batch_onset, VAT=True, reconstruction=True, xi=1e-6, eps=2.0)
         times.append(time.time() - t0)
-        if time.time() - t_start > seconds_budget and i >= 1:
+        if len(times) - 1 >= min_timed and time.time() - t_start > budget_s:
             break
-    timed = times[1:] if len(times) > 1 else times
-    per_step = sorted(timed)[len(timed) // 2]
-    return {'value': round(2 * SEG_SECONDS / per_step, 3), 'unit': 'audio-s/s', 'cores': torch.get_num_threads(),
-            'kind': 'port',
-            'sample': f'B_l=1 + B_ul=1 full 327680-sample segments, UNet_Onset VAT+recon fp32, '
-                      f'{len(timed)} timed steps after 1 warm-up ({per_step:.2f} s/step)'}
+    timed = times[1:]
+    return sorted(timed)[len(timed) // 2], len(timed)
+
+
+def cpu_baseline():
+    """The oracle (CPU restatement pinned to the reference by tests/golden) timed on this host's cores: one labelled + one
+    unlabelled full-length segment per step (B = 1 + 1: a bounded sample of the B = 8 + 8 workload, same step definition:
+    front-end, 2 x VAT, forward, backward, Adam), 1 warm-up + 3 timed steps at 8 threads and at all physical cores
+    (BASELINE.md section 4).  `value` is the faster of the two."""
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:  # noqa: BLE001
+        physical = os.cpu_count()
+    prev = torch.get_num_threads()
+    runs = []
+    for n in sorted({min(8, physical), physical}):
+        per_step, timed = _cpu_steps(n, budget_s=60.0)
+        runs.append({'threads': n, 's_per_step': round(per_step, 3), 'timed_steps': timed,
+                     'audio_s_per_s': round(2 * SEG_SECONDS / per_step, 3)})
+    torch.set_num_threads(prev)
+    best = max(runs, key=lambda r: r['audio_s_per_s'])
+    return {'value': best['audio_s_per_s'], 'unit': 'audio-s/s', 'cores': best['threads'], 'kind': 'port',
+            'physical_cores': physical, 'logical_cpus': os.cpu_count(), 'runs': runs,
+            'sample': f'B_l=1 + B_ul=1 full 327680-sample segments per step, UNet_Onset VAT+recon fp32 (oracle = CPU port pinned '
+                      f'to the reference), median of {best["timed_steps"]} timed steps after 1 warm-up at torch.set_num_threads('
+                      f'{best["threads"]}) ({best["s_per_step"]:.2f} s/step); all thread counts tried are in `runs`'}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: spawn N fresh rank processes (one per GPU) BEFORE this process touches
+    the GPU, wait for all of them, relay rank 0's JSON line; non-zero exit if any rank fails."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count()              # does not initialise the GPU runtime
+    if have < n:
+        raise SystemExit(f'bench.py --gpus {n}: this node exposes {have} GPU(s)')
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        raise SystemExit(f'bench.py: rank(s) failed: {bad}')
 
 
 def main():
@@ -168,9 +219,10 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        return self_launch(args)
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+        raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
     torch.cuda.set_device(local)
@@ -218,6 +270,17 @@ def main():
         elapsed = t.item()
     loss = float(step.loss.item())
     nan_flag = int(model.vat_loss.nan_flag.item())
+    loss_terms = {k: round(float(v), 6) for k, v in step.losses.items()}      # the 11 loss values of the last timed step
+    # replica check: identical seeded weights + one summed gradient bucket + identical Adam => bit-identical parameters on
+    # every rank.  Checksum = wrapping int64 sum of the parameter bit patterns; MAX - MIN over ranks must be 0.
+    rccl_ranks, replicas_equal = 1, True
+    checksum = opt.flat_param.view(torch.int32).sum(dtype=torch.int64).reshape(1)
+    if world > 1:
+        rccl_ranks = dist.get_world_size()
+        hi, lo = checksum.clone(), checksum.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        replicas_equal = bool((hi - lo).item() == 0)
     ms = elapsed / args.steps * 1e3
     audio_s = world * 2 * args.batch * SEG_SECONDS * args.steps / elapsed
 
@@ -228,7 +291,8 @@ def main():
         'config': {'workload': f'ReconVAT UNet_Onset VAT=True reconstruction=True, per-GPU B_l={args.batch} + '
                                f'B_ul={args.batch} segments of 327680 samples (640 frames x 229 mel), Adam+StepLR, fp32',
                    'parallelism': f'dp{world}', 'hipgraph': used_graph, 'two_stream_schedule': not args.single_stream, 'labelled_only_audio_s_per_s': round(audio_s / 2, 2),
-                   'final_loss': round(loss, 5), 'vat_nan_flag': nan_flag},
+                   'final_loss': round(loss, 5), 'vat_nan_flag': nan_flag, 'losses_last_step': loss_terms},
+        'rccl_ranks': rccl_ranks, 'replicas_equal': replicas_equal, 'param_checksum': int(checksum.item()),
     }
     if rank == 0 and world == 1:
         if not args.no_roofline:

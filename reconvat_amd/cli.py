@@ -125,8 +125,8 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
     if device_feed and hasattr(l_set, 'data') and str(device).startswith('cuda'):
         # corpus resident in HBM, batches cropped/decoded by rv_crop_segments (reconvat_amd/feed.py)
         from .feed import device_loader
-        l_loader = device_loader(l_set, train_batch_size, device, seed=42 + rank)
-        ul_loader = device_loader(ul_set, batch_size, device, seed=43 + rank) if VAT else None
+        l_loader = device_loader(l_set, train_batch_size, device, rank=rank, world=world, seed=42 + rank)
+        ul_loader = device_loader(ul_set, batch_size, device, rank=rank, world=world, seed=43 + rank) if VAT else None
     else:
         ul_loader = DataLoader(ul_set, batch_size, shuffle=True, drop_last=True) if VAT else None
         l_loader = DataLoader(l_set, train_batch_size, shuffle=True, drop_last=True)

@@ -35,6 +35,10 @@ class DeviceCorpus:
         self.n_keys = int(tracks[0]['label'].shape[1])
         self.paths = [t['path'] for t in tracks]
         self.lengths = np.array([len(t['audio']) for t in tracks], dtype=np.int64)
+        if len(tracks) < self.batch_size:
+            # an epoch of zero batches would make cycle(loader) spin forever
+            raise ValueError(f'DeviceCorpus: rank {rank} of {world} holds {len(tracks)} track(s), fewer than batch_size='
+                             f'{self.batch_size}; lower the batch size or the number of ranks')
         if (self.lengths <= self.sequence_length).any():
             raise ValueError('every track must be longer than sequence_length (the reference draws randint(T - L))')
         # concatenate; track starts padded to 8 samples / 16 label bytes so that aligned crops use 16-byte accesses
@@ -60,7 +64,11 @@ class DeviceCorpus:
         self.l_off = np.array(l_off, dtype=np.int64)
         self.random = np.random.RandomState(seed)                  # the reference's crop stream (one draw per item)
         self.sampler = torch.Generator().manual_seed(sampler_seed)  # item order (RandomSampler analogue)
-        self._begins = torch.empty((2, self.batch_size), dtype=torch.int64).pin_memory()
+        # crop offsets travel through a ring of pinned staging buffers, each guarded by the event of its last upload:
+        # a batch drawn while an earlier upload is still queued never overwrites offsets the device has not read yet
+        self._ring = [torch.empty((2, self.batch_size), dtype=torch.int64).pin_memory() for _ in range(4)]
+        self._ring_events = [None] * len(self._ring)
+        self._ring_pos = 0
 
     def __len__(self):
         return len(self.paths) // self.batch_size                  # batches per epoch (drop_last=True)
@@ -76,9 +84,17 @@ class DeviceCorpus:
         indices = [int(i) for i in indices]
         b = len(indices)
         steps, begins = self.draw(indices)
-        self._begins[0, :b] = torch.from_numpy(self.a_off[indices] + begins)
-        self._begins[1, :b] = torch.from_numpy(self.l_off[indices] + steps * self.n_keys)
-        dev_begins = self._begins[:, :b].to(self.device, non_blocking=True)
+        slot = self._ring_pos
+        self._ring_pos = (slot + 1) % len(self._ring)
+        if self._ring_events[slot] is not None:
+            self._ring_events[slot].synchronize()
+        staging = self._ring[slot]
+        staging[0, :b] = torch.from_numpy(self.a_off[indices] + begins)
+        staging[1, :b] = torch.from_numpy(self.l_off[indices] + steps * self.n_keys)
+        dev_begins = staging[:, :b].to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._ring_events[slot] = ev
         n_steps = self.sequence_length // HOP_LENGTH
         out = {'audio': torch.empty((b, self.sequence_length), device=self.device, dtype=torch.float32)}
         for k in ('onset', 'offset', 'frame', 'velocity'):
@@ -98,5 +114,7 @@ class DeviceCorpus:
 
 
 def device_loader(dataset, batch_size, device, rank=0, world=1, seed=42):
-    """DeviceCorpus over the in-memory tracks of a PianoRollAudioDataset (``dataset.data``)."""
-    return DeviceCorpus(dataset.data, dataset.sequence_length, batch_size, device, seed=seed, rank=rank, world=world)
+    """DeviceCorpus over the in-memory tracks of a PianoRollAudioDataset (``dataset.data``); with world > 1 every rank
+    keeps a disjoint shard (tracks rank, rank + world, ...) and its own item-order stream."""
+    return DeviceCorpus(dataset.data, dataset.sequence_length, batch_size, device, seed=seed, rank=rank, world=world,
+                        sampler_seed=rank)

@@ -93,7 +93,7 @@ class FlatAdam:
     Parameters that never receive a gradient keep a zero gradient and zero moments -> they do not move,
     which is what torch.optim.Adam does by skipping them (6 such tensors in UNet_Onset)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, step_size=1000, gamma=0.98, data_parallel=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, step_size=1000, gamma=0.98, data_parallel=None):
         self.params = [p for p in params if p.requires_grad]
         assert self.params, 'no trainable parameters'
         dev = self.params[0].device
@@ -120,7 +120,8 @@ class FlatAdam:
         self.n = n
         self.lr, self.betas, self.eps, self.step_size, self.gamma = lr, betas, eps, step_size, gamma
         self.grad_scale = 1.0
-        self.data_parallel = data_parallel      # all-reduce the flat bucket inside step()
+        # the ONE all-reduce call site of a step is step(); None = whenever a process group with world > 1 is up
+        self.data_parallel = data_parallel
         ops.invalidate_weight_cache()
 
     def enable_side_bucket(self, n=1):
@@ -144,8 +145,8 @@ class FlatAdam:
                 p.grad = self.flat_grad[off:off + p.numel()].view_as(p.data)
 
     def step(self):
-        if self.data_parallel:
-            allreduce_gradients(self)
+        if self.data_parallel or self.data_parallel is None:
+            allreduce_gradients(self)              # the ONE collective of a step (no-op without a process group)
         call('rv_adam_step', ptr(self.flat_param), ptr(self.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n,
              ptr(self.step_count), self.lr, self.step_size, self.gamma, self.betas[0], self.betas[1], self.eps,
              self.grad_scale, stream())
@@ -272,9 +273,7 @@ class TrainStep:
             if self.pack_plan is None:
                 self.pack_plan = ops.PackPlan(self.opt.flat_grad.device)
             self._dual_ready = True
-        if not self.opt.data_parallel:
-            allreduce_gradients(self.opt)
-        self.opt.step()
+        self.opt.step()                        # [RCCL all-reduce of the flat bucket] + Adam + StepLR
         if self.clip:
             self.opt.clip_grad_norm_(self.clip)
         self.pack_plan.run()                   # the next step's forward finds every packed weight fresh

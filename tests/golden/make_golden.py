@@ -374,6 +374,53 @@ def g_dataset():
     save('dataset', **{k: np.asarray(v) for k, v in out.items()})
 
 
+def g_ingest():
+    """model/dataset.py:85-142 (`load`: audio + tsv -> int16 audio / uint8 label / velocity rolls) and the group -> file rules
+    of MAPS (:182-214, incl. overlapping.pkl and supersmall) and MusicNet (:238-342), run by the REFERENCE classes on the
+    synthetic corpus above (soundfile -- absent here -- stubbed with a wav reader; the corpus is wav with the .flac name the
+    reference globs for)."""
+    import shutil
+    import tempfile
+    from scipy.io import wavfile
+    from oracle import dataset as od
+    root = od.ingest_corpus(tempfile.mkdtemp())
+    # the reference globs '*.flac' only: give every wav a .flac twin (same bytes; the stubbed reader sniffs nothing)
+    for dirpath, _dirs, files in os.walk(root):
+        for f in files:
+            if f.endswith('.wav'):
+                shutil.copy(os.path.join(dirpath, f), os.path.join(dirpath, f[:-4] + '.flac'))
+
+    def sf_read(path, dtype='int16'):
+        sr, pcm = wavfile.read(path)
+        return pcm, sr
+    sys.modules['soundfile'].read = sf_read
+    ref.dataset.soundfile.read = sf_read
+    cwd = os.getcwd()
+    os.chdir(root)                                    # the reference opens 'overlapping.pkl' relative to the cwd
+    out = {}
+    try:
+        def summarise(tag, ds):
+            out[tag + '_paths'] = np.array([os.path.relpath(d['path'], root)[:-5] for d in ds.data])
+            out[tag + '_label_sum'] = np.array([int(d['label'].long().sum()) for d in ds.data])
+            out[tag + '_label_w'] = np.array([int((d['label'].long() * torch.arange(1, 89)).sum()) for d in ds.data])
+            out[tag + '_vel_sum'] = np.array([int(d['velocity'].long().sum()) for d in ds.data])
+            out[tag + '_steps'] = np.array([d['label'].shape[0] for d in ds.data])
+            out[tag + '_audio_sum'] = np.array([int(d['audio'].long().sum()) for d in ds.data])
+        summarise('maps_small', ref.dataset.MAPS(path='MAPS', groups=['AkPnBcht'], overlap=False, refresh=True))
+        summarise('maps_supersmall', ref.dataset.MAPS(path='MAPS', groups=['AkPnBcht'], overlap=False, supersmall=True, refresh=True))
+        summarise('maps_test', ref.dataset.MAPS(path='MAPS', groups=['ENSTDkAm'], overlap=True, refresh=True))
+        d0 = ref.dataset.MAPS(path='MAPS', groups=['ENSTDkAm'], overlap=True, refresh=True).data[0]
+        out['maps_test_label0'] = d0['label'].numpy()
+        out['maps_test_velocity0'] = d0['velocity'].numpy()
+        for g in ('train_string_l', 'train_string_ul', 'train_violin_l', 'train_violin_ul', 'test_violin', 'train_wind_l',
+                  'train_wind_ul', 'test_wind', 'train_flute_l', 'train_flute_ul', 'test_flute'):
+            summarise('mn_' + g, ref.dataset.MusicNet(path='MusicNet', groups=[g], refresh=True))
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(root)
+    save('ingest', **out)
+
+
 def decoding_rolls(seed, T=300, P=88):
     """Smooth random posteriorgrams with note-like runs (shared with tests/test_decoding.py through this recipe)."""
     rng = np.random.RandomState(seed)
@@ -560,7 +607,7 @@ def g_onset_frames():
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['frontend', 'unet', 'attention', 'networks', 'vat', 'run_on_batch', 'train_step', 'dataset',
-                             'decoding', 'onset_frames']
+                             'decoding', 'onset_frames', 'ingest']
     for w in which:
         print('==', w)
         globals()['g_' + w]()
