@@ -137,9 +137,10 @@ int rv_reduce_mean(int kind, const float* p, const float* t, long n, float* out,
 int rv_loss_bwd(int kind, const float* p, const float* t, long n, const float* gout, float* gp, void* stream);
 
 /* ---- optimiser (torch.optim.Adam + StepLR + clip_grad_norm_, train_UNet_Onset_VAT.py:113,124;
- * model/helper_functions.py:602-607) on flat buffers; *step = optimiser steps already taken. */
+ * model/helper_functions.py:602-607) on flat buffers; *step = optimiser steps already taken.  skip (nullable): device int;
+ * when *skip != 0 (a kernel of this step flagged its results invalid, see rv_lstm_fwd) the update is not applied. */
 int rv_adam_step(float* p, const float* g, float* m, float* v, long n, const long* step, float lr0, long decay_steps,
-                 float decay_rate, float beta1, float beta2, float eps, float grad_scale, void* stream);
+                 float decay_rate, float beta1, float beta2, float eps, float grad_scale, const int* skip, void* stream);
 int rv_counter_add(long* counter, long inc, void* stream);
 int rv_clip_scale(float* g, long n, const float* total_norm, float max_norm, void* stream);
 
@@ -160,14 +161,16 @@ int rv_crop_segments(const short* audio, const unsigned char* label, const unsig
  * in registers as MFMA operands, h exchanged through `out`, per-workgroup step counters in `flags`).
  * out [B,T,2H] (forward half | reverse half, as nn.LSTM returns it); gates [B,T,2,4,H] (activated) and cs [B,T,2,H]
  * are saved for the backward pass (both NULL = inference).  flags: rv_lstm_flag_bytes(H) bytes of device scratch, reset by
- * the call itself; the last int is non-zero afterwards if a workgroup gave up waiting (co-residency violated).
+ * the call itself; the last int is non-zero afterwards if a workgroup gave up waiting (co-residency violated).  sticky_err
+ * (nullable): ONE persistent device int per device that the kernels atomicOr a time-out into and never clear -- the host
+ * reads and clears it at its own sync points, and rv_adam_step(skip = sticky_err) refuses to apply a poisoned step.
  * B <= 16 (the batch is the N side of one 16-wide MFMA tile); H in {384, 32}.  rv_lstm_bwd: dout [B,T,2H] -> dxg [B,T,2,4H]; dW_ih, dW_hh, db and dx are GEMMs / column sums
  * of dxg done by the caller. */
 long rv_lstm_flag_bytes(int H);
 int rv_lstm_fwd(const float* xg, const float* whh_fwd, const float* whh_rev, float* out, float* gates, float* cs, int* flags,
-                int B, int T, int H, void* stream);
+                int* sticky_err, int B, int T, int H, void* stream);
 int rv_lstm_bwd(const float* dout, const float* whh_fwd, const float* whh_rev, const float* gates, const float* cs, float* dxg,
-                int* flags, int B, int T, int H, void* stream);
+                int* flags, int* sticky_err, int B, int T, int H, void* stream);
 
 /* nn.MaxPool2d((1,2)) over the frequency axis of an NHWC tensor x [rows, W, C] -> y [rows, W/2, C] fused with the
  * nn.Dropout(p) that follows it in ConvStack (model/onset_frame_VAT.py:336-343; p = 0 disables the drop).  code

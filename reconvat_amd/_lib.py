@@ -50,13 +50,13 @@ SIGNATURES = {
     'rv_reduce_workspace_bytes': (L, [L]),
     'rv_reduce_mean': (I, [I, P, P, L, P, P, P, P]),
     'rv_loss_bwd': (I, [I, P, P, L, P, P, P]),
-    'rv_adam_step': (I, [P, P, P, P, L, P, F, L, F, F, F, F, F, P]),
+    'rv_adam_step': (I, [P, P, P, P, L, P, F, L, F, F, F, F, F, P, P]),
     'rv_counter_add': (I, [P, L, P]),
     'rv_clip_scale': (I, [P, L, P, F, P]),
     'rv_crop_segments': (I, [P, P, P, P, P, I, L, I, I, P, P, P, P, P, P]),
     'rv_lstm_flag_bytes': (L, [I]),
-    'rv_lstm_fwd': (I, [P, P, P, P, P, P, P, I, I, I, P]),
-    'rv_lstm_bwd': (I, [P, P, P, P, P, P, P, I, I, I, P]),
+    'rv_lstm_fwd': (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
+    'rv_lstm_bwd': (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
     'rv_maxpool_w2_dropout_fwd': (I, [P, P, P, L, I, I, F, U, P, P]),
     'rv_maxpool_w2_dropout_bwd': (I, [P, P, P, L, I, I, F, P]),
     'rv_dropout': (I, [P, P, P, P, L, F, U, P, P]),

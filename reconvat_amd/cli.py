@@ -176,6 +176,7 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
                 else:
                     step_runner.load(bl, bul)
                 total += float(step_runner())
+                step_runner.check()                # VAT NaN assert + BiLSTM time-out flag (the loss read-back just synchronised)
             losses = step_runner.losses
             if rank == 0:
                 print(f'Train Epoch: {ep}\tLoss: {total / iteration:.6f}')
@@ -184,7 +185,7 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
                                                    scheduler, clip_gradient_norm, alpha, VAT, VAT_start)
         if onset_script == 'baseline' and str(device).startswith('cuda'):
             from . import ops
-            ops.lstm_check(torch.device(device))          # a timed-out recurrence launch invalidates the epoch: fail loudly
+            ops.lstm_check(torch.device(device))          # eager loop: a timed-out recurrence launch fails the epoch loudly
         if rank == 0:
             for key, value in losses.items():
                 writer.add_scalar(key, float(value), ep)

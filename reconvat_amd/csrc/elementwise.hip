@@ -214,9 +214,11 @@ struct AdamArgs {
     const long* step;      // number of optimiser steps already taken (device scalar)
     float lr0, decay_rate; long decay_steps;
     float b1, b2, eps, grad_scale;
+    const int* skip;       // nullable: a non-zero word means "this step's gradients are invalid" -> leave p, m, v untouched
 };
 
 __global__ __launch_bounds__(256) void adam_k(AdamArgs a) {
+    if (a.skip && *a.skip != 0) return;
     const long step = *a.step;
     const double t = (double)(step + 1);
     const float lr = a.lr0 * (float)pow((double)a.decay_rate, (double)(step / a.decay_steps));
@@ -338,8 +340,9 @@ int rv_colsum(const float* x, int ld, long M, int N, float* out, int accumulate,
 // One Adam step on flat buffers; lr = lr0 * decay_rate^(step // decay_steps) (StepLR); *step is NOT modified
 // (call rv_counter_add afterwards).  grad_scale multiplies g on the fly (1/world_size after an all-reduce sum).
 int rv_adam_step(float* p, const float* g, float* m, float* v, long n, const long* step, float lr0, long decay_steps,
-                 float decay_rate, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+                 float decay_rate, float beta1, float beta2, float eps, float grad_scale, const int* skip, void* stream) {
     AdamArgs a;
+    a.skip = skip;
     a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.step = step; a.lr0 = lr0; a.decay_steps = decay_steps;
     a.decay_rate = decay_rate; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.grad_scale = grad_scale;
     hipLaunchKernelGGL(adam_k, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a);

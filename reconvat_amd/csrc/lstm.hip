@@ -49,7 +49,8 @@ struct LstmArgs {
     float* cs;              // [B,T,2,H] cell states
     const float* dout;      // bwd: [B,T,2H]
     float* dxg;             // bwd: [B,T,2,4H] gradient wrt xg
-    int* flags;             // [2][H/16] step counters + [1] error word, zeroed by the host wrapper
+    int* flags;             // [2][H/16] step counters + [1] per-launch error word, zeroed by the host wrapper
+    int* sticky;            // persistent per-device error word (never cleared here): a time-out is atomicOr'ed into it directly
     int B, T;
 };
 
@@ -74,13 +75,19 @@ __device__ __forceinline__ float xload(const float* p) { return __hip_atomic_loa
 
 // wait until every workgroup of this direction has published step >= s; wave 0 polls, one counter per lane
 template <int NWG>
-__device__ __forceinline__ void wait_step(int* flag, int* err, int s, int tid) {
+__device__ __forceinline__ void wait_step(int* flag, int* err, int* sticky, int s, int tid) {
     if ((RV_LSTM_ABL & 1) == 0 && tid < NWG) {
         // poll relaxed (an acquire load would invalidate this XCD's L2 on every iteration, under the kernels of the other
-        // streams too); ONE acquire fence once every counter has arrived
+        // streams too); ONE acquire fence once every counter has arrived.  A time-out raises the per-launch error word AND
+        // the persistent per-device word (atomics: several streams may run recurrences at once); every poller looks at the
+        // per-launch word every 256 polls, so once any workgroup has given up the remaining steps of the launch cost a few
+        // hundred polls each instead of LSTM_SPIN_LIMIT (the launch is dead: its results are flagged invalid, the optimiser
+        // kernel skips the update -- rv_adam_step's `skip`).
         int spins = 0;
         while (__hip_atomic_load(&flag[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < s) {
-            if (++spins > LSTM_SPIN_LIMIT) { atomicOr(err, 1); break; }
+            ++spins;
+            if ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            if (spins > LSTM_SPIN_LIMIT) { atomicOr(err, 1); if (sticky) atomicOr(sticky, 1); break; }
             __builtin_amdgcn_s_sleep(1);
         }
     }
@@ -150,12 +157,12 @@ __global__ __launch_bounds__(256 * KS) void lstm_fwd_k(LstmArgs a) {
                     *reinterpret_cast<f32x4*>(&hs[bb][4 * k4]) = v;
                 }
                 if (__syncthreads_and(ok || dead)) break;
-                if (++spins > LSTM_SPIN_LIMIT) { dead = true; if (tid == 0) atomicOr(err, 1); }     // block-uniform
+                if (++spins > LSTM_SPIN_LIMIT) { dead = true; if (tid == 0) { atomicOr(err, 1); if (a.sticky) atomicOr(a.sticky, 1); } }     // block-uniform
             }
 #pragma unroll
             for (int c = 0; c < NC; ++c) hb[c] = *reinterpret_cast<const f32x4*>(&hs[brow][kpart * KW + 16 * c + 4 * g]);
 #elif RV_LSTM_STAGE
-            wait_step<NWG>(flag, err, s, tid);
+            wait_step<NWG>(flag, err, a.sticky, s, tid);
             // h_{t-1} (B x H) once per workgroup through LDS: one 16-byte load per thread instead of NC per lane
             for (int idx = tid; (RV_LSTM_ABL & 2) == 0 && idx < B * (H / 4); idx += 256 * KS) {
                 const int bb = idx / (H / 4), k4 = idx - bb * (H / 4);
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(256 * KS) void lstm_fwd_k(LstmArgs a) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) hb[c] = *reinterpret_cast<const f32x4*>(&hs[brow][kpart * KW + 16 * c + 4 * g]);
 #else
-            wait_step<NWG>(flag, err, s, tid);
+            wait_step<NWG>(flag, err, a.sticky, s, tid);
             const float* hp = a.out + ((long)brow * T + tp) * 2 * H + d * H + kpart * KW + 4 * g;
 #pragma unroll
             for (int c = 0; c < NC; ++c) hb[c] = *reinterpret_cast<const f32x4*>(hp + 16 * c);
@@ -264,10 +271,10 @@ __global__ __launch_bounds__(256 * KS) void lstm_bwd_k(LstmArgs a) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { db[c][q] = xload(dp + 16 * c + q); ok &= (__float_as_uint(db[c][q]) != LSTM_SENTINEL); }
                 if (__all(ok) || dead) break;
-                if (++spins > LSTM_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(err, 1); }
+                if (++spins > LSTM_SPIN_LIMIT) { dead = true; if (lane == 0) { atomicOr(err, 1); if (a.sticky) atomicOr(a.sticky, 1); } }
             }
 #else
-            wait_step<NWG>(flag, err, s, tid);
+            wait_step<NWG>(flag, err, a.sticky, s, tid);
 #pragma unroll
             for (int c = 0; c < NC; ++c) db[c] = *reinterpret_cast<const f32x4*>(dp + 16 * c);
 #endif
@@ -321,12 +328,12 @@ static int lstm_check(int B, int T, int H) {
 }
 
 extern "C" int rv_lstm_fwd(const float* xg, const float* whh_fwd, const float* whh_rev, float* out, float* gates, float* cs,
-                           int* flags, int B, int T, int H, hipStream_t st) {
+                           int* flags, int* sticky_err, int B, int T, int H, hipStream_t st) {
     if (int rc = lstm_check(B, T, H)) return rc;
     RV_CHECK_ARG(xg && whh_fwd && whh_rev && out && flags, "rv_lstm_fwd: null pointer");
     RV_CHECK_ARG((gates == nullptr) == (cs == nullptr), "rv_lstm_fwd: gates and cs are saved together");
     LstmArgs a = {};
-    a.xg = xg; a.whh[0] = whh_fwd; a.whh[1] = whh_rev; a.out = out; a.gates = gates; a.cs = cs; a.flags = flags; a.B = B; a.T = T;
+    a.xg = xg; a.whh[0] = whh_fwd; a.whh[1] = whh_rev; a.out = out; a.gates = gates; a.cs = cs; a.flags = flags; a.sticky = sticky_err; a.B = B; a.T = T;
     hipLaunchKernelGGL(lstm_zero_flags_k, dim3(1), dim3(256), 0, st, flags, (int)(rv_lstm_flag_bytes(H) / sizeof(int)));
 #if RV_LSTM_XCD
     if (hipMemsetAsync(out, 0xFF, (size_t)B * T * 2 * H * sizeof(float), st) != hipSuccess) { rv_set_error("rv_lstm_fwd: memset failed"); return RV_ELAUNCH; }
@@ -341,12 +348,12 @@ extern "C" int rv_lstm_fwd(const float* xg, const float* whh_fwd, const float* w
 }
 
 extern "C" int rv_lstm_bwd(const float* dout, const float* whh_fwd, const float* whh_rev, const float* gates, const float* cs,
-                           float* dxg, int* flags, int B, int T, int H, hipStream_t st) {
+                           float* dxg, int* flags, int* sticky_err, int B, int T, int H, hipStream_t st) {
     if (int rc = lstm_check(B, T, H)) return rc;
     RV_CHECK_ARG(dout && whh_fwd && whh_rev && gates && cs && dxg && flags, "rv_lstm_bwd: null pointer");
     LstmArgs a = {};
     a.dout = dout; a.whh[0] = whh_fwd; a.whh[1] = whh_rev; a.gates = const_cast<float*>(gates); a.cs = const_cast<float*>(cs);
-    a.dxg = dxg; a.flags = flags; a.B = B; a.T = T;
+    a.dxg = dxg; a.flags = flags; a.sticky = sticky_err; a.B = B; a.T = T;
     hipLaunchKernelGGL(lstm_zero_flags_k, dim3(1), dim3(256), 0, st, flags, (int)(rv_lstm_flag_bytes(H) / sizeof(int)));
 #if RV_LSTM_XCD
     if (hipMemsetAsync(dxg, 0xFF, (size_t)B * T * 8 * H * sizeof(float), st) != hipSuccess) { rv_set_error("rv_lstm_bwd: memset failed"); return RV_ELAUNCH; }

@@ -1147,9 +1147,16 @@ def _lstm_err(device):
     return t
 
 
+def step_error_word(device):
+    """The persistent per-device "this step is invalid" word: kernels atomicOr into it (BiLSTM time-outs), rv_adam_step skips
+    the update while it is set, lstm_check() reads and clears it."""
+    return _lstm_err(torch.device(device))
+
+
 def lstm_check(device):
     """Raise if any BiLSTM launch since the last call gave up waiting for a neighbour workgroup (its workgroups were
-    not co-resident): the results of that launch are invalid.  Synchronises; call it once per step / epoch, not per op."""
+    not co-resident): the results of that launch are invalid (and FlatAdam did not apply them).  Synchronises; call it at
+    a point where the host waits for the step anyway (the per-step loss read-back), not per op."""
     t = _lstm_err(torch.device(device))
     if int(t.item()) != 0:
         t.zero_()
@@ -1177,8 +1184,9 @@ class BiLstmFn(Function):
         cs = torch.empty((bb, t, 2, h), device=x.device, dtype=torch.float32) if train else None
         flags = torch.empty(_lib.load().rv_lstm_flag_bytes(h) // 4, device=x.device, dtype=torch.int32)
         w_hh, w_hh_r = w_hh.contiguous(), w_hh_r.contiguous()
-        call('rv_lstm_fwd', ptr(xg), ptr(w_hh), ptr(w_hh_r), ptr(out), ptr(gates), ptr(cs), ptr(flags), bb, t, h, stream())
-        _lstm_err(x.device).bitwise_or_(flags[-1:])          # sticky time-out flag, read by ops.lstm_check()
+        # a time-out is atomicOr'ed by the kernel itself into the persistent per-device word (ops.lstm_check / FlatAdam skip)
+        call('rv_lstm_fwd', ptr(xg), ptr(w_hh), ptr(w_hh_r), ptr(out), ptr(gates), ptr(cs), ptr(flags), ptr(_lstm_err(x.device)),
+             bb, t, h, stream())
         ctx.params = (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
         ctx.save_for_backward(x2, out, gates, cs, w_ih, w_hh, w_ih_r, w_hh_r)
         ctx.dims = (bb, t, i, h)
@@ -1191,8 +1199,8 @@ class BiLstmFn(Function):
         bb, t, i, h = ctx.dims
         dout = dout.contiguous()
         dxg = torch.empty((bb * t, 2, 4 * h), device=dout.device, dtype=torch.float32)
-        call('rv_lstm_bwd', ptr(dout), ptr(w_hh), ptr(w_hh_r), ptr(gates), ptr(cs), ptr(dxg), ptr(ctx.flags), bb, t, h, stream())
-        _lstm_err(dout.device).bitwise_or_(ctx.flags[-1:])
+        call('rv_lstm_bwd', ptr(dout), ptr(w_hh), ptr(w_hh_r), ptr(gates), ptr(cs), ptr(dxg), ptr(ctx.flags),
+             ptr(_lstm_err(dout.device)), bb, t, h, stream())
         # h_{prev} of every step: the output shifted by one step along each direction's own time arrow
         hprev = torch.zeros((bb, t, 2, h), device=dout.device, dtype=torch.float32)
         o4 = out.view(bb, t, 2, h)

@@ -97,8 +97,7 @@ class FlatAdam:
         self.params = [p for p in params if p.requires_grad]
         assert self.params, 'no trainable parameters'
         dev = self.params[0].device
-        if dev.type != 'cuda':
-            raise RuntimeError('FlatAdam runs on a HIP device only (no CPU fallback)')
+        self._require_hip(dev)
         n = sum(p.numel() for p in self.params)
         self.flat_param = torch.empty(n, device=dev, dtype=torch.float32)
         self.flat_grad = torch.zeros(n, device=dev, dtype=torch.float32)
@@ -120,9 +119,15 @@ class FlatAdam:
         self.n = n
         self.lr, self.betas, self.eps, self.step_size, self.gamma = lr, betas, eps, step_size, gamma
         self.grad_scale = 1.0
+        ops.step_error_word(dev)                # create the per-device error word outside any graph capture
         # the ONE all-reduce call site of a step is step(); None = whenever a process group with world > 1 is up
         self.data_parallel = data_parallel
         ops.invalidate_weight_cache()
+
+    @staticmethod
+    def _require_hip(dev):
+        if dev.type != 'cuda':
+            raise RuntimeError('FlatAdam runs on a HIP device only (no CPU fallback)')
 
     def enable_side_bucket(self, n=1):
         """n twin buckets (one per side stream); returns them as a list."""
@@ -149,7 +154,7 @@ class FlatAdam:
             allreduce_gradients(self)              # the ONE collective of a step (no-op without a process group)
         call('rv_adam_step', ptr(self.flat_param), ptr(self.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n,
              ptr(self.step_count), self.lr, self.step_size, self.gamma, self.betas[0], self.betas[1], self.eps,
-             self.grad_scale, stream())
+             self.grad_scale, ptr(ops.step_error_word(self.flat_grad.device)), stream())
         call('rv_counter_add', ptr(self.step_count), 1, stream())
         ops.invalidate_weight_cache()
 
@@ -163,13 +168,46 @@ class FlatAdam:
         return self.lr * self.gamma ** (int(self.step_count.item()) // self.step_size)
 
     def state_dict(self):
-        return {'step': self.step_count.clone(), 'exp_avg': self.exp_avg.clone(), 'exp_avg_sq': self.exp_avg_sq.clone(),
-                'lr': self.lr, 'betas': self.betas, 'eps': self.eps, 'step_size': self.step_size, 'gamma': self.gamma}
+        """The `torch.optim.Adam.state_dict()` layout (what the reference writes to last-optimizer-state.pt,
+        train_UNet_Onset_VAT.py:152): per-parameter `step` / `exp_avg` / `exp_avg_sq` keyed by parameter index, plus one
+        param group.  Checkpoints therefore interchange with the reference and with `fused_optimizer=False`.  Parameters
+        that never received a gradient have no state entry, exactly like torch (Adam skips `grad is None`)."""
+        steps = int(self.step_count.item())
+        touched = [bool(x) for x in torch.stack([self.exp_avg_sq[o:o + p.numel()].any() for p, o in zip(self.params, self.offsets)]).tolist()]
+        state = {}
+        for i, (p, off) in enumerate(zip(self.params, self.offsets)):
+            if steps and touched[i]:
+                k = p.numel()
+                state[i] = {'step': torch.tensor(float(steps)), 'exp_avg': self.exp_avg[off:off + k].view_as(p).clone(),
+                            'exp_avg_sq': self.exp_avg_sq[off:off + k].view_as(p).clone()}
+        group = {'lr': self.current_lr(), 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': 0, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'initial_lr': self.lr, 'params': list(range(len(self.params)))}
+        return {'state': state, 'param_groups': [group]}
 
     def load_state_dict(self, sd):
-        self.step_count.copy_(sd['step'])
-        self.exp_avg.copy_(sd['exp_avg'])
-        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        """Accepts the torch.optim.Adam layout (from this class, from torch.optim.Adam or from a reference run)."""
+        groups = sd['param_groups']
+        index = [i for g in groups for i in g['params']]
+        if len(index) != len(self.params):
+            raise ValueError(f'optimizer state has {len(index)} parameters, the model has {len(self.params)}')
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = 0
+        for slot, key in enumerate(index):
+            st = sd['state'].get(key)
+            if not st:
+                continue
+            p, off = self.params[slot], self.offsets[slot]
+            if tuple(st['exp_avg'].shape) != tuple(p.shape):
+                raise ValueError(f'optimizer state {key}: shape {tuple(st["exp_avg"].shape)} vs parameter {tuple(p.shape)}')
+            self.exp_avg[off:off + p.numel()].copy_(st['exp_avg'].reshape(-1))
+            self.exp_avg_sq[off:off + p.numel()].copy_(st['exp_avg_sq'].reshape(-1))
+            steps = max(steps, int(float(st['step'])))
+        self.step_count.fill_(steps)
+        g0 = groups[0]
+        self.lr = float(g0.get('initial_lr', g0['lr']))
+        self.betas, self.eps = tuple(g0['betas']), float(g0['eps'])
 
 
 def allreduce_gradients(opt):
@@ -241,8 +279,19 @@ class TrainStep:
             for k, v in self.batch_ul.items():
                 v.copy_(batch_ul[k], non_blocking=True)
 
+    def _bn_state(self):
+        """BatchNorm running statistics / counters (NOT the 17.7 MB spectrogram tables) and the dropout epoch."""
+        bufs = [b for n, b in self.model.named_buffers() if n.rsplit('.', 1)[-1] in ('running_mean', 'running_var', 'num_batches_tracked')]
+        return bufs + [ops.drop_epoch(self.opt.flat_grad.device)]
+
     def capture(self, warmup=2):
+        """Warm up (weight packing, conv autotune, allocator) and capture the step.  The warm-up passes run the real step
+        body on the first batch but must leave no trace in the training trajectory: they apply no optimiser step, and the
+        BatchNorm running statistics / `num_batches_tracked` / dropout epoch they advance are restored afterwards, so the
+        first replay sees exactly the state the reference loop would (checkpointed buffers stay comparable)."""
         self.model.train()
+        state = self._bn_state()
+        saved = [b.clone() for b in state]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -253,6 +302,8 @@ class TrainStep:
                 # tuned: from now on the step may use the second stream
                 self._dual_ready = True
         torch.cuda.current_stream().wait_stream(s)
+        for b, v in zip(state, saved):
+            b.copy_(v)
         torch.cuda.synchronize()
         # all weights are repacked by ONE launch after every optimiser step (outside the graph); the graph itself is
         # captured with a fresh cache and therefore holds no packing kernels
@@ -278,3 +329,14 @@ class TrainStep:
             self.opt.clip_grad_norm_(self.clip)
         self.pack_plan.run()                   # the next step's forward finds every packed weight fresh
         return self.loss
+
+    def check(self):
+        """Host-side health check of the steps since the last call (synchronises: call it where the host reads the loss
+        anyway).  Graph replays cannot assert on the device, so the reference's VAT NaN assert (model/UNet_onset.py:146-147)
+        and the BiLSTM time-out are device flags read here."""
+        vat = getattr(self.model, 'vat_loss', None)
+        flag = getattr(vat, 'nan_flag', None)
+        if flag is not None and int(flag.item()) != 0:
+            flag.zero_()
+            raise AssertionError('r_adv has nan, please debug tune down the XI for VAT')
+        ops.lstm_check(self.opt.flat_grad.device)

@@ -115,3 +115,28 @@ def test_device_corpus_full_size_epoch_and_sharding(dev):
     r0 = DeviceCorpus(tracks, 327680, 2, dev, rank=0, world=2)
     r1 = DeviceCorpus(tracks, 327680, 2, dev, rank=1, world=2)
     assert set(r0.paths).isdisjoint(r1.paths) and len(r0.paths) + len(r1.paths) == 9
+
+
+@pytest.mark.gpu
+def test_device_loader_shards_ranks_and_refuses_empty_epochs(dev):
+    """What cli.run_training builds for a 2-rank run: disjoint track sets per rank, rank-specific item order, and a shard
+    smaller than one batch is an error (an epoch of zero batches would make cycle(loader) spin forever)."""
+    from types import SimpleNamespace
+    from oracle import dataset as od
+    from reconvat_amd.feed import device_loader
+    tracks = od.synthetic_tracks(n=8, seed=5)
+    ds = SimpleNamespace(data=tracks, sequence_length=16384)
+    loaders = [device_loader(ds, 2, dev, rank=r, world=2, seed=42 + r) for r in range(2)]
+    seen = [set(p for b in ld for p in b['path']) for ld in loaders]
+    assert seen[0].isdisjoint(seen[1]) and len(seen[0] | seen[1]) == 8
+    with pytest.raises(ValueError, match='fewer than batch_size'):
+        device_loader(ds, 8, dev, rank=0, world=2)
+    # many batches in flight without a sync: the pinned offset ring must not be overwritten before the device read it
+    ld = device_loader(ds, 2, dev, seed=42)
+    outs = [ld.batch([i % 8, (i + 3) % 8]) for i in range(12)]
+    torch.cuda.synchronize()
+    rs = np.random.RandomState(42)
+    for i, out in enumerate(outs):
+        for j, idx in enumerate([i % 8, (i + 3) % 8]):
+            sb, _ = od.draw_begin(rs, len(tracks[idx]['audio']), 16384)
+            assert np.array_equal(out['audio'][j].cpu().numpy(), od.crop_item(tracks[idx], sb, 16384)['audio']), (i, j)

@@ -129,3 +129,118 @@ def test_data_parallel_bucket_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+DP_ADAM_WORKER = r'''
+import math, os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import reconvat_amd.train as tr
+from reconvat_amd import ops
+rank = int(sys.argv[3])
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:' + sys.argv[2], rank=rank, world_size=2)
+
+# fake backend for the two device entry points FlatAdam.step() launches (the product has no CPU path: this is the test's
+# stand-in for libreconvat_hip.so so that the HOST logic -- flat views, twin-bucket fold, the one all-reduce, grad_scale,
+# step counter, replica equality -- runs under gloo)
+def fake_call(name, *a):
+    if name == 'rv_adam_step':
+        p, g, m, v, n, step, lr0, decay_steps, gamma, b1, b2, eps, gscale, skip, _st = a
+        assert int(skip.item()) == 0
+        t = int(step.item())
+        lr = lr0 * gamma ** (t // decay_steps)
+        gg = g * gscale
+        m.mul_(b1).add_(gg, alpha=1 - b1)
+        v.mul_(b2).addcmul_(gg, gg, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** (t + 1), 1 - b2 ** (t + 1)
+        p.sub_((lr / bc1) * m / (v.sqrt() / math.sqrt(bc2) + eps))
+    elif name == 'rv_counter_add':
+        a[0].add_(a[1])
+    else:
+        raise AssertionError(name)
+tr.call, tr.ptr, tr.stream = fake_call, (lambda t: t), (lambda: None)
+tr.FlatAdam._require_hip = staticmethod(lambda dev: None)
+err = torch.zeros(1, dtype=torch.int32)
+ops.step_error_word = lambda dev: err
+
+torch.manual_seed(0)                                   # identical initial weights on every rank
+net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+ref = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+ref.load_state_dict(net.state_dict())
+ropt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+rsch = torch.optim.lr_scheduler.StepLR(ropt, step_size=2, gamma=0.5)
+opt = tr.FlatAdam(net.parameters(), lr=1e-2, step_size=2, gamma=0.5)        # data_parallel=None: auto
+twin, = opt.enable_side_bucket(1)
+calls = {'n': 0}
+real_allreduce = dist.all_reduce
+def counting(t, *a, **k):
+    calls['n'] += 1
+    return real_allreduce(t, *a, **k)
+dist.all_reduce = counting
+for it in range(5):
+    opt.zero_grad()
+    ropt.zero_grad()
+    gens = [torch.Generator().manual_seed(100 * it + r) for r in range(2)]
+    mine = None
+    per_rank = []
+    for r in range(2):
+        main = [torch.randn(p.shape, generator=gens[r]) for p in net.parameters()]
+        side = [torch.randn(p.shape, generator=gens[r]) for p in net.parameters()]
+        per_rank.append([a + b for a, b in zip(main, side)])
+        if r == rank:
+            mine = (main, side)
+    for p, g in zip(net.parameters(), mine[0]):
+        p.grad.add_(g)                                 # autograd accumulates into views of the flat bucket
+        assert p.grad.data_ptr() >= opt.flat_grad.data_ptr()
+    off = 0
+    for p, g in zip(net.parameters(), mine[1]):        # the side stream's backward lands in the twin bucket
+        twin[off:off + p.numel()].add_(g.reshape(-1)); off += p.numel()
+    opt.merge_side_grads()                             # fold BEFORE the collective
+    before = calls['n']
+    opt.step()
+    assert calls['n'] == before + 1, 'exactly ONE all-reduce per optimiser step'
+    for p, a, b in zip(ref.parameters(), *per_rank):
+        p.grad = (a + b) / 2                           # what DDP would hand torch.optim.Adam
+    ropt.step(); rsch.step()
+    for p, q in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), (it, (p - q).abs().max())
+    assert abs(opt.current_lr() - ropt.param_groups[0]['lr']) < 1e-12
+# replicas are BIT-identical (what bench.py reports as replicas_equal)
+chk = opt.flat_param.view(torch.int32).sum(dtype=torch.int64).reshape(1)
+hi, lo = chk.clone(), chk.clone()
+real_allreduce(hi, op=dist.ReduceOp.MAX); real_allreduce(lo, op=dist.ReduceOp.MIN)
+assert int(hi - lo) == 0
+# checkpoint layout == torch.optim.Adam's, and it round-trips
+sd = opt.state_dict()
+rsd = ropt.state_dict()
+assert set(sd['state']) == set(rsd['state']) and sd['param_groups'][0]['params'] == rsd['param_groups'][0]['params']
+for k in rsd['state']:
+    assert torch.allclose(sd['state'][k]['exp_avg'], rsd['state'][k]['exp_avg'], rtol=1e-5, atol=1e-8)
+    assert float(sd['state'][k]['step']) == float(rsd['state'][k]['step'])
+opt2 = tr.FlatAdam(torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3)).parameters(), lr=1.0)
+opt2.load_state_dict(rsd)                              # a torch / reference optimizer checkpoint loads
+assert int(opt2.step_count) == 5 and abs(opt2.lr - 1e-2) < 1e-12 and torch.allclose(opt2.exp_avg, opt.exp_avg, rtol=1e-5, atol=1e-8)
+# a poisoned step is not applied
+err.fill_(1)
+try:
+    opt.step()
+    raise SystemExit('poisoned step was applied')
+except AssertionError:
+    pass
+dist.barrier(); dist.destroy_process_group()
+print('ok', rank)
+'''
+
+
+def test_flat_adam_two_ranks_gloo(tmp_path):
+    """World size 2 over gloo: FlatAdam's host logic end to end on a fake device backend -- gradients accumulate into the
+    flat bucket, the side-stream twin is folded in BEFORE the one all-reduce, the mean is folded into the Adam launch,
+    StepLR follows, replicas stay bit-identical and match torch.optim.Adam on the averaged gradients; the checkpoint has
+    torch.optim.Adam's layout."""
+    script = tmp_path / 'w.py'
+    script.write_text(DP_ADAM_WORKER)
+    port = str(31500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o

@@ -464,13 +464,13 @@ def test_two_stream_graph_replays_keep_running_statistics(dev):
         m.vat_loss.noise = noise
         step = ra.TrainStep(m, opt, bl, bul, graph=graph, dual_stream=True)
         per_step = []
-        for _ in range(3 if graph else 5):       # capture = 2 warm-up steps + replays; eager runs the same number of steps
+        for _ in range(3):       # capture's warm-up passes leave no trace (BatchNorm buffers restored): replay i == eager step i
             step()
             torch.cuda.synchronize()
             per_step.append(({k: float(v) for k, v in step.losses.items()},
                              {k: v.clone() for k, v in m.state_dict().items() if 'running_mean' in k}))
         res.append(per_step)
-    eager, graph = res[0][2:], res[1]            # steps 3..5 of the eager run line up with replays 1..3
+    eager, graph = res[0], res[1]
     for (le, se), (lg, sg) in zip(eager, graph):
         for k in le:
             if 'LDS' not in k and 'r_norm' not in k:
