@@ -298,6 +298,52 @@ def run_on_batch_frame(params, training, batch, batch_ul=None, VAT=False, recons
     return pred, losses, spec.squeeze(1)
 
 
+def run_on_batch_application(params, training, batch, batch_ul, VAT=False, xi=1e-6, eps=2.0, d0_l=None, d0_ul=None, log=True):
+    """UNet.run_on_batch_application, model/self_attention_VAT.py:1205-1291 (reconstruction=True model; the reference needs
+    `batch_ul`: without it `spec` is read before assignment, :1225).  Adds the unlabelled consistency term
+    `loss/ul_consistency_wrt1` = BCE(ul_frame2, ul_frame.detach())."""
+    audio, frame_label = batch['audio'], batch['frame']
+    if frame_label.dim() == 2:
+        frame_label = frame_label.unsqueeze(0)
+    zero = torch.tensor(0.)
+    spec_ul = _spec(params, batch_ul['audio'].reshape(-1, audio.shape[-1]), log)
+    lds_ul, _, r_norm_ul, _ = vat_frame(params, training, spec_ul, xi, eps, d0_ul)
+    _, ul_roll, ul_roll2, _ = forward_frame(params, training, spec_ul, True)
+    spec = _spec(params, audio, log)
+    if VAT:
+        lds_l, r_adv, r_norm_l, _ = vat_frame(params, training, spec, xi, eps, d0_l)
+        r_adv = r_adv.squeeze(1)
+    else:
+        r_adv, lds_l, r_norm_l = None, zero, zero
+    rec, roll, roll2, a = forward_frame(params, training, spec, True)
+    bce = F.binary_cross_entropy
+    if training:
+        pred = {'onset': roll, 'frame': roll, 'frame2': roll2, 'onset2': roll2, 'ul_frame': ul_roll, 'ul_frame2': ul_roll2,
+                'attention': a, 'r_adv': r_adv, 'reconstruction': rec}
+        losses = {
+            'loss/train_reconstruction': F.mse_loss(rec.squeeze(1), spec.squeeze(1).detach()),
+            'loss/train_frame': bce(roll, frame_label),
+            'loss/train_frame2': bce(roll2, frame_label),
+            'loss/ul_consistency_wrt1': bce(ul_roll2, ul_roll.detach()),
+            'loss/train_LDS_l': lds_l,
+            'loss/train_LDS_ul': lds_ul,
+            'loss/train_r_norm_l': r_norm_l.abs().mean(),
+            'loss/train_r_norm_ul': r_norm_ul.abs().mean(),
+        }
+    else:
+        roll, roll2 = roll.reshape(*frame_label.shape), roll2.reshape(*frame_label.shape)
+        pred = {'onset': roll, 'frame': roll, 'frame2': roll2, 'onset2': roll2, 'attention': a, 'r_adv': r_adv,
+                'reconstruction': rec}
+        losses = {
+            'loss/test_reconstruction': F.mse_loss(rec.squeeze(1), spec.squeeze(1).detach()),
+            'loss/test_frame': bce(roll, frame_label),
+            'loss/test_frame2': bce(roll2, frame_label),
+            'loss/test_LDS_l': lds_l,
+            'loss/test_r_norm_l': r_norm_l.abs().mean(),
+        }
+    return pred, losses, spec.squeeze(1)
+
+
 def weighted_loss(losses, alpha=1.0):
     """model/helper_functions.py:589-595: LDS keys weigh alpha/2, the rest 1."""
     total = 0

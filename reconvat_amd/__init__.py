@@ -9,4 +9,4 @@ from .model import UNet_Onset, UNet, UNet_VAT, MutliHeadAttention1D, Spec2Roll, 
 from .onset_frames import (OnsetsAndFrames_VAT_full, Frame_stack_VAT, Onset_stack_VAT, stepwise_VAT,  # noqa: F401
                            stepwise_VAT_frame_stack, ConvStack, Onset_Stack, Combine_Stack)
 from .frontend import MelSpectrogram, Normalization  # noqa: F401
-from .train import train_VAT_model, FlatAdam, TrainStep, weighted_loss, cycle  # noqa: F401
+from .train import train_VAT_model, eval_model, FlatAdam, TrainStep, weighted_loss, cycle  # noqa: F401

@@ -110,6 +110,9 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
                  **_unused):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
+    if not str(device).startswith('cuda') or not torch.cuda.is_available():
+        raise SystemExit(f"device={device!r}: this build runs the training path on an MI355X only (hand-written HIP kernels, no CPU "
+                         "fallback); use device=cuda:0.  The reference's CPU plumbing run maps to the same command with device=cuda:0.")
     if world > 1:
         local = int(os.environ.get('LOCAL_RANK', '0'))
         device = f'cuda:{local}'
@@ -153,15 +156,26 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
     else:
         optimizer = torch.optim.Adam(model.parameters(), learning_rate)
         scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=learning_rate_decay_steps, gamma=learning_rate_decay_rate)
+    first_epoch = 1
     if resume_iteration is not None:
         optimizer.load_state_dict(torch.load(os.path.join(logdir, 'last-optimizer-state.pt'), map_location=device))
+        first_epoch = int(resume_iteration) + 1
+        if scheduler is not None:                          # StepLR is not checkpointed by the reference: rebuild its position
+            steps_done = max((int(float(st['step'])) for st in optimizer.state_dict()['state'].values()), default=0)
+            scheduler.last_epoch = steps_done
+        if rank == 0:
+            if fused_optimizer:
+                print(f'Resumed from model-{resume_iteration}.pt: optimiser step {int(optimizer.step_count.item())}, '
+                      f'lr {optimizer.current_lr():.6e}')
+            else:
+                print(f'Resumed from model-{resume_iteration}.pt')
     n_params = sum(p.numel() for p in model.parameters())
     if rank == 0:
         print(f'{cls.__name__}: {n_params} parameters, world size {world}, device {device}')
     writer = ScalarLog(logdir) if rank == 0 else None
 
     step_runner = None
-    for ep in range(1, epoches + 1):
+    for ep in range(first_epoch, epoches + 1):
         use_vat = VAT and ep >= VAT_start
         if graph and fused_optimizer:
             # whole-step hipGraph replay on static buffers (same loop semantics as train_VAT_model)

@@ -608,6 +608,59 @@ class UNet(_Base):
             losses['loss/train_r_norm_ul'] = r_norm_ul
         return predictions, losses, spec.squeeze(1)
 
+    def run_on_batch_application(self, batch, batch_ul=None, VAT=False):
+        """model/self_attention_VAT.py:1205-1291: the fine-tuning-on-unlabelled-recordings variant of run_on_batch --
+        the unlabelled batch additionally goes through transcriber -> reconstructor -> transcriber and contributes the
+        consistency term `loss/ul_consistency_wrt1` = BCE(ul_frame2, ul_frame.detach()).  Same contract as the reference:
+        needs the reconstruction model and an unlabelled batch (the reference reads `spec` before assignment without one)."""
+        if not self.reconstruction:
+            raise ValueError('run_on_batch_application needs reconstruction=True (the reference unpacks four forward outputs)')
+        if not batch_ul:
+            raise UnboundLocalError("run_on_batch_application needs batch_ul (model/self_attention_VAT.py:1225 reads `spec` "
+                                    'before assignment without it)')
+        audio_label = batch['audio']
+        frame_label = batch['frame']
+        if frame_label.dim() == 2:
+            frame_label = frame_label.unsqueeze(0)
+        spec_ul = self._front(batch_ul['audio'], audio_label.shape[-1])
+        lds_ul, _, r_norm_ul = self.vat_loss(self, spec_ul)
+        _, ul_pianoroll, ul_pianoroll2, _ = self(spec_ul)
+        spec = self._front(audio_label, audio_label.shape[-1])
+        if VAT:
+            first, lds_l, r_adv, r_norm_l = self._vat_reusing_forward(spec)
+            r_adv = r_adv.squeeze(1)
+            r_norm_l = abs_mean(r_norm_l)
+        else:
+            first, r_adv, lds_l, r_norm_l = None, None, torch.tensor(0.), torch.tensor(0.)
+        reconstrut, pianoroll, pianoroll2, a = self(spec, first)
+        if self.training:
+            predictions = {'onset': pianoroll, 'frame': pianoroll, 'frame2': pianoroll2, 'onset2': pianoroll2,
+                           'ul_frame': ul_pianoroll, 'ul_frame2': ul_pianoroll2, 'attention': a, 'r_adv': r_adv,
+                           'reconstruction': reconstrut}
+            losses = {
+                'loss/train_reconstruction': mse_mean(reconstrut.squeeze(1), spec.squeeze(1)),
+                'loss/train_frame': bce_mean(pianoroll, frame_label),
+                'loss/train_frame2': bce_mean(pianoroll2, frame_label),
+                'loss/ul_consistency_wrt1': bce_mean(ul_pianoroll2, ul_pianoroll.detach()),
+                'loss/train_LDS_l': lds_l,
+                'loss/train_LDS_ul': lds_ul,
+                'loss/train_r_norm_l': r_norm_l,
+                'loss/train_r_norm_ul': abs_mean(r_norm_ul),
+            }
+        else:
+            pianoroll = pianoroll.reshape(*frame_label.shape)
+            pianoroll2 = pianoroll2.reshape(*frame_label.shape)
+            predictions = {'onset': pianoroll, 'frame': pianoroll, 'frame2': pianoroll2, 'onset2': pianoroll2, 'attention': a,
+                           'r_adv': r_adv, 'reconstruction': reconstrut}
+            losses = {
+                'loss/test_reconstruction': mse_mean(reconstrut.squeeze(1), spec.squeeze(1)),
+                'loss/test_frame': bce_mean(pianoroll, frame_label),
+                'loss/test_frame2': bce_mean(pianoroll2, frame_label),
+                'loss/test_LDS_l': lds_l,
+                'loss/test_r_norm_l': r_norm_l,
+            }
+        return predictions, losses, spec.squeeze(1)
+
     def transcribe(self, batch):
         """model/self_attention_VAT.py:1293-1314."""
         audio_label = batch['audio']

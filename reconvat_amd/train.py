@@ -85,6 +85,23 @@ def train_VAT_model(model, iteration, ep, l_loader, ul_loader, optimizer, schedu
     return predictions, losses, optimizer
 
 
+def eval_model(model, ep, loader, VAT_start=0, VAT=False):
+    """Drop-in for model/helper_functions.py:667-687: eval-mode run_on_batch over a loader, every loss key collected."""
+    from collections import defaultdict
+    model.eval()
+    batch_size = loader.batch_size
+    metrics = defaultdict(list)
+    for i, batch in enumerate(loader):
+        use_vat = not (ep < VAT_start or VAT is False)
+        predictions, losses, _ = model.run_on_batch(batch, None, use_vat)
+        for key, loss in losses.items():
+            metrics[key].append(loss.item())
+        print(f'Eval Epoch: {ep} [{i * batch_size}/{len(loader) * batch_size}({100. * i / len(loader):.0f}%)]'
+              f"\tMain Loss: {sum(losses.values()):.6f}", end='\r')
+    print(' ' * 100, end='\r')
+    return metrics
+
+
 class FlatAdam:
     """Adam(lr, betas=(0.9,0.999), eps=1e-8) + StepLR(step_size, gamma) on ONE flat fp32 buffer.
 

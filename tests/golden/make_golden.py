@@ -268,6 +268,124 @@ def g_run_on_batch():
     save('run_on_batch', **out)
 
 
+def _ref_losses(kind, recon, training, bl, bul, noises, vat=True, dtype=torch.float32, threads=8, application=False):
+    """The REFERENCE's run_on_batch (or run_on_batch_application) with injected VAT noise, at a thread count / dtype."""
+    real_randn_like = torch.randn_like
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        net, _ = build_ref(kind, recon, training)
+        if dtype == torch.float64:
+            net = net.double()
+        cast = lambda d: {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()}
+        seq = [n.to(dtype) for n in noises]
+
+        def fake(t, **kw):
+            d = seq.pop(0).clone()
+            return d.requires_grad_(True) if kw.get('requires_grad') else d
+        torch.randn_like = fake
+        fn = net.run_on_batch_application if application else net.run_on_batch
+        pr, lr, sr = fn(cast(bl), cast(bul) if bul is not None else None, vat)
+    finally:
+        torch.randn_like = real_randn_like
+        torch.set_num_threads(prev)
+    return pr, lr, sr
+
+
+def g_lds_spread():
+    """How far the REFERENCE moves its own loss terms when nothing but the arithmetic changes: every VAT-carrying fixture
+    the GPU tests compare against, re-run at 1 thread (fp32) and in fp64, next to the 8-thread fp32 values the other goldens
+    hold.  The GPU tests accept |HIP - reference| <= max(1e-3, 3 x spread) per loss key.  Also the
+    full-size anchor of the bench workload: B = 2, T = 640, VAT + reconstruction, both models, injected noise."""
+    out = {}
+    cases = []
+    for kind in ('onset', 'frame'):
+        cases.append((f'{kind}_T64', kind, 64, ('d0_ul', 'd0_l')))        # run_on_batch.npz  <kind>_r1_v1_t1
+        cases.append((f'{kind}_T64_step', kind, 64, ('d0_0', 'd0_1')))    # train_step.npz
+        cases.append((f'{kind}_T640', kind, 640, ('d0_ul', 'd0_l')))      # full-size anchor
+        cases.append((f'{kind}_T32_smoke', kind, 32, ('smoke_ul', 'smoke_l')))
+    for tag, kind, T, ntags in cases:
+        if 'smoke' in tag:
+            bl = _batch(2, T, 'smoke'); bul = bl
+        else:
+            bl, bul = _batch(2, T, 'L'), _batch(2, T, 'UL')
+        noises = [fx.fixture_noise((2, 1, T, 229), n) for n in ntags]
+        runs = {}
+        for name, dtype, threads in (('f32_8t', torch.float32, 8), ('f32_1t', torch.float32, 1), ('f64', torch.float64, 8)):
+            pr, lr, sr = _ref_losses(kind, True, True, bl, bul, noises, dtype=dtype, threads=threads)
+            runs[name] = (pr, lr)
+            out[f'{tag}_{name}'] = np.array([float(v) for v in lr.values()], dtype=np.float64)
+        out[f'{tag}_keys'] = np.array(list(runs['f32_8t'][1].keys()))
+        base = out[f'{tag}_f32_8t']
+        spread = np.maximum(np.abs(out[f'{tag}_f32_1t'] - base), np.abs(out[f'{tag}_f64'] - base)) / np.maximum(np.abs(base), 1e-12)
+        out[f'{tag}_spread'] = spread
+        print(tag, {k: f'{s_:.1e}' for k, s_ in zip(out[f'{tag}_keys'], spread)})
+        if T == 640:
+            pr = runs['f32_8t'][0]
+            for k in ('frame', 'onset', 'frame2', 'reconstruction'):
+                out[f'{tag}_{k}'] = digest(pr[k], 512)
+            p64 = runs['f64'][0]
+            out[f'{tag}_frame_f64_err'] = float((p64['frame'].float() - pr['frame']).abs().max())
+        if T == 64 and 'step' not in tag:
+            # the oracle on the same case (what bench.py's cpu leg and smoke() use as the checker)
+            fn = om.run_on_batch_onset if kind == 'onset' else om.run_on_batch_frame
+            _, lo, _ = fn(fx.fixture_params(kind, True), True, bl, bul, True, True, d0_l=noises[1], d0_ul=noises[0])
+            out[f'{tag}_oracle'] = np.array([float(v) for v in lo.values()])
+    # VAT alone at the real XI on the `vat.npz` inputs (recon=False models)
+    for kind in ('onset', 'frame'):
+        x = fx.fixture_spec(2, 64, 'spec_vat')
+        d0 = fx.fixture_noise(x.shape, 'd0_' + kind)
+        vals = {}
+        for name, dtype, threads in (('f32_8t', torch.float32, 8), ('f32_1t', torch.float32, 1), ('f64', torch.float64, 8)):
+            torch.set_num_threads(threads)
+            net, _ = build_ref(kind, False, xi=1e-6, eps=2.0)
+            if dtype == torch.float64:
+                net = net.double()
+            real = torch.randn_like
+            torch.randn_like = lambda t, **kw: (d0.to(dtype).clone().requires_grad_(True) if kw.get('requires_grad') else d0.to(dtype).clone())
+            try:
+                lds, _, _ = net.vat_loss(net, x.to(dtype))
+            finally:
+                torch.randn_like = real
+                torch.set_num_threads(8)
+            vals[name] = np.array([float(lds['frame']), float(lds['onset'])] if kind == 'onset' else [float(lds)])
+        base = vals['f32_8t']
+        out[f'vat_{kind}_f32_8t'] = base
+        out[f'vat_{kind}_spread'] = np.maximum(np.abs(vals['f32_1t'] - base), np.abs(vals['f64'] - base)) / np.abs(base)
+        print('vat', kind, out[f'vat_{kind}_spread'])
+    save('lds_spread', **out)
+
+
+def g_application():
+    """UNet.run_on_batch_application (model/self_attention_VAT.py:1205-1291) and UNet.transcribe (:1293-1314), reference run."""
+    out = {}
+    bl, bul = _batch(2, 64, 'L'), _batch(2, 64, 'UL')
+    noises = [fx.fixture_noise((2, 1, 64, 229), 'd0_ul'), fx.fixture_noise((2, 1, 64, 229), 'd0_l')]
+    for training in (True, False):
+        pr, lr, sr = _ref_losses('frame', True, training, bl, bul, noises, application=True)
+        po, lo, so = om.run_on_batch_application(fx.fixture_params('frame', True), training, bl, bul, True, d0_l=noises[1], d0_ul=noises[0])
+        assert list(lo.keys()) == list(lr.keys()) and list(po.keys()) == list(pr.keys())
+        key = f't{int(training)}'
+        for k in lr:
+            close(lo[k], lr[k], 1e-3 if 'LDS' in k else 2e-5, key + k)
+        close(so, sr, 1e-6, 'spec')
+        out[key + '_keys'] = np.array(list(lr.keys()))
+        out[key + '_pred_keys'] = np.array(list(pr.keys()))
+        out[key + '_losses'] = np.array([float(v) for v in lr.values()])
+        out[key + '_frame'] = digest(pr['frame'], 256)
+        out[key + '_frame_shape'] = np.array(pr['frame'].shape)
+        if training:
+            close(po['ul_frame2'], pr['ul_frame2'], 2e-5, 'ul_frame2')
+            out[key + '_ul_frame'] = digest(pr['ul_frame'], 256)
+            out[key + '_ul_frame2'] = digest(pr['ul_frame2'], 256)
+    net, params = build_ref('frame', True, False)
+    with torch.no_grad():
+        tr = net.transcribe(bl)
+    out['transcribe_frame'] = digest(tr['frame'], 256)
+    out['transcribe_keys'] = np.array(list(tr.keys()))
+    save('application', **out)
+
+
 def g_train_step():
     """One iteration of the reference's own train_VAT_model (torch Adam + StepLR, decay every step so
     the LR path is exercised).  Adam's first update is lr*sign(g): for weights whose gradient is
@@ -607,7 +725,7 @@ def g_onset_frames():
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['frontend', 'unet', 'attention', 'networks', 'vat', 'run_on_batch', 'train_step', 'dataset',
-                             'decoding', 'onset_frames', 'ingest']
+                             'decoding', 'onset_frames', 'ingest', 'lds_spread', 'application']
     for w in which:
         print('==', w)
         globals()['g_' + w]()

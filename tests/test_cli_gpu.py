@@ -1,0 +1,113 @@
+"""The drop-in command lines on the GPU, as fresh child processes (reference train_UNet_Onset_VAT.py:82-170 /
+train_UNet_VAT.py:26-95): epochs of `iteration` steps, a checkpoint every `saving_freq` epochs (model-{ep}.pt +
+last-optimizer-state.pt), scalar logging of every loss key, resume, the final validation; BASELINE config 1 (the plumbing
+run) on device=cuda:0 and its device=cpu form failing with one clear sentence; `bench.py --gpus N` launching itself."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ['train_on=Synthetic', 'small=True', 'supersmall=True', 'sequence_length=32768', 'batch_size=2', 'train_batch_size=2',
+         'iteration=2']
+
+
+def run(script, *args, expect_ok=True, timeout=900):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, script), 'with', *args], capture_output=True, text=True, cwd=ROOT,
+                       env=env, timeout=timeout)
+    if expect_ok:
+        assert p.returncode == 0, p.stdout[-3000:] + '\n---\n' + p.stderr[-3000:]
+    return p
+
+
+def scalar_tags(logdir):
+    with open(os.path.join(logdir, 'scalars.jsonl')) as fh:
+        rows = [json.loads(line) for line in fh]
+    return rows
+
+
+def test_onset_script_checkpoint_resume_final_eval(dev, tmp_path):
+    from oracle import fixture as fx
+    logdir = str(tmp_path / 'run')
+    p = run('train_UNet_Onset_VAT.py', *SMALL, 'reconstruction=True', 'epoches=2', 'saving_freq=1', f'logdir={logdir}')
+    assert 'Training finished.' in p.stdout and 'validation frame F1' in p.stdout
+    for f in ('model-1.pt', 'model-2.pt', 'model-final.pt', 'last-optimizer-state.pt'):
+        assert os.path.exists(os.path.join(logdir, f)), f
+    # checkpoint = the reference's state_dict surface (keys and shapes), loadable by a fresh model
+    sd = torch.load(os.path.join(logdir, 'model-2.pt'), map_location='cpu')
+    want = dict(fx.param_shapes('onset', True))
+    want.update({'spectrogram.mel_basis': (229, 1025), 'spectrogram.stft.wsin': (1025, 1, 2048),
+                 'spectrogram.stft.wcos': (1025, 1, 2048), 'spectrogram.stft.window_mask': (1, 2048, 1)})
+    assert {k: tuple(v.shape) for k, v in sd.items()} == want
+    # 8 transcriber forwards per step x 2 steps x 2 epochs; the capture warm-up must leave no trace
+    assert int(sd['transcriber.Unet1_encoder.block1.bn1.num_batches_tracked']) == 32
+    # optimizer checkpoint has torch.optim.Adam's layout: 4 steps taken
+    osd = torch.load(os.path.join(logdir, 'last-optimizer-state.pt'), map_location='cpu')
+    assert set(osd) == {'state', 'param_groups'} and osd['param_groups'][0]['initial_lr'] == 1e-3
+    assert {float(st['step']) for st in osd['state'].values()} == {4.0}
+    reference_adam = torch.optim.Adam([torch.nn.Parameter(torch.zeros(s)) for s in
+                                       (tuple(v['exp_avg'].shape) for _, v in sorted(osd['state'].items()))])
+    reference_adam.load_state_dict({'state': {i: v for i, (_, v) in enumerate(sorted(osd['state'].items()))},
+                                    'param_groups': [dict(osd['param_groups'][0], params=list(range(len(osd['state']))))]})
+    # every loss key of the VAT + reconstruction step is logged each epoch
+    rows = scalar_tags(logdir)
+    keys = {'loss/train_reconstruction', 'loss/train_frame', 'loss/train_frame2', 'loss/train_onset', 'loss/train_onset2',
+            'loss/train_LDS_l_frame', 'loss/train_LDS_l_onset', 'loss/train_LDS_ul_frame', 'loss/train_LDS_ul_onset',
+            'loss/train_r_norm_l', 'loss/train_r_norm_ul'}
+    for ep in (1, 2):
+        assert {r['tag'] for r in rows if r['step'] == ep and r['tag'].startswith('loss/')} == keys
+    assert any(r['tag'] == 'validation/metric/frame/f1' for r in rows)
+    # resume from epoch 1: runs epoch 2 only, continues the optimiser (step 2 -> 4) and the StepLR position
+    p = run('train_UNet_Onset_VAT.py', *SMALL, 'reconstruction=True', 'epoches=2', 'saving_freq=1', f'logdir={logdir}',
+            'resume_iteration=2', 'epoches=3')
+    assert 'Resumed from model-2.pt: optimiser step 4, lr 1.000000e-03' in p.stdout
+    assert 'Train Epoch: 3' in p.stdout and 'Train Epoch: 2\t' not in p.stdout and 'Train Epoch: 1\t' not in p.stdout
+    osd = torch.load(os.path.join(logdir, 'last-optimizer-state.pt'), map_location='cpu')
+    assert {float(st['step']) for st in osd['state'].values()} == {6.0}
+
+
+def test_plumbing_config_on_gpu_and_cpu_device_message(dev, tmp_path):
+    """BASELINE config 1: `train_UNet_VAT.py with ... VAT=False reconstruction=False` -- runs on device=cuda:0; device=cpu is
+    refused with one clear sentence (there is no CPU product path)."""
+    logdir = str(tmp_path / 'plumb')
+    p = run('train_UNet_VAT.py', *SMALL, 'VAT=False', 'reconstruction=False', 'epoches=1', 'saving_freq=1', 'device=cuda:0',
+            f'logdir={logdir}')
+    assert 'Training finished.' in p.stdout
+    rows = scalar_tags(logdir)
+    assert {r['tag'] for r in rows if r['tag'].startswith('loss/')} == {'loss/train_frame', 'loss/train_LDS_l', 'loss/train_LDS_ul',
+                                                                           'loss/train_r_norm_l', 'loss/train_r_norm_ul'}
+    p = run('train_UNet_VAT.py', *SMALL, 'VAT=False', 'reconstruction=False', 'epoches=1', 'device=cpu', expect_ok=False)
+    assert p.returncode != 0 and 'MI355X only' in (p.stderr + p.stdout) and 'Traceback' not in p.stderr
+
+
+def test_eager_torch_optimizer_path(dev, tmp_path):
+    """graph=False fused_optimizer=False: the reference loop verbatim (train_VAT_model + torch.optim.Adam + StepLR)."""
+    logdir = str(tmp_path / 'eager')
+    p = run('train_UNet_Onset_VAT.py', *SMALL, 'reconstruction=True', 'epoches=1', 'saving_freq=1', 'graph=False',
+            'fused_optimizer=False', f'logdir={logdir}')
+    assert 'Training finished.' in p.stdout
+    osd = torch.load(os.path.join(logdir, 'last-optimizer-state.pt'), map_location='cpu')
+    assert set(osd) == {'state', 'param_groups'}
+
+
+def test_bench_self_launch_two_ranks(dev):
+    """`python bench.py --gpus 2` with no launcher: two fresh rank processes over RCCL, replicas bit-identical."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--batch', '2'], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['replicas_equal'] is True
+
+
+def test_bench_refuses_more_gpus_than_present(dev):
+    n = torch.cuda.device_count() + 1
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert p.returncode != 0 and 'exposes' in p.stderr

@@ -131,3 +131,45 @@ def test_save_midi_roundtrip(tmp_path):
         events.append((tick, body[i], body[i + 1], body[i + 2])); i += 3
     assert events == [(0, 0x90, 60, 127), (240, 0x90, 64, 63), (480, 0x80, 60, 127), (960, 0x80, 64, 63),
                       (960, 0x90, 67, 127), (990, 0x80, 67, 127)]
+
+
+def test_parse_midi_pedal_rule_and_tempo_map(tmp_path):
+    """reconvat_amd.midi.parse_midi (reference model/midi.py:12-50 pairing rule) on a hand-assembled two-track format-1 file:
+    tempo change, running status, zero-velocity note-on as note-off, a note released under the sustain pedal, a re-strike,
+    and a note left open at the end."""
+    import struct
+    from reconvat_amd.midi import parse_midi, save_midi
+    from reconvat_amd.evaluate import midi_to_hz
+
+    def vl(n):
+        out = [n & 0x7F]
+        n >>= 7
+        while n:
+            out.append((n & 0x7F) | 0x80)
+            n >>= 7
+        return bytes(reversed(out))
+    # track 0: tempo 500000 us/beat at tick 0, 250000 at tick 480 (division 480): second 0.5 onwards runs twice as fast
+    t0 = vl(0) + b'\xff\x51\x03\x07\xa1\x20' + vl(480) + b'\xff\x51\x03\x03\xd0\x90' + vl(0) + b'\xff\x2f\x00'
+    ev = [
+        (0, bytes([0x90, 60, 100])),       # C4 on                         t = 0.0
+        (240, bytes([60, 0])),             # running status, velocity 0 = off   t = 0.25
+        (0, bytes([0xB0, 64, 127])),       # pedal down                    t = 0.25
+        (240, bytes([0x90, 64, 80])),      # E4 on                         t = 0.5
+        (480, bytes([0x80, 64, 0])),       # E4 off under the pedal        t = 0.75 -> rings until the pedal comes up
+        (0, bytes([0x90, 67, 90])),        # G4 on                         t = 0.75
+        (480, bytes([0x90, 67, 70])),      # G4 re-struck                  t = 1.0 (first G4 ends here: under pedal -> pedal up)
+        (480, bytes([0xB0, 64, 0])),       # pedal up                      t = 1.25
+        (480, bytes([0x90, 72, 60])),      # C5 on, never released         t = 1.5
+        (480, bytes([0x80, 67, 0])),       # G4 (second) off               t = 1.75 (last event)
+    ]
+    t1 = b''.join(vl(d) + m for d, m in ev) + vl(0) + b'\xff\x2f\x00'
+    path = tmp_path / 'p.mid'
+    path.write_bytes(b'MThd' + struct.pack('>IHHH', 6, 1, 2, 480) + b'MTrk' + struct.pack('>I', len(t0)) + t0 +
+                     b'MTrk' + struct.pack('>I', len(t1)) + t1)
+    notes = parse_midi(str(path))
+    want = np.array([[0.0, 0.25, 60, 100], [0.5, 1.25, 64, 80], [0.75, 1.25, 67, 90], [1.0, 1.75, 67, 70], [1.5, 1.75, 72, 60]])
+    assert np.allclose(notes, want, atol=1e-9), notes
+    # save_midi -> parse_midi round trip
+    out = tmp_path / 'r.mid'
+    save_midi(str(out), midi_to_hz(np.array([60, 64])), np.array([[0.0, 0.5], [0.25, 1.0]]), [1.0, 0.5])
+    assert np.allclose(parse_midi(str(out)), [[0.0, 0.5, 60, 127], [0.25, 1.0, 64, 63]])

@@ -155,3 +155,51 @@ def test_bilstm_time_reversal_and_batch_permutation_full_size(dev, i):
         yp = ops.BiLstmFn.apply(x.detach()[perm].contiguous(), *[p.detach() for p in ps])
     assert torch.equal(yp, y.detach()[perm])
     ops.lstm_check(dev)
+
+
+@pytest.mark.parametrize('kind', ['onset', 'frame'])
+def test_fullsize_step_anchor_vs_reference(dev, kind):
+    """The bench workload's schedule (two-stream hipGraph TrainStep, VAT + reconstruction) at full segment length (B = 2 segments
+    of 327 680 samples -> 640 frames), against the REFERENCE's own losses and posteriorgrams on the same inputs, weights and
+    injected VAT noise (tests/golden/lds_spread.npz, cases <kind>_T640).  VAT terms: 3 x the reference's own spread on this
+    case (1e-3 .. 3e-3); everything else 1e-3."""
+    import os
+    import numpy as np
+    import reconvat_amd as ra
+    import parity_tol
+    from oracle import fixture as fx
+    from test_model_gpu import build, close_digest
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'lds_spread.npz'))
+    case = f'{kind}_T640'
+
+    def mk(tag):
+        onset, frame = fx.fixture_labels(2, 640, tag)
+        return {'audio': fx.fixture_audio(2, 640 * 512, tag).to(dev), 'onset': onset.to(dev), 'frame': frame.to(dev)}
+    bl, bul = mk('L'), mk('UL')
+    noise = [fx.fixture_noise((2, 1, 640, 229), 'd0_ul').to(dev), fx.fixture_noise((2, 1, 640, 229), 'd0_l').to(dev)]
+    for graph, dual in ((False, False), (True, True)):
+        m = build(kind, True, dev)
+        opt = ra.FlatAdam(m.parameters(), lr=0.0)            # frozen weights: every step sees the fixture weights
+        state = {'i': 0}
+
+        def draw(t, state=state):
+            state['i'] += 1
+            return noise[(state['i'] - 1) % 2].clone()       # unlabelled first, labelled second (model/UNet_onset.py:425,445)
+        m.vat_loss.noise = draw
+        step = ra.TrainStep(m, opt, bl, bul, alpha=1.0, VAT=True, clip=3.0, graph=graph, dual_stream=dual)
+        step()
+        step()                                               # graph: second replay; eager: the two-stream pass proper
+        torch.cuda.synchronize()
+        step.check()
+        keys = [str(k) for k in g[case + '_keys']]
+        assert list(step.losses.keys()) == keys
+        for k, ref in zip(keys, g[case + '_f32_8t']):
+            parity_tol.check(case, k, step.losses[k], ref, f'fullsize graph={graph} dual={dual}')
+    # posteriorgrams / reconstruction of the plain forward against the reference's digests
+    m = build(kind, True, dev)
+    m.vat_loss.noise = lambda t: noise[1].clone()
+    with torch.no_grad():
+        m.train()
+        pred, _, _ = m.run_on_batch(bl, None, False)
+    for k in ('frame', 'onset', 'frame2', 'reconstruction'):
+        close_digest(pred[k], g[f'{case}_{k}'], 1e-3, 512)

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+import parity_tol
 from conftest import rel_err
 
 pytestmark = pytest.mark.gpu
@@ -125,8 +126,11 @@ def test_vat_injected_noise(dev, kind):
     m.vat_loss.noise = lambda t: d0.clone()
     lds, r_adv, dn = m.vat_loss(m, x)
     vals = [lds['frame'].item(), lds['onset'].item()] if kind == 'onset' else [lds.item()]
-    for v, ref in zip(vals, g[f'{kind}_real_lds']):
-        assert abs(v - ref) < 1e-2 * ref, (v, ref)
+    sp = np.load(os.path.join(G, 'lds_spread.npz'))
+    assert np.allclose(sp[f'vat_{kind}_f32_8t'], g[f'{kind}_real_lds'], rtol=1e-6)      # same reference run
+    for v, ref, s in zip(vals, g[f'{kind}_real_lds'], sp[f'vat_{kind}_spread']):
+        # |hip - reference| within 3 x the reference's own 1-thread / fp64 spread on this input (tests/parity_tol.py)
+        assert abs(v - ref) <= max(1e-3, 3 * float(s)) * ref, (v, ref, float(s))
     rn = r_adv.norm(dim=-1)
     assert torch.allclose(rn, torch.full_like(rn, 2.0), rtol=1e-5)
     # the power-iteration pass must not leave gradients on the weights (reference: model.zero_grad())
@@ -158,8 +162,7 @@ def test_run_on_batch_golden(dev, kind):
                 pred, losses, spec = m.run_on_batch(bl, bul if use_ul else None, vat)
                 assert list(losses.keys()) == list(g[key + '_keys']), key
                 for (k, v), ref in zip(losses.items(), g[key + '_losses']):
-                    tol = 1e-2 if ('LDS' in k or 'r_norm' in k) else 1e-3     # VAT terms: see module docstring
-                    assert abs(float(v) - ref) <= tol * max(abs(ref), 1e-6), (key, k, float(v), ref)
+                    parity_tol.check(f'{kind}_T64', k, v, ref, 'run_on_batch:' + key)
                 close_digest(pred['frame'], g[key + '_frame'], 1e-3, 256)
                 if recon:
                     close_digest(pred['reconstruction'], g[key + '_rec'], 1e-3, 256)
@@ -188,8 +191,7 @@ def test_train_step_golden(dev, kind):
     pred, losses, _ = ra.train_VAT_model(m, 1, 1, Loader([bl]), Loader([bul]), opt, None, 3, 1, True, 0)
     assert list(losses.keys()) == list(g[f'{kind}_keys'])
     for (k, v), ref in zip(losses.items(), g[f'{kind}_losses']):
-        tol = 1e-2 if ('LDS' in k or 'r_norm' in k) else 1e-3
-        assert abs(float(v) - ref) <= tol * max(abs(ref), 1e-6), (k, float(v), ref)
+        parity_tol.check(f'{kind}_T64_step', k, v, ref, 'train_step')
     assert abs(opt.current_lr() - float(g[f'{kind}_lr'])) < 1e-12
     named = dict(m.named_parameters())
     gmax = float(g[f'{kind}_gmax'])
@@ -214,6 +216,11 @@ def test_train_step_golden(dev, kind):
     assert agree / total > 0.75, (agree, total)
 
 
+# Parameter tensors whose fp32 gradient on this fixture is a heavily cancelling sum: the listed bound replaces the generic bar
+# (each entry: measured on MI355X, see gpurun_out/grad_errors_<kind>.json; the reference's own fp32 error is of the same order).
+GRAD_EXCEPTIONS = {'onset': {}, 'frame': {}}
+
+
 @pytest.mark.parametrize('kind', ['onset', 'frame'])
 def test_backward_vs_oracle(dev, kind):
     """Full forward+backward of run_on_batch (reconstruction on, VAT off -> no chaotic term) on the GPU against
@@ -224,8 +231,9 @@ def test_backward_vs_oracle(dev, kind):
     tools/debug_grads.py), so the yardstick is the oracle evaluated in fp64 and the bar is "at least as
     accurate as the reference's fp32 path": relative L2 error <= 3e-2 per tensor.  A leaky-ReLU kink
     (|bn output| < 1 ulp) can flip on a different summation order and move a few elements of one tensor by
-    a few percent, hence L2 rather than max-abs, plus a cap on outliers.  Concretely: the GPU's L2 error vs
-    fp64 must be <= max(3x the fp32 CPU oracle's own error vs fp64, 1e-2) for every parameter tensor."""
+    a few percent, hence L2 rather than max-abs.  Concretely: the GPU's L2 error vs fp64 must be
+    <= 1.5 x the fp32 CPU oracle's own error vs fp64 + 1e-3 for EVERY parameter tensor (no outlier allowance; tensors that
+    cannot meet it are listed by name in GRAD_EXCEPTIONS with their measured bound)."""
     from oracle import fixture as fx, model as om
     bl, bul = _batches(dev)
     m = build(kind, True, dev)
@@ -246,7 +254,7 @@ def test_backward_vs_oracle(dev, kind):
     for k in lo:
         assert abs(float(losses[k]) - float(lo[k])) <= 1e-3 * max(abs(float(lo[k])), 1e-6), k
     gmax = max(float(p.grad.abs().max()) for p in p64.values() if p.grad is not None)
-    outliers = []
+    rows, violators = [], []
     for k, p in m.named_parameters():
         g64 = p64[k].grad
         if g64 is None:
@@ -255,10 +263,22 @@ def test_backward_vs_oracle(dev, kind):
         den = max(g64.norm().item(), 1e-4 * gmax * g64.numel() ** 0.5)
         e_gpu = (p.grad.cpu().double() - g64).norm().item() / den
         e_cpu = (p32[k].grad.double() - g64).norm().item() / den
-        assert e_gpu <= 5e-2, (k, e_gpu, e_cpu)
-        if e_gpu > max(3.0 * e_cpu, 1e-2):
-            outliers.append((k, e_gpu, e_cpu))      # heavily cancelling sums (e.g. a 1-element bias gradient)
-    assert len(outliers) <= 4, outliers
+        rows.append({'param': k, 'e_gpu': e_gpu, 'e_cpu32': e_cpu})
+        # bar: as accurate as the reference's own fp32 CPU path (both measured against the fp64 evaluation), with 50 % + 1e-3
+        # of slack for a different (equally valid) fp32 summation order
+        if e_gpu > 1.5 * e_cpu + 1e-3 and k not in GRAD_EXCEPTIONS.get(kind, {}):
+            violators.append((k, round(e_gpu, 5), round(e_cpu, 5)))
+        if k in GRAD_EXCEPTIONS.get(kind, {}):
+            assert e_gpu <= GRAD_EXCEPTIONS[kind][k], (k, e_gpu, e_cpu)
+    try:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+        os.makedirs(out, exist_ok=True)
+        import json
+        with open(os.path.join(out, f'grad_errors_{kind}.json'), 'w') as fh:
+            json.dump(rows, fh, indent=0)
+    except OSError:
+        pass
+    assert not violators, violators
     for k, b in m.named_buffers():
         if k.endswith(('running_mean', 'running_var')):
             assert rel_err(b, p64[k]) < 1e-4, k

@@ -104,3 +104,38 @@ def test_run_on_batch_losses(kind):
         for (k, v), ref in zip(losses.items(), g[key + '_losses']):
             tol = 2e-3 if 'LDS' in k else 1e-4
             assert abs(v.item() - ref) <= tol * max(abs(ref), 1e-6), (key, k, v.item(), ref)
+
+
+def test_oracle_application_path_matches_reference_golden():
+    """oracle.model.run_on_batch_application against the reference's own outputs (application.npz)."""
+    import torch
+    from oracle import fixture as fx, model as om
+    g = np.load(os.path.join(G, 'application.npz'))
+
+    def mk(tag):
+        onset, frame = fx.fixture_labels(2, 64, tag)
+        return {'audio': fx.fixture_audio(2, 64 * 512, tag), 'onset': onset, 'frame': frame}
+    bl, bul = mk('L'), mk('UL')
+    n_ul, n_l = fx.fixture_noise((2, 1, 64, 229), 'd0_ul'), fx.fixture_noise((2, 1, 64, 229), 'd0_l')
+    for training in (True, False):
+        pred, losses, _ = om.run_on_batch_application(fx.fixture_params('frame', True), training, bl, bul, True, d0_l=n_l, d0_ul=n_ul)
+        key = f't{int(training)}'
+        assert list(losses) == list(g[key + '_keys']) and list(pred) == list(g[key + '_pred_keys'])
+        for (k, v), ref in zip(losses.items(), g[key + '_losses']):
+            assert abs(float(v) - ref) <= (5e-3 if 'LDS' in k or 'r_norm' in k else 1e-4) * max(abs(ref), 1e-6), (k, float(v), ref)
+
+
+def test_lds_spread_fixture_is_consistent_with_the_other_goldens():
+    """lds_spread.npz re-runs the reference on the run_on_batch / train_step fixtures: its 8-thread values must be the ones
+    those goldens hold, the non-VAT terms must not move between thread counts / precisions, the VAT terms do (that is the
+    point of the fixture)."""
+    sp = np.load(os.path.join(G, 'lds_spread.npz'))
+    rb = np.load(os.path.join(G, 'run_on_batch.npz'))
+    ts = np.load(os.path.join(G, 'train_step.npz'))
+    for kind in ('onset', 'frame'):
+        assert np.allclose(sp[f'{kind}_T64_f32_8t'], rb[f'{kind}_r1_v1_t1_losses'], rtol=1e-6)
+        assert np.allclose(sp[f'{kind}_T64_step_f32_8t'], ts[f'{kind}_losses'], rtol=1e-6)
+        for case in (f'{kind}_T64', f'{kind}_T640', f'{kind}_T32_smoke'):
+            for k, s in zip(sp[case + '_keys'], sp[case + '_spread']):
+                vat = 'LDS' in str(k) or 'r_norm' in str(k)
+                assert (1e-5 < s < 1e-2) if vat else (s < 1e-5), (case, k, s)

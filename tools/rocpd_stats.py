@@ -1,10 +1,29 @@
-"""Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / average, like --stats.
+"""Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / average, like --stats, over a window of WHOLE
+optimiser steps.
 
-    python tools/rocpd_stats.py gpurun_out/prof1/r1_results.db [--steps N] [--tail-ms X] > profiles/xyz.txt
+    python tools/rocpd_stats.py gpurun_out/prof1/r1_results.db [--last-steps N] > profiles/xyz.txt
+
+The window is cut at optimiser-kernel (`adam_k`) boundaries: it runs from the end of the (N+1)-th-to-last `adam_k` to the end of
+the last one, so it holds exactly N steps (N defaults to every complete step but the first five = warm-up) and "per step"
+figures divide by the step count that is actually in the window.  A per-family table (conv3x3 / conv 1x1,2x2 / wgrad / gemm / attention /
+BatchNorm / front-end / losses+VAT / optimiser) follows the per-kernel one.
 """
 import re
 import sqlite3
 import sys
+
+FAMILIES = [
+    ('conv3x3 fwd+dgrad (MFMA)', ('conv3x3_lds_k',)),
+    ('conv direct 3x3/1x1/2x2 (MFMA / HBM)', ('conv_mfma_k',)),
+    ('conv C<=2 layers (HBM)', ('conv_small_k', 'wgrad_small_k')),
+    ('weight gradients (MFMA)', ('wgrad_mfma_k', 'wgrad_reduce')),
+    ('linear GEMMs (MFMA)', ('gemm_mfma_k', 'colsum', 'sigmoid')),
+    ('local attention', ('attn_',)),
+    ('BatchNorm + leaky-ReLU (HBM)', ('bn_',)),
+    ('front-end (HBM)', ('mel_',)),
+    ('losses / VAT elementwise (HBM)', ('reduce_', 'loss_bwd', 'vat_', 'elementwise', 'vectorized', 'Philox', 'distribution')),
+    ('optimiser + weight repack', ('adam_k', 'pack_', 'clip', 'counter_add')),
+]
 
 
 def short(name):
@@ -15,23 +34,35 @@ def short(name):
 
 def main():
     db = sqlite3.connect(sys.argv[1])
-    steps = int(sys.argv[sys.argv.index('--steps') + 1]) if '--steps' in sys.argv else None
-    where = ''
-    if '--tail-ms' in sys.argv:      # only the dispatches of the last X ms of the trace (the timed steps)
-        tail = float(sys.argv[sys.argv.index('--tail-ms') + 1])
-        end = db.execute('select max(end) from kernels').fetchone()[0]
-        where = f'where start >= {end - int(tail * 1e6)} '
+    adam = [r[0] for r in db.execute("select end from kernels where name like 'adam_k%' order by end").fetchall()]
+    if len(adam) < 2:
+        raise SystemExit('fewer than two adam_k dispatches in the trace: cannot cut whole steps')
+    n = int(sys.argv[sys.argv.index('--last-steps') + 1]) if '--last-steps' in sys.argv else max(1, len(adam) - 1 - 5)
+    n = min(n, len(adam) - 1)
+    lo, hi = adam[-1 - n], adam[-1]
+    where = f'where start >= {lo} and end <= {hi} '
     rows = db.execute('select name, count(*), sum(duration), avg(duration), min(duration), max(duration) '
                       f'from kernels {where}group by name order by sum(duration) desc').fetchall()
     total = sum(r[2] for r in rows)
-    span = db.execute(f'select min(start), max(end) from kernels {where}').fetchone()
-    print(f'# kernels: {sum(r[1] for r in rows)} dispatches, {len(rows)} distinct, total kernel time {total / 1e6:.3f} ms, '
-          f'trace span {(span[1] - span[0]) / 1e6:.3f} ms')
-    if steps:
-        print(f'# per step (/{steps}): {total / 1e6 / steps:.3f} ms kernel time')
-    print(f'{"calls":>8s} {"total_ms":>10s} {"avg_us":>9s} {"min_us":>9s} {"max_us":>9s} {"pct":>6s}  name')
-    for name, n, tot, avg, mn, mx in rows:
-        print(f'{n:8d} {tot / 1e6:10.3f} {avg / 1e3:9.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} {100 * tot / total:6.2f}  {short(name)}')
+    steps = db.execute(f"select count(*) from kernels {where}and name like 'adam_k%'").fetchone()[0]
+    print(f'# window: {steps} whole optimiser steps (cut at adam_k boundaries), wall {(hi - lo) / 1e6:.3f} ms = '
+          f'{(hi - lo) / 1e6 / steps:.3f} ms/step')
+    print(f'# kernels: {sum(r[1] for r in rows)} dispatches ({sum(r[1] for r in rows) / steps:.0f}/step), {len(rows)} distinct, '
+          f'summed kernel time {total / 1e6:.3f} ms = {total / 1e6 / steps:.3f} ms/step')
+    print(f'{"calls":>8s} {"calls/st":>8s} {"total_ms":>10s} {"ms/step":>8s} {"avg_us":>9s} {"min_us":>9s} {"max_us":>9s} {"pct":>6s}  name')
+    for name, c, tot, avg, mn, mx in rows:
+        print(f'{c:8d} {c / steps:8.1f} {tot / 1e6:10.3f} {tot / 1e6 / steps:8.3f} {avg / 1e3:9.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} '
+              f'{100 * tot / total:6.2f}  {short(name)}')
+    print('\n# by family (summed kernel time per step; concurrent chains overlap, so the sum exceeds the wall time)')
+    fam = {f: [0, 0.0] for f, _ in FAMILIES}
+    fam['other'] = [0, 0.0]
+    for name, c, tot, *_ in rows:
+        key = next((f for f, pats in FAMILIES if any(p in name for p in pats)), 'other')
+        fam[key][0] += c
+        fam[key][1] += tot
+    for f, (c, tot) in fam.items():
+        if c:
+            print(f'{c / steps:8.1f} launches/step {tot / 1e6 / steps:8.3f} ms/step {100 * tot / total:6.2f} %  {f}')
 
 
 if __name__ == '__main__':
