@@ -699,33 +699,45 @@ __global__ __launch_bounds__(256) void conv_small_k(SmallArgs a) {
         float acc[CPT];
 #pragma unroll
         for (int co = 0; co < CPT; ++co) acc[co] = bias[co];
+        // Branch-free taps: an out-of-image tap reads a clamped (valid) address and its values are zeroed by a select.
+        // With a divergent `continue` per tap the compiler waits for every tap's loads before it issues the next ones --
+        // nine dependent L2 round trips per pixel, which is what bounded these layers at 1.2-2.3 TB/s; straight-line code
+        // lets it put a whole row of taps (or all nine) in flight at once.
+        const float* centre = a.in + (((long)b * a.H + oy * S) * a.W + ox * S) * a.in_ld;
 #pragma unroll
-        for (int ky = 0; ky < KH; ++ky)
+        for (int ky = 0; ky < KH; ++ky) {
+            float xin[KW][CIN];
 #pragma unroll
             for (int kx = 0; kx < KW; ++kx) {
-                int iy = oy * S - P + ky, ix = ox * S - P + kx;
-                if ((unsigned)iy >= (unsigned)a.H || (unsigned)ix >= (unsigned)a.W) continue;
-                const float* src = a.in + (((long)b * a.H + iy) * a.W + ix) * a.in_ld;
-                const float* w = a.wplain + (ky * KW + kx) * CIN * COUT + c0;
-                float xin[CIN];
+                const int dy = ky - P, dx = kx - P;
+                const int iy = oy * S + dy, ix = ox * S + dx;
+                const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const int cy = min(max(iy, 0), a.H - 1) - oy * S, cx = min(max(ix, 0), a.W - 1) - ox * S;
+                const float* src = centre + (cy * a.W + cx) * a.in_ld;
                 if constexpr (CIN % 4 == 0) {
 #pragma unroll
                     for (int c = 0; c < CIN; c += 4) {
-                        f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
-                        xin[c] = v[0]; xin[c + 1] = v[1]; xin[c + 2] = v[2]; xin[c + 3] = v[3];
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+                        xin[kx][c] = ok ? v[0] : 0.f; xin[kx][c + 1] = ok ? v[1] : 0.f;
+                        xin[kx][c + 2] = ok ? v[2] : 0.f; xin[kx][c + 3] = ok ? v[3] : 0.f;
                     }
                 } else {
 #pragma unroll
-                    for (int c = 0; c < CIN; ++c) xin[c] = src[c];
+                    for (int c = 0; c < CIN; ++c) { const float v = src[c]; xin[kx][c] = ok ? v : 0.f; }
                 }
+            }
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                const float* w = a.wplain + (ky * KW + kx) * CIN * COUT + c0;
 #pragma unroll
                 for (int c = 0; c < CIN; ++c)
 #pragma unroll
                     for (int co = 0; co < CPT; ++co) {
                         const float wv = WREG ? wreg[((ky * KW + kx) * CIN + c) * CPT + co] : w[c * COUT + co];
-                        acc[co] = fmaf(xin[c], wv, acc[co]);
+                        acc[co] = fmaf(xin[kx][c], wv, acc[co]);
                     }
             }
+        }
         float* o = a.out + (long)p * a.out_ld + c0;
         if (a.accumulate) {
 #pragma unroll

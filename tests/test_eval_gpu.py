@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+import parity_tol
 from conftest import rel_err
 
 pytestmark = pytest.mark.gpu
@@ -19,7 +20,7 @@ def build(kind, recon, dev, training=False):
     import reconvat_amd as ra
     from oracle import fixture as fx
     cls = ra.UNet_Onset if kind == 'onset' else ra.UNet
-    m = cls(*DS, log=True, reconstruction=recon, mode='imagewise', spec='Mel')
+    m = cls(*DS, log=True, reconstruction=recon, mode='imagewise', spec='Mel', XI=1e-6, eps=2.0)
     m.load_state_dict(fx.fixture_params(kind, recon))
     return m.to(dev).train(training)
 
@@ -100,8 +101,7 @@ def test_run_on_batch_application_golden(dev):
         key = f't{int(training)}'
         assert list(losses.keys()) == list(g[key + '_keys']) and list(pred.keys()) == list(g[key + '_pred_keys'])
         for (k, v), ref in zip(losses.items(), g[key + '_losses']):
-            tol = 3e-3 if 'LDS' in k else 1e-3
-            assert abs(float(v) - ref) <= tol * max(abs(ref), 1e-6), (key, k, float(v), ref)
+            parity_tol.check('frame_T64', k, v.detach(), ref, 'application:' + key)
         assert tuple(pred['frame'].shape) == tuple(g[key + '_frame_shape'])
         close_digest(pred['frame'], g[key + '_frame'], 1e-3, 256)
         if training:

