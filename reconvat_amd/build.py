@@ -52,5 +52,26 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_ablation():
+    """Timing-experiment build (wrong results by design): conv.hip with -DRV_ABLATION so that RV_ABLATE=bits switches parts of
+    the conv / wgrad kernels off.  Lives next to the real library as libreconvat_hip_abl.so; load it with
+    RECONVAT_HIP_LIB=reconvat_amd/libreconvat_hip_abl.so (tools only -- never the product default)."""
+    build()
+    obj = os.path.join(CSRC, 'conv_abl.o')
+    r = subprocess.run([HIPCC] + FLAGS + ['-DRV_ABLATION', '-c', os.path.join(CSRC, 'conv.hip'), '-o', obj], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr)
+    objs = [os.path.join(CSRC, os.path.splitext(s)[0] + '.o') for s in SOURCES if s != 'conv.hip'] + [obj]
+    lib = os.path.join(HERE, 'libreconvat_hip_abl.so')
+    r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', lib], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr)
+    print('built', lib)
+    return lib
+
+
 if __name__ == '__main__':
-    build(force='--force' in sys.argv, verbose=True)
+    if '--ablation' in sys.argv:
+        build_ablation()
+    else:
+        build(force='--force' in sys.argv, verbose=True)

@@ -317,6 +317,14 @@ __device__ __forceinline__ void lds_read(f32x4& v, unsigned addr) {
 __device__ __forceinline__ void lds_read(f32x2& v, unsigned addr) {
     asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory");
 }
+__device__ __forceinline__ void lds_read(float& v, unsigned addr) {
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+}
+// wait until at most N of this wave's LDS operations are outstanding (the counter is 4 bits wide: N is clamped to 15, which
+// only makes the wait stricter)
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N > 15 ? 15 : N) : "memory");
+}
 
 template <int R, int NT, int MTW, int NW>
 __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
@@ -667,6 +675,75 @@ __host__ __device__ constexpr int small_cpt(int cin, int cout, int taps) {
     return cout < 4 ? cout : ((cin <= 2 && taps > 1) ? cout : 4);
 }
 
+// 3x3 (stride 1, pad 1) convolution from CIN in {8, 16} channels down to COUT <= 2 (the last decoder layer 8 -> 2, the
+// reconstructor's 16 -> 1 head layer and the input-gradients of the first layers): pure bandwidth kernels whose cost is the
+// number of CACHE LINES a wave-instruction touches, not its bytes.  With one thread per pixel every 16-byte load of a wave
+// lands in a different line (pixel stride 32-64 B: 64 lines per instruction, each line touched by CIN/4 instructions per
+// tap) and the vector L1's tag rate bounds the kernel at 1.2-1.7 TB/s.  Here the CIN/4 channel quads of a pixel sit on
+// NEIGHBOURING lanes: a wave-instruction reads 1 KiB of contiguous memory (8 lines), every lane keeps the 9*4*COUT weights of
+// its quad in registers, and the per-pixel sum is two xor-shuffles over the quad lanes.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv_narrow_out_k(SmallArgs a) {
+    constexpr int LPP = CIN / 4;                     // lanes per pixel
+    static_assert(LPP == 2 || LPP == 4, "quad lanes must divide the wave");
+    const unsigned tstride = gridDim.x * blockDim.x;          // a multiple of LPP: a lane's quad never changes
+    unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned tend = (unsigned)a.npix * LPP;
+    const int q = (int)(t % LPP);
+    float w[9][4][COUT];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) w[tap][c][co] = a.wplain[(tap * CIN + 4 * q + c) * COUT + co];
+    float bias[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) bias[co] = a.bias ? a.bias[co] : 0.f;
+    // the wave's tail lanes stay in the loop (the shuffles need the whole quad): they compute pixel npix-1 and do not store
+    const unsigned tlast = (tend + 63) & ~63u;
+    for (; t < tlast; t += tstride) {
+        const bool live = t < tend;
+        const unsigned p = live ? t / LPP : (unsigned)a.npix - 1;
+        const int b = (int)fastdiv(p, a.fd_plane);
+        const unsigned rem = p - (unsigned)b * (unsigned)(a.Ho * a.Wo);
+        const int oy = (int)fastdiv(rem, a.fd_wo), ox = (int)rem - oy * a.Wo;
+        const float* centre = a.in + (((long)b * a.H + oy) * a.W + ox) * a.in_ld + 4 * q;
+        float acc[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+        f32x4 x[9];
+        bool ok[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {                   // all nine loads in flight; out-of-image taps read a clamped address
+            const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+            ok[tap] = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const int cy = min(max(iy, 0), a.H - 1) - oy, cx = min(max(ix, 0), a.W - 1) - ox;
+            x[tap] = *reinterpret_cast<const f32x4*>(centre + (cy * a.W + cx) * a.in_ld);
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float v = ok[tap] ? x[tap][c] : 0.f;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(v, w[tap][c][co], acc[co]);
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+#pragma unroll
+            for (int d = 1; d < LPP; d <<= 1) acc[co] += __shfl_xor(acc[co], d, 64);
+            acc[co] += bias[co];
+        }
+        if (live && q == 0) {
+            float* o = a.out + (long)p * a.out_ld;
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) o[co] = a.accumulate ? o[co] + acc[co] : acc[co];
+        }
+    }
+}
+
 template <int CIN, int COUT, int KH, int KW, int S, int P>
 __global__ __launch_bounds__(256) void conv_small_k(SmallArgs a) {
     constexpr int CPT = small_cpt(CIN, COUT, KH * KW);   // output channels per thread
@@ -822,6 +899,9 @@ struct WgradArgs {
     float* part; long pstride;               // partial sums [nparts][taps*Ca*Cb (+Cb)]
     int rows_per_wave, nparts, ngb;          // ngb = number of b-groups
     int want_bias;
+    int ablate;                              // -DRV_ABLATION builds only (timing experiments, wrong results): 1 no MFMAs,
+                                             // 2 no fragment reads, 4 stage the first row only, 8 no row barriers
+    unsigned long long* dbg;                 // -DRV_ABLATION: s_memtime stamps of workgroup (0,0) / wave 0 (RV_DBG_PTR)
     FastDiv fd_vplane, fd_wv;                // divide by Hv*Wv, by Wv (small-channel kernel)
 };
 
@@ -876,9 +956,20 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
 #pragma unroll
     for (int y = 0; y < TB; ++y) accbs[y] = 0.f;
 
+#ifdef RV_ABLATION
+    const bool stamp = a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+    unsigned long long t_wait = 0, t_comp = 0, t_mark = 0;
+#define TS(k) do { if (stamp) a.dbg[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TS(k) do { } while (0)
+#endif
+    TS(0);
+    if (ABL(a) & 64) return;
+    if (!(ABL(a) & 16))
     for (int k = tid; k < stage_floats; k += NTHR) smem[k] = 0.f;   // padding / unused channels stay zero
     __syncthreads();
 
+    TS(1);
     const int ca_valid = min(CA, a.Ca - a0), cb_valid = min(CB, a.Cb - b0);
     const int npxu = min(a.Wu, UP - P);
 
@@ -930,46 +1021,112 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
     for (int row = row0; row < row1; ++row) {
         const int b = row / a.Hv, y = row - b * a.Hv;
         const int vb = row & 1;
-        if (!prefetched) {
-            __syncthreads();                                  // nobody still reads the ring
+#ifdef RV_ABLATION
+        if (stamp) t_mark = __builtin_amdgcn_s_memtime();
+#endif
+        if (!prefetched && !((ABL(a) & 4) && row > row0)) {
+            if (!(ABL(a) & 8)) __syncthreads();               // nobody still reads the ring
             stage_full(b, y, vb);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                      // row (b, y) is resident for every wave
+        if (!(ABL(a) & 8)) __syncthreads();                   // row (b, y) is resident for every wave
         prefetched = (row + 1 < row1) && (y + 1 < a.Hv);
-        if (prefetched) stage_next(b, y + 1, vb ^ 1);         // DMA under the MFMAs below
+#ifdef RV_ABLATION
+        if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_wait += t - t_mark; t_mark = t; if (row == row0) a.dbg[2] = t; }
+#endif
+        if (prefetched && !(ABL(a) & 4)) stage_next(b, y + 1, vb ^ 1);         // DMA under the MFMAs below
+#ifdef RV_ABLATION
+        if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); a.dbg[8] += t - t_mark; t_mark = t; }
+#endif
         int slot_of[KH];
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky) slot_of[ky] = slot_of_row(y, ky);
         const float* vrow = vbuf + vb * Wv4 * CB;
-        for (int x0 = xg * 4; x0 < Wv4; x0 += 4 * NXG) {
+        // k-steps of 4 pixels, software-pipelined in the source: the fragments of step s+1 are loaded (plain LDS loads the
+        // compiler counts) into the other register set while step s is multiplied, and sched_group_barrier pins an
+        // MFMA / ds_read interleave.  Left alone, the compiler put every ds_read directly in front of the MFMAs that consume
+        // it with s_waitcnt lgkmcnt(0) in between -- six exposed LDS round trips per 18 MFMAs, SQ_WAIT_ANY 33 %, matrix pipe
+        // busy 49 % (profiles/r02_pmc_wgrad.txt).
+        float vfA[TB], ufA[TAPS][TAW], vfB[TB], ufB[TAPS][TAW];
+        auto ld = [&](float (&vf)[TB], float (&uf)[TAPS][TAW], const int x0) {
             const int x = x0 + g;
-            float vf[TB];
+            if (ABL(a) & 2) {
+#pragma unroll
+                for (int tb = 0; tb < TB; ++tb) vf[tb] = (float)x0;
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                    for (int ta = 0; ta < TAW; ++ta) uf[t][ta] = (float)(x0 + t);
+                return;
+            }
 #pragma unroll
             for (int tb = 0; tb < TB; ++tb) vf[tb] = vrow[x * CB + tb * 16 + i];
 #pragma unroll
             for (int ky = 0; ky < KH; ++ky) {
                 const float* ur = ubuf + slot_of[ky] * UP * CA + (S * x) * CA + i;
 #pragma unroll
-                for (int kx = 0; kx < KW; ++kx) {
+                for (int kx = 0; kx < KW; ++kx)
 #pragma unroll
-                    for (int ta = 0; ta < TAW; ++ta) {
-                        const float uf = ur[kx * CA + (hp * TAW + ta) * 16];
-#pragma unroll
-                        for (int tb = 0; tb < TB; ++tb)
-                            acc[ky * KW + kx][ta][tb] =
-                                __builtin_amdgcn_mfma_f32_16x16x4f32(uf, vf[tb], acc[ky * KW + kx][ta][tb], 0, 0, 0);
-                    }
-                }
+                    for (int ta = 0; ta < TAW; ++ta) uf[ky * KW + kx][ta] = ur[kx * CA + (hp * TAW + ta) * 16];
             }
+        };
+        auto mm = [&](const float (&vf)[TB], const float (&uf)[TAPS][TAW]) {
+            if (ABL(a) & 1) {                                 // keep the operands live without the matrix pipe
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                    for (int ta = 0; ta < TAW; ++ta) acc[t][ta][0][0] += uf[t][ta] * vf[0] + vf[TB - 1];
+                return;
+            }
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                for (int ta = 0; ta < TAW; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < TB; ++tb)
+                        acc[t][ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[t][ta], vf[tb], acc[t][ta][tb], 0, 0, 0);
             if (do_bias) {
                 // bias gradient on the VALU (co-issues with the MFMAs): only the ga == 0 workgroups carry it, and as two
                 // extra MFMAs per step it made exactly those workgroups -- hence the whole launch -- ~10 % longer
 #pragma unroll
                 for (int tb = 0; tb < TB; ++tb) accbs[tb] += vf[tb];
             }
+        };
+        auto interleave = [&]() {                             // one ds_read after each of the first MFMAs of the block
+#pragma unroll
+            for (int k = 0; k < TAPS * TAW * TB; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (k < TB + TAPS * TAW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        };
+        constexpr int DX = 4 * NXG;
+        // the prefetch of a step past the end of the row reads the row's last (valid, staged) k-step instead: no branch
+        // around the loads, so each [prefetch ; multiply] pair stays one straight-line block the scheduler can interleave
+        const int xlast = Wv4 - 4;
+        int x0 = xg * 4;
+        if (x0 < Wv4) {
+            ld(vfA, ufA, x0);
+            for (;;) {
+                const int x1 = x0 + DX;
+                ld(vfB, ufB, min(x1, xlast));
+                mm(vfA, ufA);
+                interleave();
+                if (x1 >= Wv4) break;
+                x0 = x1 + DX;
+                ld(vfA, ufA, min(x0, xlast));
+                mm(vfB, ufB);
+                interleave();
+                if (x0 >= Wv4) break;
+            }
         }
+#ifdef RV_ABLATION
+        if (stamp) t_comp += __builtin_amdgcn_s_memtime() - t_mark;
+#endif
     }
+#ifdef RV_ABLATION
+    if (stamp) { a.dbg[6] = t_wait; a.dbg[7] = t_comp; }
+#endif
+    TS(3);
     if (do_bias) {                                           // pixel lanes g -> every lane of a channel holds the sum
 #pragma unroll
         for (int tb = 0; tb < TB; ++tb) {
@@ -979,6 +1136,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
             accb[tb] = (f32x4){sb, sb, sb, sb};
         }
     }
+    if (ABL(a) & 32) { if (acc[0][0][0][0] == 123.456f) a.part[0] = accbs[0]; return; }
     // fold the x groups through LDS (x group w > 0 publishes, x group 0 of the same half accumulates)
     constexpr int NACC = (TAPS * TAW * TB + TB) * 4;
     float* fold = smem + hp * NACC * 64;
@@ -1016,6 +1174,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
                 for (int r = 0; r < 4; ++r) accb[tb][r] += fold[(q++) * 64 + lane];
         }
     }
+    TS(4);
     if (xg != 0) return;
     // D[row = a_local = 4g+r][col = b_local = i]
     float* dst = a.part + (long)blockIdx.x * a.pstride;
@@ -1039,6 +1198,8 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
             if (bb < a.Cb) dst[(long)TAPS * a.Ca * a.Cb + bb] = accb[tb][0];
         }
     }
+    TS(5);
+#undef TS
 }
 
 // VALU version for tiny channel counts (Ca*Cb*taps <= 144).  One wave = one partial.  The wider channel dimension is
@@ -1519,6 +1680,17 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
         RV_LAUNCH_CHECK("conv_small");                                                           \
         return RV_OK;                                                                            \
     }
+#define RV_NARROW(ci, co)                                                                         \
+    if (mode == 0 && Cin == ci && Cout == co && (in_ld & 3) == 0 && ((((uintptr_t)in) & 15) == 0)) { \
+        RV_CHECK_ARG(s.npix < (1L << 28), "rv_conv_fwd: more than 2^28 pixels");                \
+        long nb = cdiv(s.npix * (ci / 4), 256);                                                  \
+        if (nb > 4096) nb = 4096;                                                                \
+        hipLaunchKernelGGL((conv_narrow_out_k<ci, co>), dim3((unsigned)nb), blk, 0, st, s);      \
+        RV_LAUNCH_CHECK("conv_narrow_out");                                                      \
+        return RV_OK;                                                                            \
+    }
+        RV_NARROW(16, 1) RV_NARROW(8, 2) RV_NARROW(8, 1)
+#undef RV_NARROW
         if (mode == 0) {
             RV_SMALL(1, 16, 3, 3, 1, 1) RV_SMALL(16, 1, 3, 3, 1, 1)
             RV_SMALL(8, 2, 3, 3, 1, 1)  RV_SMALL(2, 8, 3, 3, 1, 1)
@@ -1693,6 +1865,8 @@ static int conv_wgrad_impl(int mode, const float* U, int u_ld, int Hu, int Wu, i
     WgradArgs a;
     a.U = U; a.u_ld = u_ld; a.Hu = Hu; a.Wu = Wu; a.Ca = Ca; a.V = V; a.v_ld = v_ld; a.Hv = Hv; a.Wv = Wv; a.Cb = Cb;
     a.B = B; a.want_bias = dbias != nullptr;
+    a.ablate = getenv("RV_ABLATE") ? atoi(getenv("RV_ABLATE")) : 0;
+    a.dbg = getenv("RV_DBG_PTR") ? (unsigned long long*)strtoull(getenv("RV_DBG_PTR"), nullptr, 10) : nullptr;
     a.pstride = (long)taps * Ca * Cb + Cb;
     a.fd_vplane = fastdiv_make((unsigned)(Hv * Wv)); a.fd_wv = fastdiv_make((unsigned)Wv);
     RV_CHECK_ARG((long)B * Hv * Wv < (1L << 31), "rv_conv_wgrad: more than 2^31 pixels");
