@@ -11,6 +11,7 @@
 // The MFMA is issued as D^T = B^T A^T so that an accumulator lane holds four consecutive n of one m
 // (16-byte stores along the contiguous dimension of C).
 #include "common.h"
+#include <stdlib.h>
 
 #define GBM 64
 #define GBN 64

@@ -270,6 +270,24 @@ def _pack_rel(rel, f):
     return out
 
 
+def _lin_t(w2d):
+    """Contiguous transposed copy [K, N] of a row-major linear weight view w2d [N, K] (cached per weight version; part of
+    the PackPlan table).  The input-gradient GEMM dY @ W then reads BOTH operands along their contiguous dimension
+    (rv_gemm's LDS-DMA kernel) instead of gathering W column-wise."""
+    n, k = w2d.shape
+    assert w2d.stride(1) == 1 and w2d.stride(0) == k
+    key = (w2d.data_ptr(), 'lin', 'T', n, k)
+    tag = (_EPOCH[0], w2d._version, (n, k))
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1].view(k, n)
+    args = (1, k, n, 1, k, 0, 0, 1)              # out[kk*n + nn] = w[kk + nn*k]
+    out = torch.empty(k * n, device=w2d.device, dtype=torch.float32)
+    call('rv_pack_weights', ptr(w2d), ptr(out), *args, stream())
+    _pack_cache[key] = (tag, out, w2d, args)
+    return out.view(k, n)
+
+
 class PackPlan:
     """Every packed weight currently in the cache, repacked by ONE kernel launch (rv_pack_table_run).  Build it after
     a warm-up step has populated the cache, call ``run()`` right after each optimiser step: the cache entries are
@@ -804,7 +822,7 @@ class LinearFn(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((m, k), device=dy.device, dtype=torch.float32)
-            gemm(dz, w, dx)
+            gemm(dz, _lin_t(w).t(), dx)
         bias_done = False
         if ctx.needs_input_grad[1]:
             if ctx.needs_input_grad[2]:
@@ -851,8 +869,8 @@ class OnsetHeadsFn(Function):
         if ctx.needs_input_grad[0]:
             dy = torch.empty_like(y)
             d2 = dy.view(m, nb, 2)
-            gemm(dzo, wo, d2[..., 0])
-            gemm(dzf, wf, d2[..., 1])
+            gemm(dzo, _lin_t(wo).t(), d2[..., 0])
+            gemm(dzf, _lin_t(wf).t(), d2[..., 1])
         pwo, pbo, pwf, pbf = ctx.params
         if ctx.needs_input_grad[1]:
             dwo, done = _param_wgrad(dzo.t(), y2[..., 0], pwo, _splitk_for(88, nb, m), pbo)
@@ -937,11 +955,11 @@ class LocalAttnFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x2)
             if fused:
-                gemm(dqkv, torch.as_strided(wk, (3 * f, fin), (fin, 1)), dx, splitk=_splitk_for(m, fin, 3 * f))
+                gemm(dqkv, _lin_t(torch.as_strided(wk, (3 * f, fin), (fin, 1))).t(), dx, splitk=_splitk_for(m, fin, 3 * f))
             else:
-                gemm(dq, wq, dx)
-                gemm(dk, wk, dx, accumulate=True)
-                gemm(dv, wv, dx, accumulate=True)
+                gemm(dq, _lin_t(wq).t(), dx)
+                gemm(dk, _lin_t(wk).t(), dx, accumulate=True)
+                gemm(dv, _lin_t(wv).t(), dx, accumulate=True)
             dx = dx.view(bb, l, -1)
         pwq, pwk, pwv, prel = ctx.params
         if ctx.needs_input_grad[1]:

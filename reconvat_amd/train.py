@@ -115,8 +115,14 @@ class FlatAdam:
         assert self.params, 'no trainable parameters'
         dev = self.params[0].device
         self._require_hip(dev)
-        n = sum(p.numel() for p in self.params)
-        self.flat_param = torch.empty(n, device=dev, dtype=torch.float32)
+        # every parameter starts on a 16-byte boundary of the flat buffers: the GEMM / conv kernels take 16-byte (LDS-DMA,
+        # dwordx4) loads only from aligned rows, and a weight that follows a 229- or 88-element bias would otherwise sit
+        # at an odd offset and fall back to scalar loads.  The pad elements stay zero (zero gradient, zero moments).
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 3) & ~3
+        self.flat_param = torch.zeros(n, device=dev, dtype=torch.float32)
         self.flat_grad = torch.zeros(n, device=dev, dtype=torch.float32)
         self.flat_grad_side = None            # twin bucket of the side stream (TrainStep two-stream mode)
         self.flat_grad_sides = []             # ... all twins (one per side stream in use)
@@ -124,15 +130,11 @@ class FlatAdam:
         self.exp_avg_sq = torch.zeros(n, device=dev, dtype=torch.float32)
         self.step_count = torch.zeros((), device=dev, dtype=torch.int64)
         self.norm_buf = torch.zeros((), device=dev, dtype=torch.float32)
-        off = 0
-        self.offsets = []
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             k = p.numel()
             self.flat_param[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat_param[off:off + k].view_as(p.data)
             p.grad = self.flat_grad[off:off + k].view_as(p.data)
-            self.offsets.append(off)
-            off += k
         self.n = n
         self.lr, self.betas, self.eps, self.step_size, self.gamma = lr, betas, eps, step_size, gamma
         self.grad_scale = 1.0

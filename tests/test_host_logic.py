@@ -191,9 +191,8 @@ for it in range(5):
     for p, g in zip(net.parameters(), mine[0]):
         p.grad.add_(g)                                 # autograd accumulates into views of the flat bucket
         assert p.grad.data_ptr() >= opt.flat_grad.data_ptr()
-    off = 0
-    for p, g in zip(net.parameters(), mine[1]):        # the side stream's backward lands in the twin bucket
-        twin[off:off + p.numel()].add_(g.reshape(-1)); off += p.numel()
+    for p, g, off in zip(net.parameters(), mine[1], opt.offsets):   # the side stream's backward lands in the twin bucket
+        twin[off:off + p.numel()].add_(g.reshape(-1))
     opt.merge_side_grads()                             # fold BEFORE the collective
     before = calls['n']
     opt.step()

@@ -402,3 +402,44 @@ def test_adam(dev):
     for a, r in zip(gp, ref):
         assert rel_err(a, r) < 1e-5
     assert abs(o.current_lr() - o_ref.param_groups[0]['lr']) < 1e-12
+
+
+@pytest.mark.parametrize('M,N,K,kw', [
+    (5120, 2304, 176, {}),                                   # fused [k|q|v] projection, 128-row blocks
+    (5120, 176, 2304, {'splitk': 2}),                        # its input gradient through the transposed weight copy
+    (5120, 88, 768, {'act': 1, 'bias': True}),               # narrow N: 64-row blocks, sigmoid epilogue
+    (5120, 229, 916, {'act': 1, 'bias': True}),              # K tail (916 = 28 x 32 + 20), N not a multiple of 4 -> scalar stores
+    (333, 100, 88, {'bias': True, 'c2': True}),              # ragged M / N, second destination
+    (200, 72, 40, {'accumulate': True}),                     # K of a single partial stage, C += 
+    (64, 64, 4, {}),                                         # smallest legal problem
+])
+def test_gemm_k_contiguous_full_size(dev, M, N, K, kw):
+    """rv_gemm with two K-contiguous, 16-byte aligned operands (the forward and -- through ops._lin_t -- input-gradient
+    GEMMs of the step) at the step's shapes, against torch.matmul in fp64; and against the same product from an unaligned
+    view (scalar-load path of the kernel)."""
+    from reconvat_amd import ops
+    a, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2)
+    bias = rnd(N, seed=3) if kw.get('bias') else None
+    ref = a.double() @ b.double().t()
+    if bias is not None:
+        ref = ref + bias.double()
+    if kw.get('act'):
+        ref = torch.sigmoid(ref)
+    c0 = rnd(M, N, seed=4)
+    if kw.get('accumulate'):
+        ref = ref + c0.double()
+    ag, bg = a.to(dev), b.to(dev)
+    c = c0.to(dev).clone() if kw.get('accumulate') else torch.full((M, N), float('nan'), device=dev)
+    c2 = torch.full((N, M), float('nan'), device=dev) if kw.get('c2') else None
+    ops.gemm(ag, bg.t(), c, bias.to(dev) if bias is not None else None, act=kw.get('act', 0), accumulate=bool(kw.get('accumulate')),
+             splitk=kw.get('splitk', 1), c2=c2.t() if c2 is not None else None)
+    assert rel_err(c, ref.float()) < 2e-5
+    if c2 is not None:
+        assert rel_err(c2.t(), ref.float()) < 2e-5
+    # the same product from an operand that is not 16-byte aligned
+    if not kw.get('accumulate') and not kw.get('splitk'):
+        pad = torch.zeros(M, K + 1, device=dev)
+        pad[:, 1:] = ag
+        c3 = torch.empty((M, N), device=dev)
+        ops.gemm(pad[:, 1:], bg.t(), c3, bias.to(dev) if bias is not None else None, act=kw.get('act', 0))
+        assert rel_err(c3, c) < 2e-5

@@ -38,7 +38,10 @@ for a in recs:
     g = groups.setdefault(sig, [0, a])
     g[0] += 1
 rows = []
+cur = torch.cuda.current_stream().cuda_stream
 for sig, (cnt, a) in groups.items():
+    a = list(a)
+    a[-1] = cur                # re-time on the stream the events are recorded on (the step runs some GEMMs on a side stream)
     for _ in range(2):
         lib.rv_gemm(*a)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

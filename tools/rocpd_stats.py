@@ -17,7 +17,7 @@ FAMILIES = [
     ('conv direct 3x3/1x1/2x2 (MFMA / HBM)', ('conv_mfma_k',)),
     ('conv C<=2 layers (HBM)', ('conv_small_k', 'wgrad_small_k')),
     ('weight gradients (MFMA)', ('wgrad_mfma_k', 'wgrad_reduce')),
-    ('linear GEMMs (MFMA)', ('gemm_mfma_k', 'colsum', 'sigmoid')),
+    ('linear GEMMs (MFMA)', ('gemm_', 'colsum', 'sigmoid', 'zero_strided')),
     ('local attention', ('attn_',)),
     ('BatchNorm + leaky-ReLU (HBM)', ('bn_',)),
     ('front-end (HBM)', ('mel_',)),
