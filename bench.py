@@ -129,6 +129,103 @@ def measure_conv_phase(step_fn, device):
     return total_ms, total_flops, per_kernel, len(records)
 
 
+# ---------------------------------------------------------------------------------------------
+# the other kernel families of the step (linear GEMMs, local attention, BatchNorm, front-end): every launch of one eager
+# step is recorded with its arguments and each distinct launch is re-issued between two HIP events on the launch stream
+# (the operands of the recorded step are still mapped -- the caching allocator keeps them -- and the kernels are
+# idempotent or accumulate into scratch statistics; results are not used).
+# ---------------------------------------------------------------------------------------------
+HBM_PEAK_TBS = 8.0                    # /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s measured for a copy)
+FAMILY = {
+    'rv_gemm': 'linear GEMMs', 'rv_local_attn_fwd': 'local attention', 'rv_local_attn_bwd': 'local attention',
+    'rv_bn_lrelu_fwd': 'BatchNorm + leaky-ReLU', 'rv_bn_lrelu_bwd': 'BatchNorm + leaky-ReLU',
+    'rv_melspec_lognorm_fwd': 'log-Mel front-end',
+}
+
+
+def family_work(name, a):
+    """(flops, algorithmic HBM bytes) of one launch from its argument list (include/reconvat_hip.h)."""
+    if name == 'rv_gemm':
+        m, n, k, batch = a[13], a[14], a[15], a[19]
+        return 2.0 * m * n * k * batch, 4.0 * batch * (m * k + k * n + m * n)
+    if name == 'rv_bn_lrelu_fwd':                 # reads z (+ residual), writes y
+        p_, c = a[2], a[3]
+        return 0.0, 4.0 * p_ * c * (3 if a[13] else 2)
+    if name == 'rv_bn_lrelu_bwd':                 # reads dy, z, writes dz
+        p_, c = a[4], a[5]
+        return 0.0, 4.0 * p_ * c * 3
+    if name == 'rv_local_attn_fwd':               # q, k, v in, out + attention map out
+        b, l, g, dh = a[7], a[8], a[9], a[10]
+        return 2.0 * 2 * b * l * g * dh * 31, 4.0 * b * l * (4 * g * dh + g * 31)
+    if name == 'rv_local_attn_bwd':
+        b, l, g, dh = a[12], a[13], a[14], a[15]
+        return 2.0 * 5 * b * l * g * dh * 31, 4.0 * b * l * (8 * g * dh + 2 * g * 31)
+    if name == 'rv_melspec_lognorm_fwd':          # audio in, log-mel written, re-read and re-written by the normalisation
+        b, nsamp, n_mels, t = a[2], a[3], a[10], a[15]
+        return 0.0, 4.0 * b * (nsamp + 3 * t * n_mels)
+    return 0.0, 0.0
+
+
+def measure_families(step_fn, device):
+    from reconvat_amd import _lib
+    import reconvat_amd.ops as ops
+    import reconvat_amd.model as model_mod
+    lib = _lib.load()
+    records, real_call = [], _lib.call
+
+    def spy(name, *args):
+        if name in FAMILY:
+            records.append((name, args))
+        return real_call(name, *args)
+    patched = [(m, m.call) for m in (ops, model_mod) if hasattr(m, 'call')]
+    for m, _ in patched:
+        m.call = spy
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+    finally:
+        for m, orig in patched:
+            m.call = orig
+    cur = torch.cuda.current_stream().cuda_stream
+    groups = {}
+    for name, a in records:
+        sig = (name,) + tuple(v for v in a[:-1] if isinstance(v, (int, float)) and not (isinstance(v, int) and v > (1 << 32)))
+        g = groups.setdefault(sig, {'count': 0, 'name': name, 'args': a})
+        g['count'] += 1
+    fam = {}
+    for g in groups.values():
+        a = list(g['args'])
+        a[-1] = cur
+        fn = getattr(lib, g['name'])
+        for _ in range(2):
+            fn(*a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn(*a)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        fl, by = family_work(g['name'], g['args'])
+        f = fam.setdefault(FAMILY[g['name']], {'ms_per_step': 0.0, 'launches': 0, 'gflop': 0.0, 'gbyte': 0.0})
+        f['ms_per_step'] += ms * g['count']
+        f['launches'] += g['count']
+        f['gflop'] += fl * g['count'] / 1e9
+        f['gbyte'] += by * g['count'] / 1e9
+    out = []
+    for name, f in fam.items():
+        mfma = name == 'linear GEMMs'
+        achieved = (f['gflop'] / f['ms_per_step']) if mfma else (f['gbyte'] / f['ms_per_step'])      # TFLOP/s or TB/s
+        peak = MFMA_F32_PEAK_TFLOPS if mfma else HBM_PEAK_TBS
+        out.append({'family': name, 'bound': 'mfma' if mfma else 'hbm', 'ms_per_step': round(f['ms_per_step'], 3),
+                    'launches_per_step': f['launches'], 'achieved': round(achieved, 3), 'unit': 'TFLOP/s' if mfma else 'TB/s',
+                    'peak': peak, 'frac': round(achieved / peak, 4),
+                    'work_per_step': round(f['gflop'], 1) if mfma else round(f['gbyte'], 2),
+                    'work_unit': 'GFLOP' if mfma else 'GB (algorithmic)'})
+    out.sort(key=lambda r: -r['ms_per_step'])
+    return out
+
+
 def _cpu_steps(threads, budget_s, min_timed=3, max_timed=3):
     """`min_timed`..`max_timed` oracle steps (after one warm-up) with torch.set_num_threads(threads)."""
     from oracle import fixture as fx, model as om
@@ -304,16 +401,23 @@ def main():
                     print(f'[conv] {t:8.3f} ms/step  x{c:3d}  {m_:8.4f} ms  {tf:7.1f} TF/s  {sg}', file=sys.stderr)
             # HBM bytes of the same launches from the committed PMC passes (rocprofv3 cannot run inside this process):
             # tools/pmc_traffic.py over separate FETCH_SIZE / WRITE_SIZE runs of `bench.py --no-graph`, gfx950-corrected
-            traffic = None
-            tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-            if os.path.exists(tpath):
-                with open(tpath) as fh:
-                    traffic = json.load(fh).get('traffic_bytes')
+            traffic, traffic_src = None, None
+            for cand in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+                tpath = os.path.join(ROOT, 'profiles', cand)
+                if os.path.exists(tpath):
+                    with open(tpath) as fh:
+                        tj = json.load(fh)
+                    traffic, traffic_src = tj.get('traffic_bytes'), f"profiles/{cand} (committed PMC pass, {tj.get('git', 'commit not recorded')})"
+                    break
+            families = measure_families(eager, device)
             line['roofline'] = {
                 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,
-                'traffic_scope': 'HBM bytes (FETCH_SIZE x2 + WRITE_SIZE) of all conv launches of one step, profiles/r01_pmc_traffic.json',
-                'kernel': 'conv_mfma_k / wgrad_mfma_k family (all conv launches of one step)',
+                'traffic_scope': 'HBM bytes (FETCH_SIZE x2 + WRITE_SIZE) of all conv launches of one step; NOT measured by this run: '
+                                 + str(traffic_src),
+                'kernel': 'conv3x3_lds_k / conv_mfma_k / wgrad_mfma_k family (all conv launches of one step)',
+                'conv_ms_source': 'isolated re-launch of every distinct conv launch of one step on scratch operands, HIP events on '
+                                  'the launch stream, after the timed loop (per-kernel figure; the timed step overlaps two chains)',
                 'launches_per_step': nlaunch, 'conv_ms_per_step': round(conv_ms, 3),
                 'executed_gflop_per_step': round(conv_flops_total / 1e9, 1),
                 'reference_gflop_per_step': 1531.0,
@@ -322,6 +426,11 @@ def main():
                 'frac_counting_reference_work': round(1531.0e9 / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                 'top': [{'ms_per_step': round(t, 3), 'count': c, 'ms': round(m, 4), 'tflops': round(tf, 1), 'sig': list(map(str, s))}
                         for t, c, m, tf, s in per_kernel[:6]],
+                # every other kernel family of the step against the roofline that bounds it (same isolated re-launch method)
+                'families': [{'family': 'convolutions (3x3 / 1x1 / 2x2, fwd + dgrad + wgrad)', 'bound': 'mfma',
+                              'ms_per_step': round(conv_ms, 3), 'launches_per_step': nlaunch, 'achieved': round(achieved, 2),
+                              'unit': 'TFLOP/s', 'peak': MFMA_F32_PEAK_TFLOPS, 'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                              'work_per_step': round(conv_flops_total / 1e9, 1), 'work_unit': 'GFLOP'}] + families,
             }
         if not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()

@@ -12,7 +12,8 @@ import os
 import sys
 from collections import defaultdict
 
-CONV = ('conv3x3_lds_k', 'conv_mfma_k', 'conv_small_k', 'wgrad_mfma_k', 'wgrad_small_k', 'wgrad_reduce_k', 'wgrad_reduce_table_k')
+CONV = ('conv3x3_lds_k', 'conv_mfma_k', 'conv_small_k', 'conv_narrow_out_k', 'wgrad_mfma_k', 'wgrad_small_k', 'wgrad_reduce_k',
+        'wgrad_reduce_table_k')
 
 
 def one_pass(path, counter):
@@ -51,7 +52,12 @@ def main():
                 break
     fetch = out['FETCH_SIZE']['kb_reported'] * 1024 * 2       # gfx950: x2
     write = out['WRITE_SIZE']['kb_reported'] * 1024
-    res = {'scope': 'all conv-family launches of one optimiser step (eager launches, B_l=B_ul=8)',
+    import subprocess
+    try:
+        git = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD'], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:  # noqa: BLE001 -- the GPU box has no .git
+        git = os.environ.get('RV_GIT_SHA', 'unknown (no .git on the GPU box)')
+    res = {'scope': 'all conv-family launches of one optimiser step (eager launches, B_l=B_ul=8)', 'git': git,
            'fetch_bytes': fetch, 'write_bytes': write, 'traffic_bytes': fetch + write,
            'launches': out['FETCH_SIZE']['launches'],
            'correction': 'FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported',
