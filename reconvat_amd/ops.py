@@ -368,6 +368,8 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
                         cands += [0x200 | nt << 4 | mt for mt in (1, 2, 4, 8)]
                         cands += [0x300 | nt << 4 | mt for mt in (1, 2, 4)]
                         cands += [0x400 | nt << 4 | mt for mt in (1, 2, 4)]
+                        cands += [0x500 | nt << 4 | mt for mt in (1, 2, 4)]     # wave-specialised: 8 / 12 compute + 4 loader waves
+                        cands += [0x600 | nt << 4 | mt for mt in (1, 2, 4)]
                 for cand in cands:
                     if lib.rv_conv_fwd(*targs, cand, scratch, *tail, st.cuda_stream) != 0:
                         continue                                   # tile does not fit this shape
