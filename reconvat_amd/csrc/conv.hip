@@ -651,383 +651,6 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Wave-specialised form of conv3x3_lds_k: NW COMPUTE waves + WS_NLW LOADER waves per workgroup, no workgroup barrier in the
-// unit loop.  The loader waves issue every LDS-DMA (input rows, weight fragments; they own the staging plan and all its
-// address arithmetic) into a ring of three unit buffers, two units ahead; the compute waves only read fragments, multiply
-// and store.  Hand-off through two monotonic LDS counters per ring slot: `landed` (+1 per loader wave once its share of
-// the unit is in LDS: its vmcnt has drained past it) and `freed` (+1 per compute wave after its last fragment read of the
-// unit).  A compute wave polls `landed` of its next unit, a loader wave polls `freed` before it refills a slot.  Because
-// nothing synchronises the compute waves with EACH OTHER, they drift apart: one wave's band epilogue (stores) or fragment
-// reads run under its siblings' MFMAs, and nobody issues DMA on the compute side -- in the barrier-synchronous kernel every
-// wave goes through DMA issue / reads / MFMAs / stores at the same time and the matrix pipe idles in between
-// (profiles/r02_conv3x3_stamps.txt: DMA issue 7-12 %, epilogue 4-32 %, barrier skew).  Stores are never waited for.
-// ------------------------------------------------------------------------------------------
-#define WS_NLW 4
-#define WS_SPIN_MAX (1 << 20)      // a hand-off that never arrives ends the poll (wrong output, caught by the tests) instead of hanging the GPU
-__device__ __forceinline__ int lds_flag_read(unsigned addr) {        // load + wait in ONE statement (the compiler does not count it)
-    int v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
-    return v;
-}
-__device__ __forceinline__ void lds_flag_add1(unsigned addr) {
-    const int one = 1;
-    asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(one) : "memory");
-}
-__device__ __forceinline__ void wait_vmcnt_le32(int n) {            // n wave-uniform; rounding DOWN only makes the wait stricter
-    if (n >= 32) { asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); return; }
-    if (n >= 24) { asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); return; }
-    if (n >= 20) { asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); return; }
-    if (n >= 16) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); return; }
-    if (n >= 14) { asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); return; }
-    if (n >= 12) { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); return; }
-    if (n >= 10) { asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); return; }
-    wait_vmcnt_le(n);
-}
-
-template <int R, int NT, int MTW, int NW>
-__global__ __launch_bounds__((NW + WS_NLW) * 64) void conv3x3_ws_k(ConvLdsArgs aa) {
-    constexpr int NLW = WS_NLW;
-    constexpr int NTHR = (NW + NLW) * 64;
-    typedef typename VecR<R>::T vec;
-    constexpr int KC = 4 * R;                    // channels per chunk
-    constexpr int Q = R;                         // float4 per staged pixel (KC/4)
-    constexpr int PPI = 64 / Q;                  // pixels per DMA wave-instruction
-    constexpr int LPF = 16 * R;                  // lanes (float4) per weight fragment
-    constexpr int FPI = 64 / LPF;                // fragments per DMA wave-instruction
-    constexpr int WFLOATS = 9 * NT * 64 * R;
-    const ConvArgs& a = aa.c;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 15, g = lane >> 4;
-    const bool loader = wave >= NW;                       // wave-uniform role
-    const int lw = loader ? wave - NW : 0;                // loader index (staging plan)
-    const int W = a.W, H = a.H, W2 = W + 2, TH = aa.TH;
-    const int nrow = TH + 2;
-    const int xfloats = nrow * W2 * KC;
-    // XCD-aware placement (1-D grid): every XCD gets a contiguous run of (band group, n-split) pairs with the
-    // splits fastest, so the workgroups that re-read the same input rows -- the n-splits of one band group and
-    // the neighbouring band groups (halo rows) -- share one L2 instead of pulling the rows into several.
-    if (ABL(aa) & 32) return;
-    const int vid = aa.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-    const int grp = vid / aa.nsplit, split = vid - grp * aa.nsplit;
-    const int nt0 = split * NT;
-    const int nbuf = aa.nbuf;                            // ring depth 3 (two units in flight ahead of the multiply), 2 when three do not fit
-    float* xs0 = smem;                                   // [nbuf][nrow][W2][KC]
-    float* ws0 = smem + nbuf * xfloats;                  // [nbuf][9][NT][64][R]
-    const int band_lo = grp * aa.bands_per_wg;
-    const int band_hi = min(band_lo + aa.bands_per_wg, aa.total_bands);
-    if (band_lo >= band_hi) return;
-    const int nchunk = a.nchunk;
-    const int nunits = (band_hi - band_lo) * nchunk;
-    const int ipr = (W + PPI - 1) / PPI;                 // DMA instructions per input row
-
-    // ---- staging plan.  Staging is instruction-issue bound and does not hide under the other waves' MFMAs, so
-    // everything that does not depend on the unit is computed ONCE per wave: per DMA slot the lane's byte offset
-    // from the unit's first input row / from the chunk's first weight fragment, the LDS destination and the lane
-    // mask.  Per unit that leaves two scalar base pointers and one DMA instruction per slot. ----
-    constexpr int TXF = 8;                                // x slots planned in registers (any further: generic loop)
-    constexpr int NWF = (9 * NT + FPI - 1) / FPI;         // weight DMA instructions per unit (whole workgroup)
-    constexpr int TW = (NWF + NLW - 1) / NLW;             // ... per loader wave
-    const int nx = nrow * ipr;
-    int xs_row[TXF], xs_ldst[TXF];
-    unsigned xs_goff[TXF];
-    bool xs_lane[TXF];
-#pragma unroll
-    for (int t = 0; t < TXF; ++t) {
-        const int i = lw + NLW * t;
-        const int row = i / ipr, k = i - row * ipr;
-        const int px = k * PPI + lane / Q, q = lane - (lane / Q) * Q;
-        xs_row[t] = row;
-        xs_ldst[t] = (row * W2 + 1 + k * PPI) * KC;
-        xs_goff[t] = (unsigned)((row * W + px) * a.in_ld + q * 4) * 4u;
-        xs_lane[t] = i < nx && px < W;
-    }
-    unsigned w_off[TW];
-    bool w_lane[TW];
-#pragma unroll
-    for (int t = 0; t < TW; ++t) {
-        const int i = lw + NLW * t;
-        const int f = i * FPI + lane / LPF, o = lane - (lane / LPF) * LPF;
-        const int tap = f / NT, n = f - tap * NT;
-        w_lane[t] = i < NWF && f < 9 * NT;
-        w_off[t] = (unsigned)((tap * nchunk * a.ntile_n + nt0 + n) * 64 * R + o * 4) * 4u;
-    }
-    const int b_first = band_lo / aa.nbands, y_first = (band_lo - b_first * aa.nbands) * TH;
-    int sg_u = 0, sg_buf = 0, sg_b = b_first, sg_y0 = y_first, sg_c = 0;      // staging cursor (units in order)
-
-    // issues the DMA of the next unit; returns how many VMEM instructions this wave issued (wave-uniform)
-    auto stage = [&]() -> int {
-        int issued = 0;
-        float* xb = xs0 + sg_buf * xfloats;
-        const char* src = reinterpret_cast<const char*>(a.in + ((long)(sg_b * H + sg_y0 - 1) * W) * a.in_ld + sg_c * KC);
-#pragma unroll
-        for (int t = 0; t < TXF; ++t) {
-            if (lw + NLW * t >= nx) break;
-            const int gy = sg_y0 - 1 + xs_row[t];
-            float* ldst = xb + xs_ldst[t];                               // wave-uniform
-            if (gy >= 0 && gy < H) {
-                if (xs_lane[t]) glds16(reinterpret_cast<const float*>(src + xs_goff[t]), ldst);
-                ++issued;
-            } else if (xs_lane[t]) {
-                *reinterpret_cast<f32x4*>(ldst + lane * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-        for (int i = lw + NLW * TXF; i < nx; i += NLW) {                // wide rows
-            const int row = i / ipr, k = i - row * ipr;
-            const int gy = sg_y0 - 1 + row;
-            const int px = k * PPI + lane / Q, q = lane - (lane / Q) * Q;
-            float* ldst = xb + (row * W2 + 1 + k * PPI) * KC;
-            if (gy >= 0 && gy < H) {
-                if (px < W) glds16(reinterpret_cast<const float*>(src) + ((long)row * W + px) * a.in_ld + q * 4, ldst);
-                ++issued;
-            } else if (px < W) {
-                *reinterpret_cast<f32x4*>(ldst + lane * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-        if (nchunk > 1 || sg_u == 0) {
-            float* wb = ws0 + ((nchunk > 1) ? sg_buf : 0) * WFLOATS;
-            const char* wsrc = reinterpret_cast<const char*>(a.wpack + (long)sg_c * a.ntile_n * 64 * R);
-#pragma unroll
-            for (int t = 0; t < TW; ++t) {
-                if (lw + NLW * t >= NWF) break;
-                if (w_lane[t]) glds16(reinterpret_cast<const float*>(wsrc + w_off[t]), wb + (lw + NLW * t) * 256);
-                ++issued;
-            }
-        }
-        ++sg_u;
-        if (++sg_buf == nbuf) sg_buf = 0;
-        if (++sg_c == nchunk) {
-            sg_c = 0;
-            sg_y0 += TH;
-            if (sg_y0 >= H) { sg_y0 = 0; ++sg_b; }
-        }
-        return issued;
-    };
-
-    // halo columns of both buffers are zero for the whole kernel (the DMA never touches them)
-    for (int k = tid; k < nbuf * nrow * 2 * KC; k += NTHR) {
-        const int buf = k / (nrow * 2 * KC), rem = k - buf * (nrow * 2 * KC);
-        const int row = rem / (2 * KC), rem2 = rem - row * (2 * KC);
-        const int side = rem2 / KC, ch = rem2 - side * KC;
-        xs0[buf * xfloats + (row * W2 + (side ? W + 1 : 0)) * KC + ch] = 0.f;
-    }
-
-    f32x4 acc[MTW][NT];
-    int lbase[MTW];
-    bool pv[MTW];
-    f32x4 bv[NT];
-    __shared__ __attribute__((aligned(16))) float cf[4 * 64];   // mean | invstd | scale | shift of this workgroup's channels
-    __shared__ int flags[8];                                    // landed[3] | freed[3]
-    if (tid < 8) flags[tid] = 0;
-    if (a.bn_z) {
-        for (int idx = tid; idx < 4 * NT * 16; idx += NTHR) {
-            const int k = idx / (NT * 16), cl = idx - k * (NT * 16), ch = nt0 * 16 + cl;
-            cf[k * 64 + cl] = ch < a.Cout ? a.bn_coef[k * a.Cout + ch] : 0.f;
-        }
-    }
-    f32x4 st1[NT], st2[NT];                      // BatchNorm statistics of this thread's outputs (a.bn_sums)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) st1[n] = st2[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int cb = (nt0 + n) * 16 + 4 * g;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bv[n][r] = (a.bias && cb + r < a.Cout) ? a.bias[cb + r] : 0.f;
-    }
-    __syncthreads();                                      // halo columns, coefficient table, zeroed counters: the ONLY barrier before the end
-    const unsigned fl_landed = lds_addr(reinterpret_cast<const float*>(flags)), fl_freed = fl_landed + 12;
-    if (loader) {
-        // ---- loader waves: unit u goes to ring slot u % 3 once every compute wave has released unit u - 3; the previous
-        // unit is announced as soon as this wave's vmcnt shows it has landed (loads return in order) ----
-        int slot = 0, round = 0;
-        for (int u = 0; u < nunits; ++u) {
-            if (round > 0) {
-                const int need = NW * round;                  // completions of unit u - 3 by every compute wave
-                for (int spin = 0; lds_flag_read(fl_freed + 4 * slot) < need && spin < WS_SPIN_MAX; ++spin) __builtin_amdgcn_s_sleep(2);
-            }
-            const int issued = stage();
-            if (u > 0) {
-                wait_vmcnt_le32(issued);                      // everything older than unit u's instructions has landed
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and the zero-filled rows are written
-                if (lane == 0) lds_flag_add1(fl_landed + 4 * (slot == 0 ? nbuf - 1 : slot - 1));
-            }
-            if (++slot == nbuf) { slot = 0; ++round; }
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        if (lane == 0) lds_flag_add1(fl_landed + 4 * (slot == 0 ? nbuf - 1 : slot - 1));
-    }
-    int cu_buf = 0, cu_round = 0, cu_b = b_first, cu_y0 = y_first, cu_c = 0;  // compute cursor
-    for (int u = 0; u < (loader ? 0 : nunits); ++u) {
-        const int b = cu_b, y0 = cu_y0, c = cu_c, buf = cu_buf;
-        const int round = cu_round;
-        if (++cu_buf == nbuf) { cu_buf = 0; ++cu_round; }
-        if (++cu_c == nchunk) {
-            cu_c = 0;
-            cu_y0 += TH;
-            if (cu_y0 >= H) { cu_y0 = 0; ++cu_b; }
-        }
-        const int th = min(TH, H - y0);
-        const int npx = th * W;
-        const int ntile = (npx + 15) >> 4;
-        if (c == 0) {
-#pragma unroll
-            for (int m = 0; m < MTW; ++m) {
-                const int t = wave + NW * m;
-                const int p = t * 16 + j;
-                pv[m] = t < ntile && p < npx;
-                const unsigned pp = pv[m] ? (unsigned)p : 0u;
-                const int ty = (int)fastdiv(pp, a.fd_w), tx = (int)pp - ty * W;
-                lbase[m] = (ty * W2 + tx) * KC + g * R;
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-        {
-            const int need = NLW * (round + 1);               // every loader wave has landed its share of unit u
-            for (int spin = 0; lds_flag_read(fl_landed + 4 * buf) < need && spin < WS_SPIN_MAX; ++spin) __builtin_amdgcn_s_sleep(1);
-        }
-        const float* xs = xs0 + buf * xfloats;
-        const float* ws = ws0 + ((nchunk > 1) ? buf : 0) * WFLOATS;
-        // Software-pipelined tap loop: the fragments of tap t+1 are in flight while tap t is multiplied.  The
-        // ds_reads and their s_waitcnt are issued by hand: with LDS-DMA pending the compiler's own wait-count
-        // model degrades every LDS wait to lgkmcnt(0), which would serialise the prefetch again.
-        vec wf[2][NT], xf[2][MTW];
-        const unsigned ws_a = lds_addr(ws) + lane * (R * 4);
-        unsigned xs_a[MTW];
-#pragma unroll
-        for (int m = 0; m < MTW; ++m) xs_a[m] = lds_addr(xs) + lbase[m] * 4;
-        auto ldtap = [&](const int buf, const int tap) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n) lds_read(wf[buf][n], ws_a + (tap * NT + n) * 64 * R * 4);
-            const int toff = ((tap / 3) * W2 + (tap % 3)) * KC * 4;
-#pragma unroll
-            for (int m = 0; m < MTW; ++m) lds_read(xf[buf][m], xs_a[m] + toff);
-        };
-        ldtap(0, 0);
-        if (!(ABL(aa) & 4))
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            if (tap + 1 < 9) {
-                if (!(ABL(aa) & 16)) ldtap((tap + 1) & 1, tap + 1);
-                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NT + MTW) : "memory");   // tap's own fragments have landed
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-#pragma unroll
-                    for (int m = 0; m < MTW; ++m)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tap & 1][n][r], xf[tap & 1][m][r], acc[m][n], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (lane == 0) lds_flag_add1(fl_freed + 4 * buf);      // this wave's last fragment read of the unit has returned (lgkmcnt(0) above)
-        if (c != nchunk - 1) continue;
-        // epilogue of this band
-        const long pix0 = ((long)b * H + y0) * W;
-        f32x4 zreg[MTW][NT];                     // fused BatchNorm backward: all z loads of the band in flight at once
-        if (a.bn_z) {
-#pragma unroll
-            for (int m = 0; m < MTW; ++m) {
-                const long opix = pix0 + (wave + NW * m) * 16 + j;
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const int co0 = (nt0 + n) * 16 + 4 * g;
-                    zreg[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (!pv[m] || co0 >= a.Cout) continue;
-                    const float* zp = a.bn_z + opix * a.bn_z_ld + co0;
-                    if ((a.bn_z_ld & 3) == 0 && co0 + 3 < a.Cout) zreg[m][n] = *reinterpret_cast<const f32x4*>(zp);
-                    else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (co0 + r < a.Cout) zreg[m][n][r] = zp[r];
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < MTW; ++m) {
-            if (!pv[m] || (ABL(aa) & 8)) continue;
-            const long opix = pix0 + (wave + NW * m) * 16 + j;
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const int co0 = (nt0 + n) * 16 + 4 * g;
-                if (co0 >= a.Cout) continue;
-                float* o = a.out + opix * a.out_ld + co0;
-                f32x4 v = acc[m][n] + bv[n];
-                if (a.vec_store && co0 + 3 < a.Cout) {
-                    if (a.accumulate) { f32x4 old = *reinterpret_cast<f32x4*>(o); v += old; }
-                    *reinterpret_cast<f32x4*>(o) = v;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (co0 + r < a.Cout) {
-                            if (a.accumulate) v[r] += o[r];
-                            o[r] = v[r];
-                        }
-                }
-                if (a.bn_z) {
-                    // backward statistics: coefficients of these 4 channels from LDS, z of this pixel prefetched above
-                    const f32x4 mean4 = *reinterpret_cast<const f32x4*>(&cf[0 * 64 + n * 16 + 4 * g]);
-                    const f32x4 inv4 = *reinterpret_cast<const f32x4*>(&cf[1 * 64 + n * 16 + 4 * g]);
-                    const f32x4 sc4 = *reinterpret_cast<const f32x4*>(&cf[2 * 64 + n * 16 + 4 * g]);
-                    const f32x4 sh4 = *reinterpret_cast<const f32x4*>(&cf[3 * 64 + n * 16 + 4 * g]);
-                    const f32x4 z4 = zreg[m][n];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float zh = fmaf(z4[r], sc4[r], sh4[r]);
-                        const float dd = zh > 0.f ? v[r] : v[r] * a.bn_slope;
-                        st1[n][r] += dd;
-                        st2[n][r] = fmaf(dd, (z4[r] - mean4[r]) * inv4[r], st2[n][r]);
-                    }
-                } else {
-                    st1[n] += v;
-                    st2[n] += v * v;
-                }
-            }
-        }
-    }
-    // Fused BatchNorm statistics: the consumer's per-channel sum / sum of squares leave with the conv instead of
-    // costing another pass over the output.  16 pixel lanes -> one lane (xor shuffles), waves -> LDS, then ONE fp64
-    // atomic per channel and workgroup (a persistent grid: a few hundred atomics per address at most).
-    if (a.bn_sums) {
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float u = st1[n][r], q = st2[n][r];
-#pragma unroll
-                for (int d = 1; d < 16; d <<= 1) {
-                    u += __shfl_xor(u, d, 64);
-                    q += __shfl_xor(q, d, 64);
-                }
-                st1[n][r] = u; st2[n][r] = q;
-            }
-        __syncthreads();                                   // every wave is done with the unit buffers
-        float* red = smem;                                 // [NW][NT*16][2]
-        if (j == 0 && !loader) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    red[((wave * NT + n) * 16 + 4 * g + r) * 2] = st1[n][r];
-                    red[((wave * NT + n) * 16 + 4 * g + r) * 2 + 1] = st2[n][r];
-                }
-        }
-        __syncthreads();
-        for (int t = tid; t < NT * 16 * 2; t += NTHR) {
-            const int cl = t >> 1, which = t & 1, ch = nt0 * 16 + cl;
-            double dsum = 0.0;
-            for (int w = 0; w < NW; ++w) dsum += (double)red[((w * NT) * 16 + cl) * 2 + which];
-            if (ch < a.Cout) atomicAdd(&a.bn_sums[(blockIdx.x % RV_BN_NREP) * 2 * a.Cout + which * a.Cout + ch], dsum);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // small-channel convolution on the VALU (Cin==1, or Cout<=2): pure bandwidth kernels
 // ------------------------------------------------------------------------------------------
 struct SmallArgs {
@@ -1851,28 +1474,41 @@ static int launch_conv3x3_lds_r(const ConvArgs& a, int NT, int MTW, int TH, int 
         hipLaunchKernelGGL(kern, grid, blk, lds, st, aa);                                         \
         return RV_OK;                                                                             \
     }
-    RV_L3(1, 1) RV_L3(1, 2) RV_L3(1, 4) RV_L3(1, 8)
-    RV_L3(2, 1) RV_L3(2, 2) RV_L3(2, 4) RV_L3(2, 8)
-    RV_L3(3, 1) RV_L3(3, 2) RV_L3(3, 4)
-    RV_L3(4, 1) RV_L3(4, 2) RV_L3(4, 4)
+    if constexpr (NW == 12) {
+        // 12 waves = three per SIMD with 3 / 5 / 6 tiles each: 9 / 15 / 18 tiles per SIMD and band, the band sizes at which whole
+        // rows of the 57- / 114- / 229-pixel-wide layers fill 99 % of the tile slots (a power-of-two tile count leaves 89 %)
+        RV_L3(1, 3) RV_L3(2, 3) RV_L3(3, 3) RV_L3(4, 3)
+        RV_L3(1, 5) RV_L3(2, 5) RV_L3(1, 6) RV_L3(2, 6)
+        RV_L3(1, 1) RV_L3(2, 1) RV_L3(4, 1) RV_L3(1, 2) RV_L3(2, 2) RV_L3(4, 2) RV_L3(1, 4) RV_L3(2, 4)
+    } else {
+        RV_L3(1, 1) RV_L3(1, 2) RV_L3(1, 4) RV_L3(1, 8)
+        RV_L3(2, 1) RV_L3(2, 2) RV_L3(2, 4) RV_L3(2, 8)
+        RV_L3(3, 1) RV_L3(3, 2) RV_L3(3, 4)
+        RV_L3(4, 1) RV_L3(4, 2) RV_L3(4, 4)
+    }
 #undef RV_L3
     return RV_EUNSUPPORTED;
 }
 
-static int launch_conv3x3_lds(const ConvArgs& a, int R, hipStream_t st, int force_nt = 0, int force_mt = 0, int nw = 4) {
-    static const int mts[4] = {8, 4, 2, 1};
+static int launch_conv3x3_lds(const ConvArgs& a, int R, hipStream_t st, int force_nt = 0, int force_mt = 0, int nw = 4, int force_th = 0) {
+    static const int mts_pow2[7] = {8, 4, 2, 1, 0, 0, 0}, mts_12[7] = {6, 5, 4, 3, 2, 1, 0};
+    const int* mts = nw == 12 ? mts_12 : mts_pow2;
     // search (NT, MTW): prefer large tiles, but need >= ~1.5 units per workgroup slot on the chip
     int best_nt = 0, best_mt = 0, best_th = 0, best_wpc = 1;
     long best_score = -1;
     for (int nt = 4; nt >= 1; --nt) {
         if (a.ntile_n % nt) continue;
         if (force_nt && nt != force_nt) continue;
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 7; ++k) {
             const int mt = mts[k];
-            if (force_mt && mt != force_mt) continue;
-            if (nt * mt > 16 || (nw == 16 && nt * mt > 8)) continue;      // accumulator budget (<= 128 registers per wave at 16 waves)
+            if (!mt || (force_mt && mt != force_mt)) continue;
+            if (nt * mt > 16 || (nw >= 12 && nt * mt > (nw == 16 ? 8 : 12)) || (nw == 12 && ((mt > 3 && nt > 2) || nt == 3 && mt != 3))) continue;      // accumulator budget (<= 128 registers per wave at 16 waves)
             int th = (mt * 16 * nw) / a.W;                                // nw waves x mt tiles x 16 pixels per band
             if (th > a.H) th = a.H;
+            if (force_th) {                                               // fewer rows than the tile slots hold: band-count quantisation
+                if (force_th > th) continue;
+                th = force_th;
+            }
             if (th < 1) continue;
             const size_t lds = conv3x3_lds_bytes(R, nt, th, a.W, a.nchunk);
             if (lds > 150 * 1024) continue;
@@ -1888,6 +1524,9 @@ static int launch_conv3x3_lds(const ConvArgs& a, int R, hipStream_t st, int forc
         }
     }
     if (!best_nt) return RV_EUNSUPPORTED;
+    if (nw == 12)
+        return R == 4 ? launch_conv3x3_lds_r<4, 12>(a, best_nt, best_mt, best_th, best_wpc, st)
+                      : launch_conv3x3_lds_r<2, 12>(a, best_nt, best_mt, best_th, best_wpc, st);
     if (nw == 16)
         return R == 4 ? launch_conv3x3_lds_r<4, 16>(a, best_nt, best_mt, best_th, best_wpc, st)
                       : launch_conv3x3_lds_r<2, 16>(a, best_nt, best_mt, best_th, best_wpc, st);
@@ -1896,53 +1535,6 @@ static int launch_conv3x3_lds(const ConvArgs& a, int R, hipStream_t st, int forc
                       : launch_conv3x3_lds_r<2, 8>(a, best_nt, best_mt, best_th, best_wpc, st);
     return R == 4 ? launch_conv3x3_lds_r<4, 4>(a, best_nt, best_mt, best_th, best_wpc, st)
                   : launch_conv3x3_lds_r<2, 4>(a, best_nt, best_mt, best_th, best_wpc, st);
-}
-
-// wave-specialised persistent 3x3 (conv3x3_ws_k): `ncw` compute waves + WS_NLW loader waves, three-slot unit ring
-template <int R, int NCW>
-static int launch_conv3x3_ws_r(const ConvArgs& a, int NT, int MTW, int TH, hipStream_t st) {
-    ConvLdsArgs aa;
-    aa.c = a; aa.TH = TH; aa.nbands = cdiv(a.H, TH);
-    aa.total_bands = a.B * aa.nbands;
-    const int nsplit = a.ntile_n / NT;
-    int wgs = 256 / nsplit;
-    if (wgs < 1) wgs = 1;
-    if (wgs > aa.total_bands) wgs = aa.total_bands;
-    aa.bands_per_wg = cdiv(aa.total_bands, wgs);
-    wgs = cdiv(aa.total_bands, aa.bands_per_wg);
-    aa.nbuf = conv3x3_lds_bytes(R, NT, TH, a.W, a.nchunk, 3) <= (size_t)150 * 1024 ? 3 : 2; aa.skew = 0;
-    aa.ablate = getenv("RV_ABLATE") ? atoi(getenv("RV_ABLATE")) : 0;
-    static const int xcd_env = getenv("RV_CONV_XCD") ? atoi(getenv("RV_CONV_XCD")) : 1;
-    aa.nsplit = nsplit; aa.xcd = xcd_env;
-    const size_t lds = conv3x3_lds_bytes(R, NT, TH, a.W, a.nchunk, aa.nbuf);
-    dim3 grid(wgs * nsplit), blk((NCW + WS_NLW) * 64);
-#define RV_W3(nt, mt)                                                                              \
-    if (NT == nt && MTW == mt) {                                                                  \
-        auto kern = conv3x3_ws_k<R, nt, mt, NCW>;                                                 \
-        static bool attr_done = false;                                                            \
-        if (!attr_done) {                                                                         \
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) \
-                (void)hipGetLastError();                                                          \
-            attr_done = true;                                                                     \
-        }                                                                                         \
-        hipLaunchKernelGGL(kern, grid, blk, lds, st, aa);                                         \
-        return RV_OK;                                                                             \
-    }
-    RV_W3(1, 1) RV_W3(1, 2) RV_W3(1, 4)
-    RV_W3(2, 1) RV_W3(2, 2) RV_W3(2, 4)
-    RV_W3(4, 1) RV_W3(4, 2)
-#undef RV_W3
-    return RV_EUNSUPPORTED;
-}
-
-static int launch_conv3x3_ws(const ConvArgs& a, int R, hipStream_t st, int nt, int mt, int ncw) {
-    if (nt < 1 || a.ntile_n % nt || nt * mt > (ncw == 12 ? 4 : 8)) return RV_EUNSUPPORTED;   // 16 waves: 128 VGPRs each
-    int th = (mt * 16 * ncw) / a.W;                       // ncw compute waves x mt tiles x 16 pixels per band
-    if (th > a.H) th = a.H;
-    if (th < 1) return RV_EUNSUPPORTED;
-    if (conv3x3_lds_bytes(R, nt, th, a.W, a.nchunk, 2) > (size_t)150 * 1024) return RV_EUNSUPPORTED;   // ring of 3 when it fits, else 2
-    if (ncw == 12) return R == 4 ? launch_conv3x3_ws_r<4, 12>(a, nt, mt, th, st) : launch_conv3x3_ws_r<2, 12>(a, nt, mt, th, st);
-    return R == 4 ? launch_conv3x3_ws_r<4, 8>(a, nt, mt, th, st) : launch_conv3x3_ws_r<2, 8>(a, nt, mt, th, st);
 }
 
 static int frag_R(int kdim) { return (kdim % 16 == 0) ? 4 : ((kdim % 8 == 0) ? 2 : 0); }
@@ -2149,19 +1741,15 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
     // algo: 0 = library default, 1 = LDS-free direct kernel, 2 = LDS/DMA-pipelined kernel (3x3 only),
     // 0x100|NT<<4|MT = direct kernel with that register tile, 0x200|NT<<4|MTW = LDS kernel with that tile (4 waves),
     // 0x300|NT<<4|MTW = LDS kernel with 8 waves per workgroup (two per SIMD), 0x400|... = 16 waves (four per SIMD),
-    // 0x500|... / 0x600|... = wave-specialised LDS kernel with 8 / 12 compute waves + 4 loader waves (conv3x3_ws_k).
+    // 0x700|NT<<4|MTW = 12 waves (three per SIMD) with MTW in {3, 5, 6}: the band sizes that fit whole 57/114/229-pixel rows.
+    // TH<<12 on top of a forced LDS tile: rows per band (<= what the tile slots hold; 0 = as many as they hold).
     // Forced tiles that do not fit the shape return RV_EUNSUPPORTED (the host autotuner skips them).
-    const int fam = algo >> 8, f_nt = (algo >> 4) & 15, f_mt = algo & 15;
-    if (mode == 0 && (fam == 5 || fam == 6)) {
-        const int rcw = launch_conv3x3_ws(a, R, st, f_nt, f_mt, fam == 6 ? 12 : 8);
-        if (rcw == RV_OK) { RV_LAUNCH_CHECK("rv_conv_fwd(ws)"); *sums_done = true; return RV_OK; }
-        rv_set_error("rv_conv_fwd: forced wave-specialised tile NT=%d MTW=%d does not fit", f_nt, f_mt);
-        return RV_EUNSUPPORTED;
-    }
+    const int fam = (algo >> 8) & 15, f_nt = (algo >> 4) & 15, f_mt = algo & 15, f_th = (algo >> 12) & 255;
     if (mode == 0 && algo != 1 && fam != 1) {
-        int rc3 = (fam >= 2 && fam <= 4) ? launch_conv3x3_lds(a, R, st, f_nt, f_mt, fam == 4 ? 16 : (fam == 3 ? 8 : 4)) : launch_conv3x3_lds(a, R, st);
+        const bool forced = (fam >= 2 && fam <= 4) || fam == 7;
+        int rc3 = forced ? launch_conv3x3_lds(a, R, st, f_nt, f_mt, fam == 7 ? 12 : (fam == 4 ? 16 : (fam == 3 ? 8 : 4)), f_th) : launch_conv3x3_lds(a, R, st);
         if (rc3 == RV_OK) { RV_LAUNCH_CHECK("rv_conv_fwd(lds)"); *sums_done = true; return RV_OK; }
-        if (fam >= 2 && fam <= 4) { rv_set_error("rv_conv_fwd: forced LDS tile NT=%d MTW=%d does not fit", f_nt, f_mt); return RV_EUNSUPPORTED; }
+        if (forced) { rv_set_error("rv_conv_fwd: forced LDS tile NT=%d MTW=%d does not fit", f_nt, f_mt); return RV_EUNSUPPORTED; }
     }
     int NT, MT;
     choose_tiles((a.npix + 15) / 16, a.ntile_n, &NT, &MT);

@@ -368,8 +368,24 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
                         cands += [0x200 | nt << 4 | mt for mt in (1, 2, 4, 8)]
                         cands += [0x300 | nt << 4 | mt for mt in (1, 2, 4)]
                         cands += [0x400 | nt << 4 | mt for mt in (1, 2, 4)]
-                        cands += [0x500 | nt << 4 | mt for mt in (1, 2, 4)]     # wave-specialised: 8 / 12 compute + 4 loader waves
-                        cands += [0x600 | nt << 4 | mt for mt in (1, 2, 4)]
+                        cands += [0x700 | nt << 4 | mt for mt in (1, 2, 3, 4, 5, 6)]     # 12 waves: 3 .. 18 tiles per SIMD and band
+                if mode == 0:
+                    # rows per band: the tile slots of a (waves, MTW) pair hold th_max rows; fewer rows trade padding for a band
+                    # count that divides over the 256 workgroup slots (the deep layers have only a few bands per image)
+                    extra = []
+                    for cand in cands:
+                        nwv = {2: 4, 3: 8, 4: 16, 7: 12}.get(cand >> 8)
+                        if nwv is None:
+                            continue
+                        th_max = min(h, (cand & 15) * 16 * nwv // wd)
+                        if th_max < 2:
+                            continue
+                        nb0 = -(-h // th_max)
+                        for nb in range(nb0, nb0 + 4):
+                            th = -(-h // nb)
+                            if 0 < th < th_max and th < 256:
+                                extra.append(th << 12 | cand)
+                    cands += sorted(set(extra))
                 for cand in cands:
                     if lib.rv_conv_fwd(*targs, cand, scratch, *tail, st.cuda_stream) != 0:
                         continue                                   # tile does not fit this shape

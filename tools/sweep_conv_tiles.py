@@ -1,6 +1,6 @@
 """Time every tile of every 3x3 kernel family on the step's main shapes; print the best of each family per shape.
 
-    python tools/sweep_conv_tiles.py            # families: 1 direct, 2/3/4 LDS kernel with 4/8/16 waves, 5/6 wave-specialised 8/12(+4)
+    python tools/sweep_conv_tiles.py            # families: 1 direct, 2/3/4/7 LDS kernel with 4/8/16/12 waves
 """
 import os
 import sys
@@ -11,6 +11,7 @@ from reconvat_amd import ops, _lib
 SHAPES = [(16, 16, 640, 229), (48, 24, 320, 114), (32, 32, 320, 114), (64, 64, 160, 57), (96, 48, 160, 57), (128, 128, 80, 28),
           (192, 96, 80, 28), (256, 256, 40, 14), (128, 64, 80, 28), (64, 32, 160, 57)]
 B = 8
+TH = range(0, 41) if '--th' in sys.argv else (0,)       # --th: also sweep the rows per band
 dev = torch.device('cuda:0')
 lib = _lib.load()
 st = torch.cuda.current_stream()
@@ -26,12 +27,13 @@ for cin, cout, h, w in SHAPES:
     flops = 2.0 * B * h * w * cin * cout * 9
     best = {}
     ntile_n = (cout + 15) // 16
-    for fam in (1, 2, 3, 4, 5, 6):
+    for fam in (1, 2, 3, 4, 7):
         for nt in (1, 2, 3, 4):
             if ntile_n % nt:
                 continue
-            for mt in (1, 2, 4, 8):
-                cand = fam << 8 | nt << 4 | mt
+            for mt in (1, 2, 3, 4, 5, 6, 8):
+              for th in (TH if fam > 1 else (0,)):
+                cand = th << 12 | fam << 8 | nt << 4 | mt
                 if lib.rv_conv_fwd(*args, cand, ops.ptr(stats), *tail, st.cuda_stream) != 0:
                     continue
                 t = None
