@@ -65,9 +65,10 @@ def measure_conv_phase(step_fn, device):
 
     import reconvat_amd.ops as ops
     ops.call = spy
-    # the recorded step runs the weight gradients in their immediate form (partial sums + per-layer reduction) so that every
-    # conv launch goes through the spied entry points; the timed step batches those reductions into one launch per chain,
-    # i.e. the conv-phase time below is (slightly) conservative
+    # the recorded step runs the weight gradients in their immediate form so that every conv launch goes through the spied entry
+    # points; they are then TIMED the way the timed step executes them: the partial-sum kernel of each layer
+    # (rv_conv_wgrad_deferred) plus the table launches that run all per-layer reductions of a backward pass at once
+    # (rv_wgrad_reduce_table, one per chain: timed below with every reduction of the step in two tables)
     prev_defer = os.environ.get('RV_DEFER_WGRAD')
     os.environ['RV_DEFER_WGRAD'] = '0'
     try:
@@ -93,6 +94,15 @@ def measure_conv_phase(step_fn, device):
     out = torch.empty_like(big)
     ws = torch.empty(256 * 1024 * 1024 // 4, device=device)
     st = torch.cuda.current_stream()
+    eb = lib.rv_wgrad_table_entry_bytes()
+    entry_scratch = torch.empty(eb, dtype=torch.uint8)
+
+    def deferrable(a):           # mirrors ops.conv_wgrad: accumulating calls, except the 1 -> many 3x3 layer
+        return bool(a[17]) and not (a[0] == 0 and a[5] == 1 and a[10] > 16)
+
+    def deferred_fn(*a):
+        return 0 if lib.rv_conv_wgrad_deferred(*a) > 0 else -1
+
     total_ms, total_flops, per_kernel = 0.0, 0.0, []
     for sig, g in groups.items():
         a = list(g['args'])
@@ -110,6 +120,9 @@ def measure_conv_phase(step_fn, device):
             a[19] = ws.numel() * 4
         a[-1] = st.cuda_stream
         fn = getattr(lib, g['name'])
+        if g['name'] == 'rv_conv_wgrad' and deferrable(a):
+            a = a[:17] + a[18:20] + [entry_scratch.data_ptr(), st.cuda_stream]      # (no `acc`; entry slot before the stream)
+            fn = deferred_fn
         for _ in range(2):
             if fn(*a) != 0:
                 raise RuntimeError(f"{g['name']} {sig}: {_lib.last_error()}")
@@ -125,8 +138,46 @@ def measure_conv_phase(step_fn, device):
         total_ms += ms * g['count']
         total_flops += fl * g['count']
         per_kernel.append((ms * g['count'], g['count'], ms, fl / ms / 1e9, sig))
+    # the batched reductions: every deferrable weight gradient of the step, split over two tables like the two chains of the step
+    wg = [list(r[1]) for r in records if r[0] == 'rv_conv_wgrad' and deferrable(r[1])]
+    ntab = 0
+    if wg:
+        halves = [wg[:len(wg) // 2], wg[len(wg) // 2:]]
+        tables = []
+        off = 0
+        for half in halves:
+            if not half:
+                continue
+            host = torch.empty(len(half) * eb, dtype=torch.uint8)
+            for i, a in enumerate(half):
+                a[1], a[6] = big.data_ptr(), big.data_ptr() + 128 * 1024 * 1024
+                a[12], a[16] = out.data_ptr(), None
+                nbytes = lib.rv_conv_wgrad_workspace_bytes({0: 9, 1: 1, 2: 4}[a[0]], a[11], a[8], a[5], a[10])
+                if (off + nbytes) > ws.numel() * 4:
+                    off = 0                                  # (scratch partial sums may alias: only the timing matters)
+                da = a[:17] + [ws.data_ptr() + off, nbytes, host.data_ptr() + i * eb, st.cuda_stream]
+                off += (nbytes + 255) & ~255
+                if lib.rv_conv_wgrad_deferred(*da) <= 0:
+                    raise RuntimeError('rv_conv_wgrad_deferred: ' + _lib.last_error())
+            total_blocks = lib.rv_wgrad_table_finalize(host.data_ptr(), len(half))
+            tables.append((host.to(device), len(half), total_blocks))
+        torch.cuda.synchronize()
+        for _ in range(2):
+            for t, n, tb in tables:
+                lib.rv_wgrad_reduce_table(t.data_ptr(), n, tb, st.cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(5):
+            for t, n, tb in tables:
+                lib.rv_wgrad_reduce_table(t.data_ptr(), n, tb, st.cuda_stream)
+        e1.record(st)
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        total_ms += ms
+        ntab = len(tables)
+        per_kernel.append((ms, ntab, ms / ntab, 0.0, ('rv_wgrad_reduce_table', f'{len(wg)} reductions in {ntab} launches')))
     per_kernel.sort(reverse=True)
-    return total_ms, total_flops, per_kernel, len(records)
+    return total_ms, total_flops, per_kernel, len(records) + ntab
 
 
 # ---------------------------------------------------------------------------------------------
@@ -417,7 +468,8 @@ def main():
                                  + str(traffic_src),
                 'kernel': 'conv3x3_lds_k / conv_mfma_k / wgrad_mfma_k family (all conv launches of one step)',
                 'conv_ms_source': 'isolated re-launch of every distinct conv launch of one step on scratch operands, HIP events on '
-                                  'the launch stream, after the timed loop (per-kernel figure; the timed step overlaps two chains)',
+                                  'the launch stream, after the timed loop (per-kernel figure; the timed step overlaps two chains); weight gradients '
+                                  'as the step runs them: per-layer partial-sum kernel + the per-chain reduction table launches',
                 'launches_per_step': nlaunch, 'conv_ms_per_step': round(conv_ms, 3),
                 'executed_gflop_per_step': round(conv_flops_total / 1e9, 1),
                 'reference_gflop_per_step': 1531.0,

@@ -30,6 +30,7 @@ SIGNATURES = {
     'rv_pack_table_run': (I, [P, I, L, P]),
     'rv_conv_fwd': (I, [I, P, I, I, I, I, I, P, I, I, I, I, P, P, I, I, P, P, I, P, F, P]),
     'rv_conv_wgrad_workspace_bytes': (L, [I, I, I, I, I]),
+    'rv_conv_wgrad_set_plan': (I, [I, I, I, I, I, I, I]),
     'rv_conv_wgrad': (I, [I, P, I, I, I, I, P, I, I, I, I, I, P, L, L, I, P, I, P, L, P]),
     'rv_conv_wgrad_deferred': (L, [I, P, I, I, I, I, P, I, I, I, I, I, P, L, L, I, P, P, L, P, P]),
     'rv_wgrad_table_entry_bytes': (L, []),

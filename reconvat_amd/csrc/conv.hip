@@ -940,7 +940,9 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
     float* vbuf = smem + NSLOT * UP * CA;                    // [2][Wv4][CB]
     const int stage_floats = NSLOT * UP * CA + 2 * Wv4 * CB;
 
-    const int xg = wave % NXG, hp = wave / NXG;
+    // The waves of one SIMD are wave, wave + 4: with two halves the second half's x groups are rotated by two, so that the x
+    // groups that own one k-step more per row (8/7/7/7 of the 29 steps of a 114-pixel row) do not share a SIMD (-2 % there).
+    const int hp = wave / NXG, xg = (wave + (NH == 2 ? 2 * hp : 0)) % NXG;
     f32x4 acc[TAPS][TAW][TB];
     f32x4 accb[TB];
 #pragma unroll
@@ -1502,7 +1504,7 @@ static int launch_conv3x3_lds(const ConvArgs& a, int R, hipStream_t st, int forc
         for (int k = 0; k < 7; ++k) {
             const int mt = mts[k];
             if (!mt || (force_mt && mt != force_mt)) continue;
-            if (nt * mt > 16 || (nw >= 12 && nt * mt > (nw == 16 ? 8 : 12)) || (nw == 12 && ((mt > 3 && nt > 2) || nt == 3 && mt != 3))) continue;      // accumulator budget (<= 128 registers per wave at 16 waves)
+            if (nt * mt > 16 || (nw >= 12 && nt * mt > (nw == 16 ? 8 : 12)) || (nw == 12 && ((mt > 3 && nt > 2) || (nt == 3 && mt != 3)))) continue;      // accumulator budget (<= 128 registers per wave at 16 waves)
             int th = (mt * 16 * nw) / a.W;                                // nw waves x mt tiles x 16 pixels per band
             if (th > a.H) th = a.H;
             if (force_th) {                                               // fewer rows than the tile slots hold: band-count quantisation
@@ -1778,9 +1780,24 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
 }
 
 // wgrad partitioning shared by the workspace query and the launch
-struct WgradPlan { bool small; int TA, TB, nga, ngb, rows_per_wave, nparts; };
+struct WgradPlan { bool small; int TA, TB, nga, ngb, rows_per_wave, nparts, nw; };
+
+// per-shape launch partition of wgrad_mfma_k chosen by the host autotuner (rv_conv_wgrad_set_plan): waves per workgroup and
+// workgroups on the chip.  Keyed like rv_conv_wgrad_workspace_bytes, whose result depends on it.
+struct WgradTune { int taps, B, Hv, Ca, Cb, nw, wgs; };
+static WgradTune g_wgrad_tune[256];
+static int g_wgrad_ntune = 0;
+static const WgradTune* wgrad_tuned(int taps, int B, int Hv, int Ca, int Cb) {
+    for (int i = 0; i < g_wgrad_ntune; ++i) {
+        const WgradTune& t = g_wgrad_tune[i];
+        if (t.taps == taps && t.B == B && t.Hv == Hv && t.Ca == Ca && t.Cb == Cb) return &t;
+    }
+    return nullptr;
+}
+
 static WgradPlan wgrad_plan(int taps, int B, int Hv, int Ca, int Cb) {
     WgradPlan p;
+    p.nw = 0;
     const int nrows = B * Hv;
     p.small = (Ca * Cb * taps <= 144) && (Ca < 8 || Cb < 8);
     if (p.small) {
@@ -1800,7 +1817,12 @@ static WgradPlan wgrad_plan(int taps, int B, int Hv, int Ca, int Cb) {
     p.nga = cdiv(Ca, p.TA * 16); p.ngb = cdiv(Cb, p.TB * 16);
     static int want_total = 0;
     if (!want_total) { const char* e = getenv("RV_WGRAD_WGS"); want_total = e ? atoi(e) : 256; }
-    int want = want_total / (p.nga * p.ngb);        // one resident workgroup per CU (register-limited): exactly one block wave, no tail
+    int total = want_total;
+    if (const WgradTune* t = wgrad_tuned(taps, B, Hv, Ca, Cb)) {
+        if (t->wgs > 0) total = t->wgs;
+        p.nw = t->nw;
+    }
+    int want = total / (p.nga * p.ngb);        // one resident workgroup per CU (register-limited): exactly one block wave, no tail
     if (want < 4) want = 4;
     if (want > nrows) want = nrows;
     p.rows_per_wave = cdiv(nrows, want);     // rows per WORKGROUP for the LDS-staged kernel
@@ -1812,6 +1834,20 @@ static WgradPlan wgrad_plan(int taps, int B, int Hv, int Ca, int Cb) {
 // a one-channel input against a wide dY (ConvStack layer 0, 1 -> 48) runs as Cb/16 launches of the (1, 16) VALU kernel on
 // 16-channel slices of dY
 static inline bool wgrad_sliced(int taps, int Ca, int Cb) { return taps == 9 && Ca == 1 && Cb > 16 && Cb % 16 == 0; }
+
+// Autotuner hook: the partition rv_conv_wgrad uses for this shape from now on (nw: 4 or 8 waves per workgroup, 0 = default;
+// wgs: workgroups on the chip, 0 = default 256).  Changes what rv_conv_wgrad_workspace_bytes returns for the shape.
+int rv_conv_wgrad_set_plan(int taps, int B, int Hv, int Ca, int Cb, int nw, int wgs) {
+    RV_CHECK_ARG(nw == 0 || nw == 4 || nw == 8, "rv_conv_wgrad_set_plan: nw must be 0, 4 or 8");
+    RV_CHECK_ARG(wgs == 0 || (wgs >= 32 && wgs <= 4096), "rv_conv_wgrad_set_plan: wgs out of range");
+    WgradTune* t = const_cast<WgradTune*>(wgrad_tuned(taps, B, Hv, Ca, Cb));
+    if (!t) {
+        RV_CHECK_ARG(g_wgrad_ntune < 256, "rv_conv_wgrad_set_plan: table full");
+        t = &g_wgrad_tune[g_wgrad_ntune++];
+    }
+    *t = WgradTune{taps, B, Hv, Ca, Cb, nw, wgs};
+    return RV_OK;
+}
 
 long rv_conv_wgrad_workspace_bytes(int taps, int B, int Hv, int Ca, int Cb) {
     if (wgrad_sliced(taps, Ca, Cb)) Cb = 16;
@@ -1913,8 +1949,9 @@ static int conv_wgrad_impl(int mode, const float* U, int u_ld, int Hu, int Wu, i
         const int UP = SS * (Wv4 - 1) + KH;
         const int nslot = SS == 1 ? KH + 1 : 2 * KH;
         size_t lds = ((size_t)nslot * UP * TA * 16 + (size_t)2 * Wv4 * TB * 16) * sizeof(float);
-        static int nw = 0;
-        if (!nw) { const char* e = getenv("RV_WGRAD_NW"); nw = (e && atoi(e) == 4) ? 4 : 8; }
+        static int nw_env = 0;
+        if (!nw_env) { const char* e = getenv("RV_WGRAD_NW"); nw_env = (e && atoi(e) == 4) ? 4 : 8; }
+        const int nw = plan.nw ? plan.nw : nw_env;
         const size_t fold = (size_t)((mode == 0 ? 9 : (mode == 1 ? 1 : 4)) * TA * TB + 2 * TB) * 4 * 64 * sizeof(float);
         if (lds < fold) lds = fold;
         RV_CHECK_ARG(lds <= 160 * 1024, "rv_conv_wgrad: row of %d pixels x %d channels does not fit LDS", Wv, TA * 16);

@@ -459,6 +459,45 @@ class BnLink:
         return self.ws is not None and self.z is not None and tuple(self.z.shape) == tuple(dx.shape)
 
 
+_wgrad_tuned = set()
+
+
+def _tune_wgrad(lib, mode, taps, u, uld, hu, wu, ca, v, vld, hv, wv, cb, bb, w, s_a, s_b, flip):
+    """Per-shape partition of the MFMA weight-gradient kernel (waves per workgroup x workgroups on the chip): the first eager
+    call of a shape times the candidates (HIP events on the launch stream, scratch outputs) and pins the winner in the library
+    (rv_conv_wgrad_set_plan); under hipGraph capture an untuned shape keeps the library default (8 waves, 256 workgroups)."""
+    key = (taps, bb, hv, ca, cb)
+    if not AUTOTUNE or key in _wgrad_tuned or ca * cb * taps <= 144 or ca == 1 or torch.cuda.is_current_stream_capturing():
+        return
+    _wgrad_tuned.add(key)
+    st = torch.cuda.current_stream()
+    dw = torch.empty_like(w)
+    db = torch.empty(cb, device=w.device, dtype=torch.float32)
+    best, choice = None, (0, 0)
+    for nw, wgs in ((8, 256), (8, 512), (4, 256), (4, 512), (8, 128), (8, 1024)):
+        if lib.rv_conv_wgrad_set_plan(taps, bb, hv, ca, cb, nw, wgs) != 0:
+            continue
+        nbytes = lib.rv_conv_wgrad_workspace_bytes(taps, bb, hv, ca, cb)
+        ws = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+        args = (mode, ptr(u), uld, hu, wu, ca, ptr(v), vld, hv, wv, cb, bb, ptr(dw), s_a, s_b, flip, ptr(db), 0, ptr(ws), nbytes,
+                st.cuda_stream)
+        if lib.rv_conv_wgrad(*args) != 0:
+            continue
+        t = None
+        for _rep in range(2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(3):
+                lib.rv_conv_wgrad(*args)
+            e1.record(st)
+            e1.synchronize()
+            dt = e0.elapsed_time(e1)
+            t = dt if t is None else min(t, dt)
+        if best is None or t < best:
+            best, choice = t, (nw, wgs)
+    lib.rv_conv_wgrad_set_plan(taps, bb, hv, ca, cb, *choice)
+
+
 def conv_wgrad(kind, x, dy, w, want_bias=True, dw_acc=None, db_acc=None):
     """(dw, db) in the PyTorch layouts of `w` / bias; with dw_acc/db_acc the results are ADDED into those buffers."""
     bb, h, wd, cin, xld = _geom(x)
@@ -487,6 +526,7 @@ def conv_wgrad(kind, x, dy, w, want_bias=True, dw_acc=None, db_acc=None):
         else:
             s_a, s_b, flip = taps, cin * taps, 0
         bias_ptr = ptr(db)
+    _tune_wgrad(lib, mode, taps, u, uld, hu, wu, ca, v, vld, hv, wv, cb, bb, w, s_a, s_b, flip)
     nbytes = lib.rv_conv_wgrad_workspace_bytes(taps, bb, hv, ca, cb)
     ws = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
     tables = _WGRAD_DEFER[0]
