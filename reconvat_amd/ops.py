@@ -6,6 +6,7 @@ Internal activation layout is NHWC ([B, H=time, W=bins, C]); a tensor handed to 
 slice (view) of a wider buffer -- the pixel stride is taken from ``stride(2)``.
 """
 import os
+import sys
 
 import torch
 from torch.autograd import Function
@@ -402,6 +403,8 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
                     if best is None or t < best:
                         best, algo = t, cand
                 _algo_cache[key] = algo
+                if os.environ.get('RV_TUNE_LOG') and best is not None:
+                    print(f'[tune] conv mode={mode} {cin}->{cout} {h}x{wd} B={bb}: algo={algo:#x} {best / 3 * 1e3:.1f} us', file=sys.stderr)
     call('rv_conv_fwd', *args, algo, ptr(stats), *tail, stream())
 
 
@@ -496,6 +499,8 @@ def _tune_wgrad(lib, mode, taps, u, uld, hu, wu, ca, v, vld, hv, wv, cb, bb, w, 
         if best is None or t < best:
             best, choice = t, (nw, wgs)
     lib.rv_conv_wgrad_set_plan(taps, bb, hv, ca, cb, *choice)
+    if os.environ.get('RV_TUNE_LOG'):
+        print(f'[tune] wgrad taps={taps} {ca}->{cb} {hv}x{wv} B={bb}: nw={choice[0]} wgs={choice[1]} {best / 3 * 1e3:.1f} us', file=sys.stderr)
 
 
 def conv_wgrad(kind, x, dy, w, want_bias=True, dw_acc=None, db_acc=None):
