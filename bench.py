@@ -258,6 +258,10 @@ def measure_families(step_fn, device):
         e1.synchronize()
         ms = e0.elapsed_time(e1) / 5
         fl, by = family_work(g['name'], g['args'])
+        if os.environ.get('RV_FAMILY_VERBOSE'):
+            sig = [v for v in g['args'][:-1] if isinstance(v, (int, float)) and not (isinstance(v, int) and v > (1 << 32))]
+            print(f"[fam] {ms * g['count']:8.3f} ms/step  x{g['count']:3d} {ms * 1e3:8.1f} us  {by / ms / 1e9 if by else fl / ms / 1e9:7.2f} "
+                  f"{'TB/s' if by else 'TF/s'}  {g['name']} {sig}", file=sys.stderr)
         f = fam.setdefault(FAMILY[g['name']], {'ms_per_step': 0.0, 'launches': 0, 'gflop': 0.0, 'gbyte': 0.0})
         f['ms_per_step'] += ms * g['count']
         f['launches'] += g['count']
