@@ -41,7 +41,10 @@ int rv_melspec_lognorm_fwd(const float* audio, long audio_stride, int B, int nsa
  * rv_conv_fwd mode: 0 = 3x3 s1 p1, 1 = 1x1, 2 = 2x2/s2 gather (down fwd, up dgrad), 3 = 2x2/s2 scatter
  *   (ConvTranspose2d(k=2,s=2)(x, output_size=...) fwd, down dgrad).  Forward AND input-gradient of
  *   every layer are instances of it (the packing decides which).  algo: 0 default, 1 LDS-free direct kernel,
- *   2 LDS/DMA-pipelined kernel (3x3 only) -- the host autotunes 1 vs 2 per layer shape.  bn_sums (nullable,
+ *   2 LDS/DMA-pipelined kernel (3x3 only); forced tiles for the host autotuner (ops._conv_call), RV_EUNSUPPORTED when the tile
+ *   does not fit the shape: 0x100|NT<<4|MT direct kernel, 0x200 / 0x300 / 0x400 / 0x700 |NT<<4|MTW LDS kernel with 4 / 8 / 16 /
+ *   12 waves per workgroup (MTW in {3,5,6} for 12 waves: 9/15/18 tiles per SIMD and band), optionally TH<<12 = rows per band
+ *   (<= what the tile slots hold).  bn_sums (nullable,
  *   rv_bn_workspace_bytes(Cout) bytes of fp64 = 8 replicas of [2*Cout] that the consumer adds up, += ): per-channel sum / sum of squares of the written output, i.e. the batch statistics of the
  *   BatchNorm2d that consumes it (conv -> bn call sites, model/UNet_onset.py:196-198,221-223), produced in the conv
  *   epilogue; pass the same buffer to rv_bn_lrelu_fwd as `workspace` with sums_ready = 1.  bn_z (nullable; with
