@@ -11,6 +11,7 @@ gradient all-reduce per step), the fused FlatAdam, optional whole-step hipGraph 
 """
 import json
 import os
+import time
 from datetime import datetime
 
 import numpy as np
@@ -182,6 +183,7 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
             model.train()
             li, ui = cycle(l_loader), (cycle(ul_loader) if use_vat else None)
             total = 0.0
+            t_epoch = time.perf_counter()
             for _ in range(iteration):
                 bl = next(li)
                 bul = next(ui) if use_vat else None
@@ -193,7 +195,7 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
                 step_runner.check()                # VAT NaN assert + BiLSTM time-out flag (the loss read-back just synchronised)
             losses = step_runner.losses
             if rank == 0:
-                print(f'Train Epoch: {ep}\tLoss: {total / iteration:.6f}')
+                print(f'Train Epoch: {ep}\tLoss: {total / iteration:.6f}\t({(time.perf_counter() - t_epoch) / iteration * 1e3:.1f} ms/step)')
         else:
             _, losses, optimizer = train_VAT_model(model, iteration, ep, l_loader, ul_loader if VAT else None, optimizer,
                                                    scheduler, clip_gradient_norm, alpha, VAT, VAT_start)

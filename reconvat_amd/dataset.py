@@ -305,9 +305,28 @@ class SyntheticSegments(Dataset):
 
     def __init__(self, n_items=64, sequence_length=327680, seed=0, device='cpu'):
         self.n, self.sequence_length, self.seed, self.device = n_items, sequence_length, seed, device
+        self._tracks = None
 
     def __len__(self):
         return self.n
+
+    @property
+    def data(self):
+        """The same kind of material as whole TRACKS in the PianoRollAudioDataset layout (int16 audio, uint8 label roll with
+        3 = onset, 2 = frame; each 16 hops longer than a segment), so that the training scripts can keep a synthetic corpus in
+        HBM and crop it with the device feed (reconvat_amd/feed.py) exactly like a real one."""
+        if self._tracks is None:
+            tracks = []
+            steps = self.sequence_length // HOP_LENGTH + 16
+            for index in range(self.n):
+                g = torch.Generator().manual_seed(self.seed * 1000003 + index)
+                audio = ((torch.rand(steps * HOP_LENGTH, generator=g) * 0.2 - 0.1) * 32768.0).round().to(torch.int16)
+                u = torch.rand(steps, N_KEYS, generator=g)
+                label = (2 * (u > 0.95).to(torch.uint8) + (u > 0.99).to(torch.uint8))
+                tracks.append({'path': f'synthetic/{index}', 'audio': audio, 'label': label,
+                               'velocity': torch.zeros_like(label)})
+            self._tracks = tracks
+        return self._tracks
 
     def __getitem__(self, index):
         g = torch.Generator().manual_seed(self.seed * 1000003 + index)
