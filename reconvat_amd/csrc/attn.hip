@@ -19,6 +19,7 @@
 // The head dimension is padded to a multiple of 16 in LDS (229 -> 240, zero filled).  ~0.5 GFLOP per forward, so the
 // kernels are bound by staging the windows (each row is read 46/16 times, from L2).
 #include "common.h"
+#include <stdlib.h>
 
 #define AT_W 31
 #define AT_P 15
@@ -41,13 +42,15 @@ struct AttnArgs {
     float* de;
     int B, L, G, dh, dhp;
     int v4, dv4;                     // 16-byte DMA legal for q/k/v rows / for dout and rel^T rows (stride F)
+    int seq_kv;                      // attn_bwd_kv_k: one window buffer used twice (see the kernel)
 };
 
 // dst[r][f] (r < ntotal, f < dhp) = src[(row0 + r) * ld + col0 + f] for r < nvalid, 0 <= row0 + r < L, f < dh; else 0.
 // Rows travel by LDS-DMA (16 bytes per lane when `v4`: rows 16-byte aligned, else 4): all of a wave's rows are in
 // flight at once and nothing passes through VGPRs; the caller waits (stage_wait) before the barrier.
-__device__ __forceinline__ void stage_rows(float* dst, int ldk, const float* src, long ld, int col0, int dh, int dhp,
-                                           int row0, int nvalid, int ntotal, int L, bool v4) {
+__device__ __forceinline__ int stage_rows(float* dst, int ldk, const float* src, long ld, int col0, int dh, int dhp,
+                                          int row0, int nvalid, int ntotal, int L, bool v4) {
+    int issued = 0;                                                  // DMA instructions of this wave (wave-uniform)
     // Lean on purpose: the kernels are bound by the instructions spent here, not by bytes.  Everything per lane is
     // hoisted (byte offset inside a row, lane mask); per row there is a pointer bump, a range test and the DMA.
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -69,11 +72,13 @@ __device__ __forceinline__ void stage_rows(float* dst, int ldk, const float* src
                 for (int k = 0; k < ninst; ++k)
                     if (k * 64 + lf < dh) glds4(s + k * 64, drow + k * 64);
             }
+            issued += ninst;
             if (lane < npad) drow[dh + lane] = 0.f;                  // npad < 16
         } else {
             for (int f = lane; f < dhp; f += 64) drow[f] = 0.f;
         }
     }
+    return issued;
 }
 __device__ __forceinline__ void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -246,8 +251,12 @@ __global__ __launch_bounds__(AT_NTHR) void attn_bwd_q_k(AttnArgs a) {
 __global__ __launch_bounds__(AT_NTHR) void attn_bwd_kv_k(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int dh = a.dh, dhp = a.dhp, ldk = dhp + 4, nchunk = dhp >> 4, F = a.G * dh;
-    float* Yd = smem;                           // [48][ldk]  dout window
-    float* Yq = Yd + AT_WINP * ldk;             // [48][ldk]  q window
+    // a.seq_kv (wide heads): ONE row-window buffer, used for the dout window (dv) and then for the q window (dk) -- 66 KB
+    // instead of 113 KB of LDS at dh = 229, so that TWO workgroups fit a CU and one's DMA wait hides under the other's MFMAs
+    // (a 5-wave workgroup alone leaves the CU idle through every staging phase: 82 -> 58 us).  Narrow heads (dh = 128) fit
+    // twice either way and keep both windows in flight at once.
+    float* Yd = smem;                           // [48][ldk]  dout window (then q window)
+    float* Yq = a.seq_kv ? Yd : Yd + AT_WINP * ldk;   // [48][ldk]  q window
     float* Ca = Yq + AT_WINP * ldk;             // [48][32]   att window
     float* Ce = Ca + AT_WINP * 32;              // [48][32]   de window
     float* A4 = Ce + AT_WINP * 32;              // [16][52]   transposed band of att
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(AT_NTHR) void attn_bwd_kv_k(AttnArgs a) {
     // everything this tile needs is in flight at once: both row windows and both coefficient windows (a row of the
     // latter is 31 contiguous floats)
     stage_rows(Yd, ldk, a.dout + (long)b * a.L * F, F, g * dh, dh, dhp, s0 - AT_P, AT_WIN, AT_WINP, a.L, a.dv4);
-    stage_rows(Yq, ldk, a.q + (long)b * a.L * a.ld, a.ld, g * dh, dh, dhp, s0 - AT_P, AT_WIN, AT_WINP, a.L, a.v4);
+    if (!a.seq_kv) stage_rows(Yq, ldk, a.q + (long)b * a.L * a.ld, a.ld, g * dh, dh, dhp, s0 - AT_P, AT_WIN, AT_WINP, a.L, a.v4);
     const long cld = (long)a.G * AT_W;
     stage_rows(Ca, 32, a.att + (long)b * a.L * cld, cld, g * AT_W, AT_W, 32, s0 - AT_P, AT_WIN, AT_WINP, a.L, false);
     stage_rows(Ce, 32, a.de_in + (long)b * a.L * cld, cld, g * AT_W, AT_W, 32, s0 - AT_P, AT_WIN, AT_WINP, a.L, false);
@@ -276,6 +285,12 @@ __global__ __launch_bounds__(AT_NTHR) void attn_bwd_kv_k(AttnArgs a) {
     __syncthreads();
     const long orow = ((long)b * a.L + s0) * a.dld;
     apply_tiles<3>(A4, AT_A2LD, Yd, ldk, nchunk, a.dv + orow, a.dld, g * dh, dh, a.L - s0);
+    if (a.seq_kv) {
+        __syncthreads();                        // dout window dead
+        stage_rows(Yq, ldk, a.q + (long)b * a.L * a.ld, a.ld, g * dh, dh, dhp, s0 - AT_P, AT_WIN, AT_WINP, a.L, a.v4);
+        stage_wait();
+        __syncthreads();
+    }
     apply_tiles<3>(A5, AT_A2LD, Yq, ldk, nchunk, a.dk + orow, a.dld, g * dh, dh, a.L - s0);
 }
 
@@ -331,7 +346,9 @@ int rv_local_attn_bwd(const float* dout, const float* q, const float* k, const f
     const size_t lds1 = ((size_t)(AT_TT + 80) * ldk + AT_TT * AT_SLD + AT_TT * AT_A3LD) * sizeof(float);
     hipLaunchKernelGGL(attn_bwd_q_k, dim3(B * ntile, G), dim3(AT_NTHR), lds1, st, a);
     RV_LAUNCH_CHECK("rv_local_attn_bwd(q)");
-    const size_t lds2 = ((size_t)2 * AT_WINP * ldk + 2 * AT_WINP * 32 + 2 * AT_TT * AT_A2LD) * sizeof(float);
+    const size_t lds_two = ((size_t)2 * AT_WINP * ldk + 2 * AT_WINP * 32 + 2 * AT_TT * AT_A2LD) * sizeof(float);
+    a.seq_kv = lds_two > 78 * 1024;            // two windows at once would leave room for only one workgroup per CU
+    const size_t lds2 = lds_two - (a.seq_kv ? (size_t)AT_WINP * ldk * sizeof(float) : 0);
     hipLaunchKernelGGL(attn_bwd_kv_k, dim3(B * ntile, G), dim3(AT_NTHR), lds2, st, a);
     RV_LAUNCH_CHECK("rv_local_attn_bwd(kv)");
     return RV_OK;
