@@ -44,7 +44,11 @@ def test_conv_linearity_and_adjoint_full_size(dev, kind, cin, cout, h, w):
     assert abs(float(dot1 - dot2)) <= 2e-5 * max(abs(float(dot1)), float(lin.abs().max()) * 1e3)
     # weight gradient: <conv_w(x) , v> is linear in w  ->  <w, dw> = <conv(x) - bias, v>
     dotw = (wt.detach().double() * wt.grad.double()).sum()
-    assert abs(float(dotw - dot1)) <= 1e-4 * max(abs(float(dot1)), 1.0)
+    # both sides are fp32 sums over ~3e5 pixels folded in a launch-dependent order (partition tuner, fold tree): each dw element
+    # carries ~1e-6 relative rounding error of random sign, so <w, dw> is uncertain by ~1e-6 * sqrt(sum (w dw)^2); allow five of
+    # those sigmas (gross errors -- a lost row, a wrong tap -- are orders of magnitude above)
+    noise = float((wt.detach().double() * wt.grad.double()).pow(2).sum().sqrt())
+    assert abs(float(dotw - dot1)) <= max(1e-4 * max(abs(float(dot1)), 1.0), 5e-6 * noise), (float(dotw), float(dot1), noise)
     assert rel_err(bias.grad, v.reshape(-1, cout).double().sum(0).float()) < 1e-5
 
 
