@@ -246,6 +246,35 @@ def test_conv_dgrad_fused_bn_backward_reduction(dev, c1, c2, H, W, algo, monkeyp
         assert rel_err(a, b_) < 2e-5
 
 
+@pytest.mark.parametrize('kind,cin,cout,H,W', [('c3', 32, 32, 24, 57), ('c3', 48, 24, 17, 114), ('c1', 16, 32, 30, 28), ('down', 16, 16, 22, 38)])
+def test_wgrad_partition_plans_agree(dev, kind, cin, cout, H, W):
+    """rv_conv_wgrad_set_plan (the weight-gradient partition the autotuner pins per shape): every plan -- 4 or 8 waves per
+    workgroup, 128 .. 1024 workgroups -- must give the torch weight / bias gradient to fp32 rounding, and the default again
+    after the plan is cleared."""
+    from reconvat_amd import ops, _lib
+    lib = _lib.load()
+    B = 3
+    x = rnd(B, cin, H, W, seed=1)
+    stride, ksz = (2, 2) if kind == 'down' else (1, 3 if kind == 'c3' else 1)
+    w = rnd(cout, cin, ksz, ksz, seed=2, scale=0.2).requires_grad_(True)
+    b = rnd(cout, seed=3).requires_grad_(True)
+    y = F.conv2d(x, w, b, stride=stride, padding=1 if kind == 'c3' else 0)
+    cot = rnd(*y.shape, seed=4)
+    (y * cot).sum().backward()
+    xg, dyg, wg = nhwc(x).to(dev), nhwc(cot).to(dev), w.detach().to(dev)
+    taps = ksz * ksz
+    ho, wo = y.shape[2], y.shape[3]
+    try:
+        for nw, wgs in ((0, 0), (4, 128), (4, 512), (8, 256), (8, 1024), (0, 0)):
+            assert lib.rv_conv_wgrad_set_plan(taps, B, ho, cin, cout, nw, wgs) == 0
+            dw, db = ops.conv_wgrad(kind, xg, dyg, wg)
+            assert rel_err(dw, w.grad) < TOL_G, (nw, wgs)
+            assert rel_err(db, b.grad) < TOL_G, (nw, wgs)
+    finally:
+        lib.rv_conv_wgrad_set_plan(taps, B, ho, cin, cout, 0, 0)
+    assert lib.rv_conv_wgrad_set_plan(taps, B, ho, cin, cout, 3, 0) != 0          # waves must be 0 / 4 / 8
+
+
 @pytest.mark.parametrize('M,K,N,act', [(130, 229, 88, 1), (257, 176, 768, 0), (64, 768, 88, 1), (200, 916, 229, 1), (96, 88, 916, 0)])
 def test_linear(dev, M, K, N, act):
     from reconvat_amd import ops
