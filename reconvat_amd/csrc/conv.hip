@@ -663,6 +663,7 @@ struct SmallArgs {
     int accumulate;
     FastDiv fd_plane, fd_wo;   // divide by Ho*Wo, by Wo (npix * COUT/4 < 2^31)
     double* bn_sums;           // optional fused BatchNorm statistics of the output (COUT >= 4 instances)
+    int rows;                  // conv_narrow_out_k: output rows a workgroup walks down its column strip
 };
 
 // COUT >= 4: four output channels per thread (COUT/4 threads per pixel) so that a wave's stores are
@@ -684,12 +685,15 @@ __host__ __device__ constexpr int small_cpt(int cin, int cout, int taps) {
 // its quad in registers, and the per-pixel sum is two xor-shuffles over the quad lanes.
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void conv_narrow_out_k(SmallArgs a) {
+    // A workgroup owns a strip of 256 / LPP pixel columns and walks a.rows output rows down it with a SLIDING 3-row window
+    // in registers: per output row a lane loads only the three quads of the new bottom row (the other six move up), so every
+    // input quad is requested 3 times instead of 9 -- and by the same CU.  (A flat grid-stride loop over pixels put the rows
+    // above / below a pixel on other XCDs: the L2s fetched the input 2.6x from HBM, profiles/r02_pmc_traffic.json.)
     constexpr int LPP = CIN / 4;                     // lanes per pixel
     static_assert(LPP == 2 || LPP == 4, "quad lanes must divide the wave");
-    const unsigned tstride = gridDim.x * blockDim.x;          // a multiple of LPP: a lane's quad never changes
-    unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned tend = (unsigned)a.npix * LPP;
-    const int q = (int)(t % LPP);
+    constexpr int PXW = 256 / LPP;                   // pixel columns per workgroup
+    const int q = (int)(threadIdx.x % LPP);
+    const int col = (int)(threadIdx.x / LPP);
     float w[9][4][COUT];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
@@ -700,47 +704,65 @@ __global__ __launch_bounds__(256) void conv_narrow_out_k(SmallArgs a) {
     float bias[COUT];
 #pragma unroll
     for (int co = 0; co < COUT; ++co) bias[co] = a.bias ? a.bias[co] : 0.f;
-    // the wave's tail lanes stay in the loop (the shuffles need the whole quad): they compute pixel npix-1 and do not store
-    const unsigned tlast = (tend + 63) & ~63u;
-    for (; t < tlast; t += tstride) {
-        const bool live = t < tend;
-        const unsigned p = live ? t / LPP : (unsigned)a.npix - 1;
-        const int b = (int)fastdiv(p, a.fd_plane);
-        const unsigned rem = p - (unsigned)b * (unsigned)(a.Ho * a.Wo);
-        const int oy = (int)fastdiv(rem, a.fd_wo), ox = (int)rem - oy * a.Wo;
-        const float* centre = a.in + (((long)b * a.H + oy) * a.W + ox) * a.in_ld + 4 * q;
+    const int nstrip = (a.W + PXW - 1) / PXW;
+    const int nband = (a.H + a.rows - 1) / a.rows;
+    // blockIdx -> (image, row band, column strip), strips fastest: neighbouring strips (shared halo columns) and bands follow
+    int bid = blockIdx.x;
+    const int strip = bid % nstrip; bid /= nstrip;
+    const int band = bid % nband;
+    const int b = bid / nband;
+    const int ox = strip * PXW + col;
+    const bool colok = ox < a.W;                      // lanes past the row end stay in the loop (shuffles) and do not store
+    const int y0 = band * a.rows, y1 = min(y0 + a.rows, a.H);
+    const int cx[3] = {min(max(ox - 1, 0), a.W - 1), min(ox, a.W - 1), min(ox + 1, a.W - 1)};
+    const bool okx[3] = {ox - 1 >= 0 && ox - 1 < a.W, colok, ox + 1 < a.W};
+    const float* img = a.in + (long)b * a.H * a.W * a.in_ld + 4 * q;
+    auto load_raw = [&](f32x4 (&r)[3], int iy) {     // the three quads of input row iy (clamped address: always a valid load)
+        const float* rowp = img + (long)min(max(iy, 0), a.H - 1) * a.W * a.in_ld;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) r[kx] = *reinterpret_cast<const f32x4*>(rowp + (long)cx[kx] * a.in_ld);
+    };
+    auto mask_row = [&](f32x4 (&r)[3], int iy) {     // taps outside the image become zero (applied when the row is first used)
+        const bool oky = iy >= 0 && iy < a.H;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r[kx][c] = (oky && okx[kx]) ? r[kx][c] : 0.f;
+    };
+    f32x4 win[3][3], nxt[3];                          // rows oy-1, oy, oy+1; nxt = row oy+2 in flight under the FMAs of row oy
+    load_raw(win[0], y0 - 1);
+    load_raw(win[1], y0);
+    load_raw(win[2], y0 + 1);
+    mask_row(win[0], y0 - 1);
+    mask_row(win[1], y0);
+    mask_row(win[2], y0 + 1);
+    for (int oy = y0; oy < y1; ++oy) {
+        load_raw(nxt, oy + 2);
         float acc[COUT];
 #pragma unroll
         for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
-        f32x4 x[9];
-        bool ok[9];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {                   // all nine loads in flight; out-of-image taps read a clamped address
-            const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
-            ok[tap] = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const int cy = min(max(iy, 0), a.H - 1) - oy, cx = min(max(ix, 0), a.W - 1) - ox;
-            x[tap] = *reinterpret_cast<const f32x4*>(centre + (cy * a.W + cx) * a.in_ld);
-        }
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+            for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float v = ok[tap] ? x[tap][c] : 0.f;
+                for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(v, w[tap][c][co], acc[co]);
-            }
-        }
+                    for (int co = 0; co < COUT; ++co) acc[co] = fmaf(win[ky][kx][c], w[ky * 3 + kx][c][co], acc[co]);
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
 #pragma unroll
             for (int d = 1; d < LPP; d <<= 1) acc[co] += __shfl_xor(acc[co], d, 64);
             acc[co] += bias[co];
         }
-        if (live && q == 0) {
-            float* o = a.out + (long)p * a.out_ld;
+        if (colok && q == 0) {
+            float* o = a.out + (((long)b * a.H + oy) * a.W + ox) * a.out_ld;
 #pragma unroll
             for (int co = 0; co < COUT; ++co) o[co] = a.accumulate ? o[co] + acc[co] : acc[co];
         }
+        mask_row(nxt, oy + 2);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) { win[0][kx] = win[1][kx]; win[1][kx] = win[2][kx]; win[2][kx] = nxt[kx]; }
     }
 }
 
@@ -1704,8 +1726,9 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
 #define RV_NARROW(ci, co)                                                                         \
     if (mode == 0 && Cin == ci && Cout == co && (in_ld & 3) == 0 && ((((uintptr_t)in) & 15) == 0)) { \
         RV_CHECK_ARG(s.npix < (1L << 28), "rv_conv_fwd: more than 2^28 pixels");                \
-        long nb = cdiv(s.npix * (ci / 4), 256);                                                  \
-        if (nb > 4096) nb = 4096;                                                                \
+        static const int nrows_env = getenv("RV_NARROW_ROWS") ? atoi(getenv("RV_NARROW_ROWS")) : 16;   \
+        s.rows = nrows_env;                                                                      \
+        const long nb = (long)B * cdiv(H, s.rows) * cdiv(W, 256 / (ci / 4));                     \
         hipLaunchKernelGGL((conv_narrow_out_k<ci, co>), dim3((unsigned)nb), blk, 0, st, s);      \
         RV_LAUNCH_CHECK("conv_narrow_out");                                                      \
         return RV_OK;                                                                            \
