@@ -1331,6 +1331,104 @@ __global__ __launch_bounds__(256) void wgrad_small_k(WgradArgs a) {
     }
 }
 
+// 3x3 weight gradient of the 8 -> 1 / 8 -> 2 layers with the same locality as conv_narrow_out_k: a WAVE owns a strip of 32 pixel
+// columns (2 lanes per pixel, one channel quad of U each) and walks `rows` rows down it with a sliding 3-row window of U in
+// registers -- every U quad is requested 3 times by one CU instead of 9 times from flat pixel runs that put a pixel's vertical
+// neighbours on other XCDs (wgrad_small_k: 1.2 GB fetched per step for 0.6 GB of operands).  One partial per wave.
+template <int CB>
+__global__ __launch_bounds__(256) void wgrad_small_sw_k(WgradArgs a, int rows, int nstrip, int nband) {
+    constexpr int CA = 8, LPP = 2, PXW = 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane % LPP, col = lane / LPP;
+    const int pw = blockIdx.x * 4 + wave;
+    if (pw >= a.nparts) return;
+    int id = pw;
+    const int strip = id % nstrip; id /= nstrip;
+    const int band = id % nband;
+    const int b = id / nband;
+    const int x = strip * PXW + col;
+    const bool colok = x < a.Wv;
+    const int y0 = band * rows, y1 = min(y0 + rows, a.Hv);
+    const int cx[3] = {min(max(x - 1, 0), a.Wu - 1), min(x, a.Wu - 1), min(x + 1, a.Wu - 1)};
+    const bool okx[3] = {colok && x - 1 >= 0, colok, colok && x + 1 < a.Wu};
+    const float* img = a.U + (long)b * a.Hu * a.Wu * a.u_ld + 4 * q;
+    const float* vimg = a.V + (long)b * a.Hv * a.Wv * a.v_ld;
+    float acc[9][4][CB], accb[CB];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) acc[t][c][cb] = 0.f;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) accb[cb] = 0.f;
+    auto load_raw = [&](f32x4 (&r)[3], int iy) {
+        const float* rowp = img + (long)min(max(iy, 0), a.Hu - 1) * a.Wu * a.u_ld;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) r[kx] = *reinterpret_cast<const f32x4*>(rowp + (long)cx[kx] * a.u_ld);
+    };
+    auto mask_row = [&](f32x4 (&r)[3], int iy) {
+        const bool oky = iy >= 0 && iy < a.Hu;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r[kx][c] = (oky && okx[kx]) ? r[kx][c] : 0.f;
+    };
+    auto load_v = [&](float (&v)[CB], int y) {
+        const float* vp = vimg + ((long)min(y, a.Hv - 1) * a.Wv + min(x, a.Wv - 1)) * a.v_ld;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) v[cb] = vp[cb];
+    };
+    f32x4 win[3][3], nxt[3];
+    float v[CB], vn[CB];
+    load_raw(win[0], y0 - 1); load_raw(win[1], y0); load_raw(win[2], y0 + 1);
+    load_v(v, y0);
+    mask_row(win[0], y0 - 1); mask_row(win[1], y0); mask_row(win[2], y0 + 1);
+    for (int y = y0; y < y1; ++y) {
+        load_raw(nxt, y + 2);
+        load_v(vn, y + 1);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const float vv = colok ? v[cb] : 0.f;
+            if (q == 0) accb[cb] += vv;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[ky * 3 + kx][c][cb] = fmaf(win[ky][kx][c], vv, acc[ky * 3 + kx][c][cb]);
+        }
+        mask_row(nxt, y + 2);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) { win[0][kx] = win[1][kx]; win[1][kx] = win[2][kx]; win[2][kx] = nxt[kx]; }
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) v[cb] = vn[cb];
+    }
+    // fold the 32 pixel columns of the wave (lanes with the same channel quad): xor over the lane bits above log2(LPP)
+    auto fold = [&](float s_) {
+#pragma unroll
+        for (int o = 32; o >= LPP; o >>= 1) s_ += __shfl_xor(s_, o, 64);
+        return s_;
+    };
+    float* dst = a.part + (long)pw * a.pstride;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const float s_ = fold(acc[t][c][cb]);
+                if (col == 0) dst[((long)t * CA + 4 * q + c) * CB + cb] = s_;
+            }
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        float s_ = accb[cb];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s_ += __shfl_xor(s_, o, 64);
+        if (lane == 0 && a.want_bias) dst[(long)9 * CA * CB + cb] = s_;
+    }
+}
+
 // fold the per-wave partials and scatter into the PyTorch weight layout
 struct WreduceArgs {
     const float* part; long pstride; int nparts;
@@ -1962,6 +2060,21 @@ static int conv_wgrad_impl(int mode, const float* U, int u_ld, int Hu, int Wu, i
         hipLaunchKernelGGL((wgrad_small_k<ca, cb, kh, kw, ss, pp>), grid, blk, 0, st, a);        \
         goto reduce;                                                                             \
     }
+        if (mode == 0 && Ca == 8 && (Cb == 1 || Cb == 2) && (u_ld & 3) == 0 && ((((uintptr_t)U) & 15) == 0) && Hu == Hv && Wu == Wv) {
+            // sliding-window kernel: one partial per wave = (image, band of `rows` rows, strip of 32 columns)
+            static const int sw_env = getenv("RV_WGRAD_SW") ? atoi(getenv("RV_WGRAD_SW")) : 1;
+            if (sw_env) {
+                const int nstrip = cdiv(Wv, 32);
+                int rows = 16;
+                while ((long)B * cdiv(Hv, rows) * nstrip > plan.nparts) rows *= 2;       // the workspace holds plan.nparts partials
+                const int nband = cdiv(Hv, rows);
+                a.nparts = B * nband * nstrip;
+                dim3 g2(cdiv(a.nparts, 4));
+                if (Cb == 2) hipLaunchKernelGGL((wgrad_small_sw_k<2>), g2, blk, 0, st, a, rows, nstrip, nband);
+                else hipLaunchKernelGGL((wgrad_small_sw_k<1>), g2, blk, 0, st, a, rows, nstrip, nband);
+                goto reduce;
+            }
+        }
         if (mode == 0) { RV_WS(1, 16, 3, 3, 1, 1) RV_WS(8, 2, 3, 3, 1, 1) RV_WS(8, 1, 3, 3, 1, 1) }
         else if (mode == 1) { RV_WS(1, 16, 1, 1, 1, 0) }
 #undef RV_WS
