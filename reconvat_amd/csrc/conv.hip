@@ -766,6 +766,95 @@ __global__ __launch_bounds__(256) void conv_narrow_out_k(SmallArgs a) {
     }
 }
 
+// 3x3 convolution of a ONE-channel input (the first encoder layer 1 -> 16, 1 -> 8): COUT / 4 lanes per pixel, each owning four
+// output channels with its 36 weights in registers; a workgroup walks a.rows output rows down a strip of 1024 / COUT pixel columns
+// with a sliding 3-row window of the input (three new values per row, shared by the lanes of a pixel), so a wave's stores are
+// 1 KiB contiguous without an LDS transpose and the taps cost 3 loads per pixel instead of 9.  Fused BatchNorm statistics as
+// in conv_small_k (per-lane sums -> pixel lanes by xor shuffles -> waves through LDS -> one fp64 atomic per channel and workgroup).
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_cin1_k(SmallArgs a) {
+    constexpr int LPP = COUT / 4;                    // lanes per pixel
+    constexpr int PXW = 256 / LPP;                   // pixel columns per workgroup
+    const int q = (int)(threadIdx.x % LPP);
+    const int col = (int)(threadIdx.x / LPP);
+    float w[9][4];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[tap][c] = a.wplain[tap * COUT + 4 * q + c];
+    f32x4 bias = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + 4 * q);
+    const int nstrip = (a.W + PXW - 1) / PXW;
+    const int nband = (a.H + a.rows - 1) / a.rows;
+    int bid = blockIdx.x;
+    const int strip = bid % nstrip; bid /= nstrip;
+    const int band = bid % nband;
+    const int b = bid / nband;
+    const int ox = strip * PXW + col;
+    const bool colok = ox < a.W;
+    const int y0 = band * a.rows, y1 = min(y0 + a.rows, a.H);
+    const int cx[3] = {min(max(ox - 1, 0), a.W - 1), min(ox, a.W - 1), min(ox + 1, a.W - 1)};
+    const bool okx[3] = {ox - 1 >= 0 && ox - 1 < a.W, colok, ox + 1 < a.W};
+    const float* img = a.in + (long)b * a.H * a.W * a.in_ld;
+    auto load_raw = [&](float (&r)[3], int iy) {
+        const float* rowp = img + (long)min(max(iy, 0), a.H - 1) * a.W * a.in_ld;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) r[kx] = rowp[(long)cx[kx] * a.in_ld];
+    };
+    auto mask_row = [&](float (&r)[3], int iy) {
+        const bool oky = iy >= 0 && iy < a.H;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) r[kx] = (oky && okx[kx]) ? r[kx] : 0.f;
+    };
+    float win[3][3], nxt[3];
+    load_raw(win[0], y0 - 1); load_raw(win[1], y0); load_raw(win[2], y0 + 1);
+    mask_row(win[0], y0 - 1); mask_row(win[1], y0); mask_row(win[2], y0 + 1);
+    f32x4 st1 = (f32x4){0.f, 0.f, 0.f, 0.f}, st2 = st1;
+    const bool vec = (a.out_ld & 3) == 0 && ((((uintptr_t)a.out) & 15) == 0);
+    for (int oy = y0; oy < y1; ++oy) {
+        load_raw(nxt, oy + 2);
+        f32x4 acc = bias;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = fmaf(win[ky][kx], w[ky * 3 + kx][c], acc[c]);
+        if (colok) {
+            float* o = a.out + (((long)b * a.H + oy) * a.W + ox) * a.out_ld + 4 * q;
+            if (vec) {
+                if (a.accumulate) acc += *reinterpret_cast<const f32x4*>(o);
+                *reinterpret_cast<f32x4*>(o) = acc;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { if (a.accumulate) acc[c] += o[c]; o[c] = acc[c]; }
+            }
+            st1 += acc;
+            st2 += acc * acc;
+        }
+        mask_row(nxt, oy + 2);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) { win[0][kx] = win[1][kx]; win[1][kx] = win[2][kx]; win[2][kx] = nxt[kx]; }
+    }
+    if (a.bn_sums) {
+        __shared__ float red[4][COUT * 2];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float u = st1[c], v = st2[c];
+#pragma unroll
+            for (int o = 32; o >= LPP; o >>= 1) { u += __shfl_xor(u, o, 64); v += __shfl_xor(v, o, 64); }
+            if (lane < LPP) { red[wave][(4 * q + c) * 2] = u; red[wave][(4 * q + c) * 2 + 1] = v; }
+        }
+        __syncthreads();
+        if (threadIdx.x < COUT * 2) {
+            const int ch = threadIdx.x >> 1, which = threadIdx.x & 1;
+            const double d = (double)red[0][threadIdx.x] + (double)red[1][threadIdx.x] + (double)red[2][threadIdx.x] + (double)red[3][threadIdx.x];
+            atomicAdd(&a.bn_sums[(blockIdx.x % RV_BN_NREP) * 2 * COUT + which * COUT + ch], d);
+        }
+    }
+}
+
 template <int CIN, int COUT, int KH, int KW, int S, int P>
 __global__ __launch_bounds__(256) void conv_small_k(SmallArgs a) {
     constexpr int CPT = small_cpt(CIN, COUT, KH * KW);   // output channels per thread
@@ -1833,6 +1922,15 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
     }
         RV_NARROW(16, 1) RV_NARROW(8, 2) RV_NARROW(8, 1)
 #undef RV_NARROW
+        static const int cin1_env = getenv("RV_CONV_CIN1") ? atoi(getenv("RV_CONV_CIN1")) : 1;
+        if (cin1_env && mode == 0 && Cin == 1 && (Cout == 16 || Cout == 8) && (!bias || ((((uintptr_t)bias) & 15) == 0))) {
+            s.rows = 16;
+            const long nb = (long)B * cdiv(H, s.rows) * cdiv(W, 1024 / Cout);
+            if (Cout == 16) hipLaunchKernelGGL((conv_cin1_k<16>), dim3((unsigned)nb), blk, 0, st, s);
+            else hipLaunchKernelGGL((conv_cin1_k<8>), dim3((unsigned)nb), blk, 0, st, s);
+            RV_LAUNCH_CHECK("conv_cin1");
+            return RV_OK;
+        }
         if (mode == 0) {
             RV_SMALL(1, 16, 3, 3, 1, 1) RV_SMALL(16, 1, 3, 3, 1, 1)
             RV_SMALL(8, 2, 3, 3, 1, 1)  RV_SMALL(2, 8, 3, 3, 1, 1)
