@@ -1518,6 +1518,80 @@ __global__ __launch_bounds__(256) void wgrad_small_sw_k(WgradArgs a, int rows, i
     }
 }
 
+// 3x3 weight gradient of the one-channel-input layer (1 -> 16): 4 lanes per pixel, each owning a channel quad of V (= dY) and the
+// 9 x 4 sums against the sliding 3-row window of the one-channel U; a wave owns a strip of 16 pixel columns.  Same locality
+// argument as wgrad_small_sw_k; V is read with 16-byte loads, 1 KiB contiguous per wave instruction.
+__global__ __launch_bounds__(256) void wgrad_cin1_k(WgradArgs a, int rows, int nstrip, int nband) {
+    constexpr int CB = 16, LPP = 4, PXW = 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane % LPP, col = lane / LPP;
+    const int pw = blockIdx.x * 4 + wave;
+    if (pw >= a.nparts) return;
+    int id = pw;
+    const int strip = id % nstrip; id /= nstrip;
+    const int band = id % nband;
+    const int b = id / nband;
+    const int x = strip * PXW + col;
+    const bool colok = x < a.Wv;
+    const int y0 = band * rows, y1 = min(y0 + rows, a.Hv);
+    const int cx[3] = {min(max(x - 1, 0), a.Wu - 1), min(x, a.Wu - 1), min(x + 1, a.Wu - 1)};
+    const bool okx[3] = {colok && x - 1 >= 0, colok, colok && x + 1 < a.Wu};
+    const float* img = a.U + (long)b * a.Hu * a.Wu * a.u_ld;
+    const float* vimg = a.V + (long)b * a.Hv * a.Wv * a.v_ld + 4 * q;
+    f32x4 acc[9], accb = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto load_raw = [&](float (&r)[3], int iy) {
+        const float* rowp = img + (long)min(max(iy, 0), a.Hu - 1) * a.Wu * a.u_ld;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) r[kx] = rowp[(long)cx[kx] * a.u_ld];
+    };
+    auto mask_row = [&](float (&r)[3], int iy) {
+        const bool oky = iy >= 0 && iy < a.Hu;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) r[kx] = (oky && okx[kx]) ? r[kx] : 0.f;
+    };
+    auto load_v = [&](int y) -> f32x4 {
+        return *reinterpret_cast<const f32x4*>(vimg + ((long)min(y, a.Hv - 1) * a.Wv + min(x, a.Wv - 1)) * a.v_ld);
+    };
+    float win[3][3], nxt[3];
+    load_raw(win[0], y0 - 1); load_raw(win[1], y0); load_raw(win[2], y0 + 1);
+    f32x4 v = load_v(y0);
+    mask_row(win[0], y0 - 1); mask_row(win[1], y0); mask_row(win[2], y0 + 1);
+    for (int y = y0; y < y1; ++y) {
+        load_raw(nxt, y + 2);
+        const f32x4 vn = load_v(y + 1);
+        const f32x4 vv = colok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        accb += vv;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] += vv * win[ky][kx];
+        mask_row(nxt, y + 2);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) { win[0][kx] = win[1][kx]; win[1][kx] = win[2][kx]; win[2][kx] = nxt[kx]; }
+        v = vn;
+    }
+    auto fold = [&](float s_) {                       // over the 16 pixel columns of the wave (lanes with the same quad)
+#pragma unroll
+        for (int o = 32; o >= LPP; o >>= 1) s_ += __shfl_xor(s_, o, 64);
+        return s_;
+    };
+    float* dst = a.part + (long)pw * a.pstride;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float s_ = fold(acc[t][c]);
+            if (col == 0) dst[(long)t * CB + 4 * q + c] = s_;
+        }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float s_ = fold(accb[c]);
+        if (col == 0 && a.want_bias) dst[(long)9 * CB + 4 * q + c] = s_;
+    }
+}
+
 // fold the per-wave partials and scatter into the PyTorch weight layout
 struct WreduceArgs {
     const float* part; long pstride; int nparts;
@@ -2164,13 +2238,29 @@ static int conv_wgrad_impl(int mode, const float* U, int u_ld, int Hu, int Wu, i
             if (sw_env) {
                 const int nstrip = cdiv(Wv, 32);
                 int rows = 16;
-                while ((long)B * cdiv(Hv, rows) * nstrip > plan.nparts) rows *= 2;       // the workspace holds plan.nparts partials
+                while (rows < Hv && (long)B * cdiv(Hv, rows) * nstrip > plan.nparts) rows *= 2;   // the workspace holds plan.nparts partials
                 const int nband = cdiv(Hv, rows);
-                a.nparts = B * nband * nstrip;
-                dim3 g2(cdiv(a.nparts, 4));
-                if (Cb == 2) hipLaunchKernelGGL((wgrad_small_sw_k<2>), g2, blk, 0, st, a, rows, nstrip, nband);
-                else hipLaunchKernelGGL((wgrad_small_sw_k<1>), g2, blk, 0, st, a, rows, nstrip, nband);
-                goto reduce;
+                if ((long)B * nband * nstrip <= plan.nparts) {          // (tiny images: the flat kernel below)
+                    a.nparts = B * nband * nstrip;
+                    dim3 g2(cdiv(a.nparts, 4));
+                    if (Cb == 2) hipLaunchKernelGGL((wgrad_small_sw_k<2>), g2, blk, 0, st, a, rows, nstrip, nband);
+                    else hipLaunchKernelGGL((wgrad_small_sw_k<1>), g2, blk, 0, st, a, rows, nstrip, nband);
+                    goto reduce;
+                }
+            }
+        }
+        if (mode == 0 && Ca == 1 && Cb == 16 && (v_ld & 3) == 0 && ((((uintptr_t)V) & 15) == 0) && Hu == Hv && Wu == Wv) {
+            static const int c1_env = getenv("RV_WGRAD_SW") ? atoi(getenv("RV_WGRAD_SW")) : 1;
+            if (c1_env) {
+                const int nstrip = cdiv(Wv, 16);
+                int rows = 32;
+                while (rows < Hv && (long)B * cdiv(Hv, rows) * nstrip > plan.nparts) rows *= 2;
+                const int nband = cdiv(Hv, rows);
+                if ((long)B * nband * nstrip <= plan.nparts) {
+                    a.nparts = B * nband * nstrip;
+                    hipLaunchKernelGGL(wgrad_cin1_k, dim3(cdiv(a.nparts, 4)), blk, 0, st, a, rows, nstrip, nband);
+                    goto reduce;
+                }
             }
         }
         if (mode == 0) { RV_WS(1, 16, 3, 3, 1, 1) RV_WS(8, 2, 3, 3, 1, 1) RV_WS(8, 1, 3, 3, 1, 1) }
