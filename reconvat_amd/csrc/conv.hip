@@ -663,7 +663,8 @@ struct SmallArgs {
     int accumulate;
     FastDiv fd_plane, fd_wo;   // divide by Ho*Wo, by Wo (npix * COUT/4 < 2^31)
     double* bn_sums;           // optional fused BatchNorm statistics of the output (COUT >= 4 instances)
-    int rows;                  // conv_narrow_out_k: output rows a workgroup walks down its column strip
+    int rows;                  // conv_narrow_out_k / conv_cin12_k: output rows a workgroup walks down its column strip
+    const float* bn_z; int bn_z_ld; const float* bn_coef; float bn_slope;    // conv_cin12_k: fused BatchNorm backward reduction
 };
 
 // COUT >= 4: four output channels per thread (COUT/4 threads per pixel) so that a wave's stores are
@@ -766,22 +767,26 @@ __global__ __launch_bounds__(256) void conv_narrow_out_k(SmallArgs a) {
     }
 }
 
-// 3x3 convolution of a ONE-channel input (the first encoder layer 1 -> 16, 1 -> 8): COUT / 4 lanes per pixel, each owning four
-// output channels with its 36 weights in registers; a workgroup walks a.rows output rows down a strip of 1024 / COUT pixel columns
-// with a sliding 3-row window of the input (three new values per row, shared by the lanes of a pixel), so a wave's stores are
-// 1 KiB contiguous without an LDS transpose and the taps cost 3 loads per pixel instead of 9.  Fused BatchNorm statistics as
-// in conv_small_k (per-lane sums -> pixel lanes by xor shuffles -> waves through LDS -> one fp64 atomic per channel and workgroup).
-template <int COUT>
-__global__ __launch_bounds__(256) void conv_cin1_k(SmallArgs a) {
+// 3x3 convolution of a ONE- or TWO-channel input (the first encoder layer 1 -> 16 / 1 -> 8, the input gradient 2 -> 8 of the last
+// decoder layer): COUT / 4 lanes per pixel, each owning four output channels with its 36 (72) weights in registers; a workgroup walks
+// a.rows output rows down a strip of 1024 / COUT pixel columns with a sliding 3-row window of the input (three new pixels per row,
+// shared by the lanes of a pixel), so a wave's stores are 1 KiB contiguous without an LDS transpose and the taps cost 3 loads per
+// pixel instead of 9.  Fused BatchNorm statistics of the output (per-lane sums -> pixel lanes by xor shuffles -> waves through LDS
+// -> one fp64 atomic per channel and workgroup); with a.bn_z the sums are the BACKWARD reduction of the BatchNorm whose output
+// gradient this conv produces (z of the next row prefetched like the input), which saves the standalone pass over dx and z.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv_cin12_k(SmallArgs a) {
     constexpr int LPP = COUT / 4;                    // lanes per pixel
     constexpr int PXW = 256 / LPP;                   // pixel columns per workgroup
     const int q = (int)(threadIdx.x % LPP);
     const int col = (int)(threadIdx.x / LPP);
-    float w[9][4];
+    float w[9][CIN][4];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) w[tap][c] = a.wplain[tap * COUT + 4 * q + c];
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w[tap][ci][c] = a.wplain[(tap * CIN + ci) * COUT + 4 * q + c];
     f32x4 bias = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + 4 * q);
     const int nstrip = (a.W + PXW - 1) / PXW;
@@ -796,30 +801,55 @@ __global__ __launch_bounds__(256) void conv_cin1_k(SmallArgs a) {
     const int cx[3] = {min(max(ox - 1, 0), a.W - 1), min(ox, a.W - 1), min(ox + 1, a.W - 1)};
     const bool okx[3] = {ox - 1 >= 0 && ox - 1 < a.W, colok, ox + 1 < a.W};
     const float* img = a.in + (long)b * a.H * a.W * a.in_ld;
-    auto load_raw = [&](float (&r)[3], int iy) {
+    auto load_raw = [&](float (&r)[3][CIN], int iy) {
         const float* rowp = img + (long)min(max(iy, 0), a.H - 1) * a.W * a.in_ld;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) r[kx] = rowp[(long)cx[kx] * a.in_ld];
+        for (int kx = 0; kx < 3; ++kx) {
+            if constexpr (CIN == 2) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(rowp + (long)cx[kx] * a.in_ld);
+                r[kx][0] = v[0]; r[kx][1] = v[1];
+            } else {
+                r[kx][0] = rowp[(long)cx[kx] * a.in_ld];
+            }
+        }
     };
-    auto mask_row = [&](float (&r)[3], int iy) {
+    auto mask_row = [&](float (&r)[3][CIN], int iy) {
         const bool oky = iy >= 0 && iy < a.H;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) r[kx] = (oky && okx[kx]) ? r[kx] : 0.f;
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) r[kx][ci] = (oky && okx[kx]) ? r[kx][ci] : 0.f;
     };
-    float win[3][3], nxt[3];
+    const bool bwd = a.bn_z != nullptr;
+    f32x4 c_mean = (f32x4){0.f, 0.f, 0.f, 0.f}, c_inv = c_mean, c_sc = c_mean, c_sh = c_mean;
+    if (bwd) {
+        c_mean = *reinterpret_cast<const f32x4*>(a.bn_coef + 4 * q);
+        c_inv = *reinterpret_cast<const f32x4*>(a.bn_coef + COUT + 4 * q);
+        c_sc = *reinterpret_cast<const f32x4*>(a.bn_coef + 2 * COUT + 4 * q);
+        c_sh = *reinterpret_cast<const f32x4*>(a.bn_coef + 3 * COUT + 4 * q);
+    }
+    auto load_z = [&](int y) -> f32x4 {
+        return *reinterpret_cast<const f32x4*>(a.bn_z + (((long)b * a.H + min(y, a.H - 1)) * a.W + min(ox, a.W - 1)) * a.bn_z_ld + 4 * q);
+    };
+    float win[3][3][CIN], nxt[3][CIN];
     load_raw(win[0], y0 - 1); load_raw(win[1], y0); load_raw(win[2], y0 + 1);
+    f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f}, zn = z4;
+    if (bwd) z4 = load_z(y0);
     mask_row(win[0], y0 - 1); mask_row(win[1], y0); mask_row(win[2], y0 + 1);
     f32x4 st1 = (f32x4){0.f, 0.f, 0.f, 0.f}, st2 = st1;
     const bool vec = (a.out_ld & 3) == 0 && ((((uintptr_t)a.out) & 15) == 0);
     for (int oy = y0; oy < y1; ++oy) {
         load_raw(nxt, oy + 2);
+        if (bwd) zn = load_z(oy + 1);
         f32x4 acc = bias;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = fmaf(win[ky][kx], w[ky * 3 + kx][c], acc[c]);
+                for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] = fmaf(win[ky][kx][ci], w[ky * 3 + kx][ci][c], acc[c]);
         if (colok) {
             float* o = a.out + (((long)b * a.H + oy) * a.W + ox) * a.out_ld + 4 * q;
             if (vec) {
@@ -829,12 +859,25 @@ __global__ __launch_bounds__(256) void conv_cin1_k(SmallArgs a) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { if (a.accumulate) acc[c] += o[c]; o[c] = acc[c]; }
             }
-            st1 += acc;
-            st2 += acc * acc;
+            if (bwd) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float zh = fmaf(z4[c], c_sc[c], c_sh[c]);
+                    const float dd = zh > 0.f ? acc[c] : acc[c] * a.bn_slope;
+                    st1[c] += dd;
+                    st2[c] = fmaf(dd, (z4[c] - c_mean[c]) * c_inv[c], st2[c]);
+                }
+            } else {
+                st1 += acc;
+                st2 += acc * acc;
+            }
         }
         mask_row(nxt, oy + 2);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) { win[0][kx] = win[1][kx]; win[1][kx] = win[2][kx]; win[2][kx] = nxt[kx]; }
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) { win[0][kx][ci] = win[1][kx][ci]; win[1][kx][ci] = win[2][kx][ci]; win[2][kx][ci] = nxt[kx][ci]; }
+        z4 = zn;
     }
     if (a.bn_sums) {
         __shared__ float red[4][COUT * 2];
@@ -1997,12 +2040,17 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
         RV_NARROW(16, 1) RV_NARROW(8, 2) RV_NARROW(8, 1)
 #undef RV_NARROW
         static const int cin1_env = getenv("RV_CONV_CIN1") ? atoi(getenv("RV_CONV_CIN1")) : 1;
-        if (cin1_env && mode == 0 && Cin == 1 && (Cout == 16 || Cout == 8) && (!bias || ((((uintptr_t)bias) & 15) == 0))) {
+        const bool cin12 = mode == 0 && ((Cin == 1 && (Cout == 16 || Cout == 8)) || (Cin == 2 && Cout == 8 && (in_ld & 1) == 0 && ((((uintptr_t)in) & 7) == 0)));
+        const bool bz_ok = !bn.z || ((bn.z_ld & 3) == 0 && ((((uintptr_t)bn.z) & 15) == 0) && ((((uintptr_t)bn.coef) & 15) == 0));
+        if (cin1_env && cin12 && bz_ok && (!bias || ((((uintptr_t)bias) & 15) == 0))) {
             s.rows = 16;
+            s.bn_z = bn.z; s.bn_z_ld = bn.z_ld; s.bn_coef = bn.coef; s.bn_slope = bn.slope;
+            if (bn.z) { s.bn_sums = bn_sums; *sums_done = true; }      // the backward reduction rides in this kernel's epilogue
             const long nb = (long)B * cdiv(H, s.rows) * cdiv(W, 1024 / Cout);
-            if (Cout == 16) hipLaunchKernelGGL((conv_cin1_k<16>), dim3((unsigned)nb), blk, 0, st, s);
-            else hipLaunchKernelGGL((conv_cin1_k<8>), dim3((unsigned)nb), blk, 0, st, s);
-            RV_LAUNCH_CHECK("conv_cin1");
+            if (Cin == 1 && Cout == 16) hipLaunchKernelGGL((conv_cin12_k<1, 16>), dim3((unsigned)nb), blk, 0, st, s);
+            else if (Cin == 1) hipLaunchKernelGGL((conv_cin12_k<1, 8>), dim3((unsigned)nb), blk, 0, st, s);
+            else hipLaunchKernelGGL((conv_cin12_k<2, 8>), dim3((unsigned)nb), blk, 0, st, s);
+            RV_LAUNCH_CHECK("conv_cin12");
             return RV_OK;
         }
         if (mode == 0) {

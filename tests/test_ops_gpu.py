@@ -168,7 +168,7 @@ def test_conv_autotuner(dev, cin, cout, H, W):
 
 
 @pytest.mark.parametrize('cin,cout,H,W,algo', [(16, 16, 21, 37, 0), (32, 24, 9, 57, 0x221), (64, 128, 12, 28, 0x321), (16, 8, 10, 19, 0),
-                                               (32, 32, 8, 30, 1), (1, 16, 9, 31, 0), (48, 24, 7, 114, 0x412),
+                                               (32, 32, 8, 30, 1), (1, 16, 9, 31, 0), (1, 16, 35, 150, 0), (1, 8, 19, 140, 0), (48, 24, 7, 114, 0x412),
                                                (32, 24, 11, 114, 0x723), (64, 128, 23, 57, 0x713), (8, 16, 12, 229, 0x716), (48, 32, 9, 57, 0x725)])
 def test_conv_fused_bn_statistics(dev, cin, cout, H, W, algo, monkeypatch):
     """rv_conv_fwd(bn_sums=...) leaves sum / sum-of-squares of its output (fused epilogue of the persistent kernel,
@@ -220,7 +220,7 @@ def test_conv3x3_forced_tile_vs_torch(dev, cin, cout, H, W, algo, monkeypatch):
             assert torch.equal(ops.ConvFn.apply(g[0], g[1], g[2], 'c3', None), yg)
 
 
-@pytest.mark.parametrize('c1,c2,H,W,algo', [(16, 16, 12, 37, 0), (24, 16, 9, 57, 0x211), (64, 32, 8, 28, 0x321), (8, 2, 6, 19, 0), (32, 32, 8, 30, 1),
+@pytest.mark.parametrize('c1,c2,H,W,algo', [(16, 16, 12, 37, 0), (24, 16, 9, 57, 0x211), (64, 32, 8, 28, 0x321), (8, 2, 6, 19, 0), (8, 2, 37, 300, 0), (32, 32, 8, 30, 1),
                                             (24, 16, 11, 114, 0x713), (64, 24, 9, 57, 0x726)])
 def test_conv_dgrad_fused_bn_backward_reduction(dev, c1, c2, H, W, algo, monkeypatch):
     """conv2(lrelu(bn(z))): with a BnLink the input-gradient kernel of conv2 also produces the BatchNorm's backward
