@@ -52,30 +52,45 @@ def conv_flops(name, a):
     return 2.0 * b * hv * wv * ca * cb * {0: 9, 1: 1, 2: 4}[mode]
 
 
+CONV_ENTRY_POINTS = ('rv_conv_fwd', 'rv_conv_wgrad', 'rv_conv_wgrad_deferred', 'rv_wgrad_reduce_table')
+ROTATE_BYTES = 320 << 20              # operand sets of one timed launch are rotated until they total more than the 256 MiB Infinity Cache
+
+
+def record_launches(step_fn, names):
+    """Run step_fn once with the library's launch hook installed; returns [(entry point, args)] of the launches in `names`."""
+    from reconvat_amd import _lib
+    records = []
+
+    def hook(name, args, fn):
+        if name in names:
+            records.append((name, args))
+        return fn(*args)
+    prev = _lib.HOOK[0]
+    _lib.HOOK[0] = hook
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+    finally:
+        _lib.HOOK[0] = prev
+    return records
+
+
 def measure_conv_phase(step_fn, device):
+    """Isolated figure: every distinct conv launch of one step re-issued back to back between two HIP events on the launch
+    stream -- on ROTATING operand sets (>= 3 sets, together larger than the 256 MiB Infinity Cache), so that no launch finds
+    its operands warm from the previous repetition (colder than the real step, where a conv's input was just written by its
+    producer: a conservative figure)."""
     from reconvat_amd import _lib
     lib = _lib.load()
-    records = []
-    real_call = _lib.call
-
-    def spy(name, *args):
-        if name in ('rv_conv_fwd', 'rv_conv_wgrad'):
-            records.append((name, args))
-        return real_call(name, *args)
-
-    import reconvat_amd.ops as ops
-    ops.call = spy
-    # the recorded step runs the weight gradients in their immediate form so that every conv launch goes through the spied entry
-    # points; they are then TIMED the way the timed step executes them: the partial-sum kernel of each layer
+    # the recorded step runs the weight gradients in their immediate form so that every conv launch goes through the recorded
+    # entry points; they are then TIMED the way the timed step executes them: the partial-sum kernel of each layer
     # (rv_conv_wgrad_deferred) plus the table launches that run all per-layer reductions of a backward pass at once
     # (rv_wgrad_reduce_table, one per chain: timed below with every reduction of the step in two tables)
     prev_defer = os.environ.get('RV_DEFER_WGRAD')
     os.environ['RV_DEFER_WGRAD'] = '0'
     try:
-        step_fn()
-        torch.cuda.synchronize()
+        records = record_launches(step_fn, ('rv_conv_fwd', 'rv_conv_wgrad'))
     finally:
-        ops.call = real_call
         if prev_defer is None:
             del os.environ['RV_DEFER_WGRAD']
         else:
@@ -89,9 +104,9 @@ def measure_conv_phase(step_fn, device):
             sig = (name, a[0]) + tuple(a[2:6]) + tuple(a[7:12])
         g = groups.setdefault(sig, {'count': 0, 'name': name, 'args': a})
         g['count'] += 1
-    big = torch.empty(400 * 1024 * 1024 // 4, device=device)      # scratch large enough for any operand
-    big.uniform_(-1, 1)
-    out = torch.empty_like(big)
+    arena = torch.empty((3 << 30) // 4, device=device)             # 3 GiB of scratch operands
+    arena.uniform_(-1, 1)
+    base = arena.data_ptr()
     ws = torch.empty(256 * 1024 * 1024 // 4, device=device)
     st = torch.cuda.current_stream()
     eb = lib.rv_wgrad_table_entry_bytes()
@@ -103,33 +118,52 @@ def measure_conv_phase(step_fn, device):
     def deferred_fn(*a):
         return 0 if lib.rv_conv_wgrad_deferred(*a) > 0 else -1
 
-    total_ms, total_flops, per_kernel = 0.0, 0.0, []
+    def up(n):
+        return (n + 4095) & ~4095
+
+    total_ms, total_flops, per_kernel, min_sets = 0.0, 0.0, [], 1 << 30
     for sig, g in groups.items():
-        a = list(g['args'])
+        a0 = list(g['args'])
         if g['name'] == 'rv_conv_fwd':
-            a[1], a[7] = big.data_ptr(), out.data_ptr()
-            a[12] = big.data_ptr() + 64 * 1024 * 1024
-            a[13] = None
-            if a[16]:
-                a[16] = ws.data_ptr()                      # fused BatchNorm statistics: any fp64 scratch
-            if a[17]:
-                a[17], a[19] = out.data_ptr() + 128 * 1024 * 1024, ws.data_ptr() + 1024 * 1024   # z / coefficients: scratch
+            b_, h_, w_, ild, ho, wo, old = a0[3], a0[4], a0[5], a0[2], a0[9], a0[10], a0[8]
+            sz = {'in': up(4 * b_ * h_ * w_ * ild), 'out': up(4 * b_ * ho * wo * old), 'w': up(4 << 20),
+                  'z': up(4 * b_ * ho * wo * a0[18]) if a0[17] else 0, 'coef': up(1 << 16) if a0[17] else 0}
         else:
-            a[1], a[6] = big.data_ptr(), big.data_ptr() + 128 * 1024 * 1024
-            a[12], a[16], a[18] = out.data_ptr(), None, ws.data_ptr()
-            a[19] = ws.numel() * 4
-        a[-1] = st.cuda_stream
-        fn = getattr(lib, g['name'])
-        if g['name'] == 'rv_conv_wgrad' and deferrable(a):
-            a = a[:17] + a[18:20] + [entry_scratch.data_ptr(), st.cuda_stream]      # (no `acc`; entry slot before the stream)
-            fn = deferred_fn
-        for _ in range(2):
+            uld, hu, wu, vld, hv, wv, b_ = a0[2], a0[3], a0[4], a0[7], a0[8], a0[9], a0[11]
+            sz = {'in': up(4 * b_ * hu * wu * uld), 'out': up(4 * b_ * hv * wv * vld), 'w': up(4 << 20), 'z': 0, 'coef': 0}
+        foot = sum(sz.values())
+        nsets = max(3, min(64, -(-ROTATE_BYTES // foot) + 1, (3 << 30) // foot))
+        min_sets = min(min_sets, nsets)
+        calls = []
+        for s_ in range(nsets):
+            a = list(a0)
+            o = base + s_ * foot
+            if g['name'] == 'rv_conv_fwd':
+                a[1], a[7], a[12], a[13] = o, o + sz['in'], o + sz['in'] + sz['out'], None
+                if a[16]:
+                    a[16] = ws.data_ptr()                      # fused BatchNorm statistics: any fp64 scratch
+                if a[17]:
+                    a[17] = o + sz['in'] + sz['out'] + sz['w']
+                    a[19] = a[17] + sz['z']                    # z / coefficients: scratch
+                a[-1] = st.cuda_stream
+                fn = lib.rv_conv_fwd
+            else:
+                a[1], a[6], a[12], a[16], a[18] = o, o + sz['in'], o + sz['in'] + sz['out'], None, ws.data_ptr()
+                a[19] = ws.numel() * 4
+                a[-1] = st.cuda_stream
+                fn = lib.rv_conv_wgrad
+                if deferrable(a):
+                    a = a[:17] + a[18:20] + [entry_scratch.data_ptr(), st.cuda_stream]      # (no `acc`; entry slot before the stream)
+                    fn = deferred_fn
+            calls.append((fn, a))
+        for fn, a in calls[:2]:
             if fn(*a) != 0:
                 raise RuntimeError(f"{g['name']} {sig}: {_lib.last_error()}")
-        reps = 5
+        reps = max(6, nsets)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
-        for _ in range(reps):
+        for i in range(reps):
+            fn, a = calls[i % nsets]
             fn(*a)
         e1.record(st)
         e1.synchronize()
@@ -150,8 +184,8 @@ def measure_conv_phase(step_fn, device):
                 continue
             host = torch.empty(len(half) * eb, dtype=torch.uint8)
             for i, a in enumerate(half):
-                a[1], a[6] = big.data_ptr(), big.data_ptr() + 128 * 1024 * 1024
-                a[12], a[16] = out.data_ptr(), None
+                a[1], a[6] = base, base + (512 << 20)
+                a[12], a[16] = base + (1 << 30), None
                 nbytes = lib.rv_conv_wgrad_workspace_bytes({0: 9, 1: 1, 2: 4}[a[0]], a[11], a[8], a[5], a[10])
                 if (off + nbytes) > ws.numel() * 4:
                     off = 0                                  # (scratch partial sums may alias: only the timing matters)
@@ -177,7 +211,57 @@ def measure_conv_phase(step_fn, device):
         ntab = len(tables)
         per_kernel.append((ms, ntab, ms / ntab, 0.0, ('rv_wgrad_reduce_table', f'{len(wg)} reductions in {ntab} launches')))
     per_kernel.sort(reverse=True)
-    return total_ms, total_flops, per_kernel, len(records) + ntab
+    return total_ms, total_flops, per_kernel, len(records) + ntab, min_sets
+
+
+def measure_in_situ(step_fn, device):
+    """In-situ figure: ONE eager single-stream step with every launch of the kernel families bracketed by two HIP events on
+    the launch stream (the operands are the step's own: as warm or cold as the step leaves them).  Returns
+    ({family: (ms, launches)}, event-bracket floor in us).  A bracket contains the dispatch gap behind the previous launch
+    (the floor: a bracket around a one-workgroup kernel), so the sums are upper bounds of rocprofv3's kernel durations."""
+    from reconvat_amd import _lib
+    fam_of = dict(FAMILY)
+    fam_of.update({n: 'convolutions' for n in CONV_ENTRY_POINTS})
+    brackets = []
+
+    def hook(name, args, fn):
+        f = fam_of.get(name)
+        if f is None:
+            return fn(*args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        brackets.append((f, name, args, e0, e1))
+        return rc
+    prev = _lib.HOOK[0]
+    _lib.HOOK[0] = hook
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+    finally:
+        _lib.HOOK[0] = prev
+    out, flops = {}, 0.0
+    for f, name, args, e0, e1 in brackets:
+        ms, n = out.get(f, (0.0, 0))
+        out[f] = (ms + e0.elapsed_time(e1), n + 1)
+        if name in ('rv_conv_fwd', 'rv_conv_wgrad'):
+            flops += conv_flops(name, args)
+        elif name == 'rv_conv_wgrad_deferred':
+            flops += conv_flops('rv_conv_wgrad', args)
+    # floor of a bracket: the same two events around a one-workgroup kernel
+    lib = _lib.load()
+    cnt = torch.zeros(1, dtype=torch.int64, device=device)
+    floors = []
+    for _ in range(50):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        lib.rv_counter_add(cnt.data_ptr(), 1, torch.cuda.current_stream().cuda_stream)
+        e1.record()
+        floors.append((e0, e1))
+    torch.cuda.synchronize()
+    fl = sorted(a.elapsed_time(b) for a, b in floors)
+    return out, flops, fl[len(fl) // 2] * 1e3
 
 
 # ---------------------------------------------------------------------------------------------
@@ -219,24 +303,8 @@ def family_work(name, a):
 
 def measure_families(step_fn, device):
     from reconvat_amd import _lib
-    import reconvat_amd.ops as ops
-    import reconvat_amd.model as model_mod
     lib = _lib.load()
-    records, real_call = [], _lib.call
-
-    def spy(name, *args):
-        if name in FAMILY:
-            records.append((name, args))
-        return real_call(name, *args)
-    patched = [(m, m.call) for m in (ops, model_mod) if hasattr(m, 'call')]
-    for m, _ in patched:
-        m.call = spy
-    try:
-        step_fn()
-        torch.cuda.synchronize()
-    finally:
-        for m, orig in patched:
-            m.call = orig
+    records = record_launches(step_fn, FAMILY)
     cur = torch.cuda.current_stream().cuda_stream
     groups = {}
     for name, a in records:
@@ -326,29 +394,97 @@ def cpu_baseline():
                       f'{best["threads"]}) ({best["s_per_step"]:.2f} s/step); all thread counts tried are in `runs`'}
 
 
+def parity_leg(device):
+    """After the timed loop, in the SAME process and kernel configuration: one frozen-weight step of the bench schedule
+    (two-stream hipGraph TrainStep, VAT + reconstruction) on the full-length fixture of tests/golden/lds_spread.npz (case
+    onset_T640: B = 2 segments of 327 680 samples, closed-form weights / inputs / injected VAT noise) against the REFERENCE's own
+    loss values on those inputs.  `oracle.fixture` only regenerates the closed-form fixture tensors (checker input, not a
+    compute path)."""
+    import numpy as np
+    import reconvat_amd as ra
+    from reconvat_amd import plans
+    from oracle import fixture as fx
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'lds_spread.npz'))
+    case = 'onset_T640'
+
+    def mk(tag):
+        onset, frame = fx.fixture_labels(2, 640, tag)
+        return {'audio': fx.fixture_audio(2, 640 * 512, tag).to(device), 'onset': onset.to(device), 'frame': frame.to(device)}
+    bl, bul = mk('L'), mk('UL')
+    noise = [fx.fixture_noise((2, 1, 640, 229), 'd0_ul').to(device), fx.fixture_noise((2, 1, 640, 229), 'd0_l').to(device)]
+    m = ra.UNet_Onset((2, 2), (2, 2), log=True, reconstruction=True, mode='imagewise', spec='Mel', XI=1e-6, eps=2)
+    m.load_state_dict(fx.fixture_params('onset', True))
+    m.to(device).train()
+    opt = ra.FlatAdam(m.parameters(), lr=0.0)            # frozen weights: every step sees the fixture weights
+    state = {'i': 0}
+
+    def draw(t):
+        state['i'] += 1
+        return noise[(state['i'] - 1) % 2].clone()       # unlabelled first, labelled second (model/UNet_onset.py:425,445)
+    m.vat_loss.noise = draw
+    step = ra.TrainStep(m, opt, bl, bul, alpha=1.0, VAT=True, clip=3.0, graph=True, dual_stream=True)
+    step()
+    step()
+    torch.cuda.synchronize()
+    step.check()
+    keys = [str(k) for k in g[case + '_keys']]
+    spread = dict(zip(keys, (float(v) for v in g[case + '_spread'])))
+    errs = {}
+    for k, ref in zip(keys, g[case + '_f32_8t']):
+        errs[k.split('/')[-1]] = abs(float(step.losses[k]) - float(ref)) / max(abs(float(ref)), 1e-6)
+    vat = {k: v for k, v in errs.items() if 'LDS' in k or 'r_norm' in k}
+    non = {k: v for k, v in errs.items() if k not in vat}
+    return {'case': f'{case} (tests/golden/lds_spread.npz: the reference at 8 threads fp32), two-stream hipGraph TrainStep, frozen weights',
+            'rel_err_non_vat_max': float(f'{max(non.values()):.3e}'), 'rel_err_vat_max': float(f'{max(vat.values()):.3e}'),
+            'rel_err': {k: float(f'{v:.3e}') for k, v in errs.items()},
+            'reference_own_spread_vat_max': float(f'{max(v for k, v in spread.items() if "LDS" in k or "r_norm" in k):.3e}'),
+            'tolerance': '1e-3 relative (north_star); VAT terms: max(1e-3, 3 x the reference\'s own 1-thread / fp64 spread)',
+            'kernel_plan_table': plans.digest()}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: spawn N fresh rank processes (one per GPU) BEFORE this process touches
-    the GPU, wait for all of them, relay rank 0's JSON line; non-zero exit if any rank fails."""
+    the GPU, watch ALL of them, relay rank 0's JSON line; if any rank exits non-zero the others are terminated and the launcher
+    exits non-zero (a rank that dies early would otherwise leave its peers blocked in the rendezvous / a collective)."""
     import socket
     import subprocess
+    import tempfile
     n = args.gpus
-    have = torch.cuda.device_count()              # does not initialise the GPU runtime
+    have = torch.cuda.device_count()              # (the ranks are fresh child processes: this process never execs and never runs GPU work)
     if have < n:
         raise SystemExit(f'bench.py --gpus {n}: this node exposes {have} GPU(s)')
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     procs = []
+    out0 = tempfile.TemporaryFile(mode='w+')
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out)
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, text=True))
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for r, p_ in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p_.poll()
+        if any(c not in (None, 0) for c in codes):
+            for r, p_ in enumerate(procs):
+                if codes[r] is None:
+                    p_.terminate()
+            for r, p_ in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = p_.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p_.kill()
+                        codes[r] = p_.wait()
+            break
+        time.sleep(0.05)
+    out0.seek(0)
+    sys.stdout.write(out0.read())
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
@@ -365,6 +501,7 @@ def main():
     ap.add_argument('--single-stream', action='store_true', help='disable the two-stream step schedule (A/B)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true', help='skip the post-run parity leg (frozen-weight step vs the reference fixture)')
     ap.add_argument('--verbose', action='store_true', help='dump the per-launch conv table to stderr')
     args = ap.parse_args()
 
@@ -384,6 +521,7 @@ def main():
         dist.init_process_group('nccl', device_id=device)
 
     import reconvat_amd as ra
+    from reconvat_amd import plans, ops as ops_mod
     torch.manual_seed(1234)                       # identical initial weights on every rank
     model = ra.UNet_Onset((2, 2), (2, 2), log=True, reconstruction=True, mode='imagewise', spec='Mel', device=str(device),
                           XI=1e-6, eps=2).to(device)
@@ -443,21 +581,28 @@ def main():
         'config': {'workload': f'ReconVAT UNet_Onset VAT=True reconstruction=True, per-GPU B_l={args.batch} + '
                                f'B_ul={args.batch} segments of 327680 samples (640 frames x 229 mel), Adam+StepLR, fp32',
                    'parallelism': f'dp{world}', 'hipgraph': used_graph, 'two_stream_schedule': not args.single_stream, 'labelled_only_audio_s_per_s': round(audio_s / 2, 2),
+                   'kernel_plan_table': plans.digest(), 'kernel_plan_mode': str(ops_mod.AUTOTUNE),
                    'final_loss': round(loss, 5), 'vat_nan_flag': nan_flag, 'losses_last_step': loss_terms},
         'rccl_ranks': rccl_ranks, 'replicas_equal': replicas_equal, 'param_checksum': int(checksum.item()),
     }
     if rank == 0 and world == 1:
         if not args.no_roofline:
             eager = ra.TrainStep(model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=False)
-            conv_ms, conv_flops_total, per_kernel, nlaunch = measure_conv_phase(eager, device)
+            conv_ms, conv_flops_total, per_kernel, nlaunch, min_sets = measure_conv_phase(eager, device)
             achieved = conv_flops_total / conv_ms / 1e9
+            # in situ: one eager single-stream step, every family launch bracketed by HIP events on the launch stream
+            eager1 = ra.TrainStep(model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=False, dual_stream=False)
+            eager1()
+            situ, situ_flops, floor_us = measure_in_situ(eager1, device)
+            conv_situ_ms, conv_situ_n = situ.get('convolutions', (0.0, 0))
+            achieved_situ = situ_flops / conv_situ_ms / 1e9 if conv_situ_ms else 0.0
             if args.verbose:
                 for t, c, m_, tf, sg in per_kernel:
                     print(f'[conv] {t:8.3f} ms/step  x{c:3d}  {m_:8.4f} ms  {tf:7.1f} TF/s  {sg}', file=sys.stderr)
             # HBM bytes of the same launches from the committed PMC passes (rocprofv3 cannot run inside this process):
             # tools/pmc_traffic.py over separate FETCH_SIZE / WRITE_SIZE runs of `bench.py --no-graph`, gfx950-corrected
             traffic, traffic_src = None, None
-            for cand in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+            for cand in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
                 tpath = os.path.join(ROOT, 'profiles', cand)
                 if os.path.exists(tpath):
                     with open(tpath) as fh:
@@ -471,9 +616,19 @@ def main():
                 'traffic_scope': 'HBM bytes (FETCH_SIZE x2 + WRITE_SIZE) of all conv launches of one step; NOT measured by this run: '
                                  + str(traffic_src),
                 'kernel': 'conv3x3_lds_k / conv_mfma_k / wgrad_mfma_k family (all conv launches of one step)',
-                'conv_ms_source': 'isolated re-launch of every distinct conv launch of one step on scratch operands, HIP events on '
-                                  'the launch stream, after the timed loop (per-kernel figure; the timed step overlaps two chains); weight gradients '
-                                  'as the step runs them: per-layer partial-sum kernel + the per-chain reduction table launches',
+                'conv_ms_source': 'isolated re-launch of every distinct conv launch of one step, HIP events on the launch stream, after the '
+                                  f'timed loop, operands ROTATED through >= {min_sets} scratch sets totalling > 256 MiB per launch shape (no launch finds '
+                                  'its operands warm from the previous repetition; per-kernel figure; the timed step overlaps two chains); weight '
+                                  'gradients as the step runs them: per-layer partial-sum kernel + the per-chain reduction table launches',
+                # the same family inside ONE eager single-stream step: every conv launch bracketed by two HIP events on the launch
+                # stream, operands as warm / cold as the step leaves them.  A bracket includes the dispatch gap behind the previous
+                # launch (`event_bracket_floor_us`: the same bracket around a one-workgroup kernel), so this is an upper bound of the
+                # rocprofv3 kernel-duration sum of the same step (profiles/r03_step_kernel_stats_single_stream.txt)
+                'frac_in_situ': round(achieved_situ / MFMA_F32_PEAK_TFLOPS, 4), 'achieved_in_situ': round(achieved_situ, 2),
+                'conv_ms_in_situ': round(conv_situ_ms, 3), 'conv_launches_in_situ': conv_situ_n,
+                'event_bracket_floor_us': round(floor_us, 2),
+                'conv_ms_in_situ_minus_floor': round(conv_situ_ms - conv_situ_n * floor_us * 1e-3, 3),
+                'families_in_situ': {k: {'ms_per_step': round(v[0], 3), 'launches': v[1]} for k, v in sorted(situ.items())},
                 'launches_per_step': nlaunch, 'conv_ms_per_step': round(conv_ms, 3),
                 'executed_gflop_per_step': round(conv_flops_total / 1e9, 1),
                 'reference_gflop_per_step': 1531.0,
@@ -488,6 +643,8 @@ def main():
                               'unit': 'TFLOP/s', 'peak': MFMA_F32_PEAK_TFLOPS, 'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                               'work_per_step': round(conv_flops_total / 1e9, 1), 'work_unit': 'GFLOP'}] + families,
             }
+        if not args.no_parity:
+            line['parity'] = parity_leg(device)
         if not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
     if rank == 0:

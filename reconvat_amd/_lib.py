@@ -104,9 +104,21 @@ def need_gpu(*tensors):
             raise RuntimeError('reconvat_amd ops run on a HIP device only (got a CPU tensor); there is no CPU fallback')
 
 
+# Measurement hook (bench.py / tools): HOOK[0](name, args, fn) -> status is called INSTEAD of fn(*args) for every launch the
+# host side makes through invoke() / call() -- it records the launch (or brackets it with HIP events) and calls through.
+HOOK = [None]
+
+
+def invoke(name, *args):
+    """Invoke an entry point and return its status (no exception)."""
+    fn = getattr(load(), name)
+    hook = HOOK[0]
+    return hook(name, args, fn) if hook is not None else fn(*args)
+
+
 def call(name, *args):
     """Invoke an int-returning entry point and raise on a non-zero status."""
     lib = load()
-    rc = getattr(lib, name)(*args)
+    rc = invoke(name, *args)
     if rc != 0:
         raise RuntimeError(f'{name} failed ({rc}): {lib.rv_last_error().decode()}')

@@ -11,8 +11,8 @@ import sys
 import torch
 from torch.autograd import Function
 
-from . import _lib
-from ._lib import call, ptr, stream, need_gpu
+from . import _lib, plans
+from ._lib import call, invoke, ptr, stream, need_gpu
 
 SLOPE = 0.01            # F.leaky_relu default (model/UNet_onset.py:197-198)
 BN_MOMENTUM = 0.1       # model/UNet_onset.py:183
@@ -325,7 +325,12 @@ _DGRAD_MODE = {'c3': 0, 't3': 0, 'c1': 1, 'down': 3, 'up': 2}
 
 
 _algo_cache = {}
-AUTOTUNE = True
+_tune_us = {}             # ('conv' | 'wgrad', key) -> microseconds the on-line tuner measured for its choice
+_algo_unchecked = set()    # table entries borrowed from another batch size: legality is checked by their first launch
+# 'table' (default): the shipped per-shape plan table (reconvat_amd/plans.py, tuned_plans.json) -- what bench.py, the scripts and
+# the -m gpu tests all run; True (RV_AUTOTUNE=1): time every legal tile on the first eager call of a shape (how the table is
+# made, tools/tune_plans.py); False (RV_AUTOTUNE=0): library default tiles.
+AUTOTUNE = plans.default_mode()
 
 
 def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias, stats=None, bnbwd=None, accumulate=False):
@@ -347,6 +352,12 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
     elif AUTOTUNE and cin % 8 == 0 and (cout > 2 or mode == 3):     # (the small-channel VALU kernels have one form)
         key = (mode, bb, h, wd, cin, cout, ild, old, stats is not None, bnbwd is not None)
         algo = _algo_cache.get(key, -1)
+        if algo < 0 and AUTOTUNE == 'table':
+            hit = plans.lookup_conv(key)
+            algo = hit[0] if hit is not None else 0
+            _algo_cache[key] = algo
+            if hit is not None and not hit[1]:
+                _algo_unchecked.add(key)
         if algo < 0:
             if torch.cuda.is_current_stream_capturing():
                 algo = 0
@@ -403,8 +414,15 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
                     if best is None or t < best:
                         best, algo = t, cand
                 _algo_cache[key] = algo
+                if best is not None:
+                    _tune_us[('conv', key)] = best / 3 * 1e3
                 if os.environ.get('RV_TUNE_LOG') and best is not None:
                     print(f'[tune] conv mode={mode} {cin}->{cout} {h}x{wd} B={bb}: algo={algo:#x} {best / 3 * 1e3:.1f} us', file=sys.stderr)
+        if key in _algo_unchecked:
+            _algo_unchecked.discard(key)
+            if invoke('rv_conv_fwd', *args, algo, ptr(stats), *tail, stream()) == 0:
+                return
+            algo = _algo_cache[key] = 0         # the borrowed tile does not fit this batch size: library default
     call('rv_conv_fwd', *args, algo, ptr(stats), *tail, stream())
 
 
@@ -463,6 +481,7 @@ class BnLink:
 
 
 _wgrad_tuned = set()
+_wgrad_plans = {}          # (taps, B, Hv, Wv, Ca, Cb) -> (nw, wgs): what this process pinned in the library (tools/tune_plans.py dumps it)
 
 
 def _tune_wgrad(lib, mode, taps, u, uld, hu, wu, ca, v, vld, hv, wv, cb, bb, w, s_a, s_b, flip):
@@ -470,7 +489,17 @@ def _tune_wgrad(lib, mode, taps, u, uld, hu, wu, ca, v, vld, hv, wv, cb, bb, w, 
     call of a shape times the candidates (HIP events on the launch stream, scratch outputs) and pins the winner in the library
     (rv_conv_wgrad_set_plan); under hipGraph capture an untuned shape keeps the library default (8 waves, 256 workgroups)."""
     key = (taps, bb, hv, ca, cb)
-    if not AUTOTUNE or key in _wgrad_tuned or ca * cb * taps <= 144 or ca == 1 or torch.cuda.is_current_stream_capturing():
+    if not AUTOTUNE or key in _wgrad_tuned or ca * cb * taps <= 144 or ca == 1:
+        return
+    if AUTOTUNE == 'table':
+        # host-only (legal under hipGraph capture); runs before the first launch of the shape, i.e. never between a deferred
+        # weight-gradient launch of that shape and its table flush
+        _wgrad_tuned.add(key)
+        plan = plans.lookup_wgrad((taps, bb, hv, wv, ca, cb))
+        if plan is not None and lib.rv_conv_wgrad_set_plan(taps, bb, hv, ca, cb, *plan) == 0:
+            _wgrad_plans[(taps, bb, hv, wv, ca, cb)] = plan
+        return
+    if torch.cuda.is_current_stream_capturing():
         return
     _wgrad_tuned.add(key)
     st = torch.cuda.current_stream()
@@ -499,6 +528,9 @@ def _tune_wgrad(lib, mode, taps, u, uld, hu, wu, ca, v, vld, hv, wv, cb, bb, w, 
         if best is None or t < best:
             best, choice = t, (nw, wgs)
     lib.rv_conv_wgrad_set_plan(taps, bb, hv, ca, cb, *choice)
+    _wgrad_plans[(taps, bb, hv, wv, ca, cb)] = choice
+    if best is not None:
+        _tune_us[('wgrad', (taps, bb, hv, wv, ca, cb))] = best / 3 * 1e3
     if os.environ.get('RV_TUNE_LOG'):
         print(f'[tune] wgrad taps={taps} {ca}->{cb} {hv}x{wv} B={bb}: nw={choice[0]} wgs={choice[1]} {best / 3 * 1e3:.1f} us', file=sys.stderr)
 
@@ -540,8 +572,8 @@ def conv_wgrad(kind, x, dy, w, want_bias=True, dw_acc=None, db_acc=None):
         tab = tables.get(cur.cuda_stream)
         if tab is None:
             tab = tables[cur.cuda_stream] = _WgradTable(w.device, cur)
-        rc = lib.rv_conv_wgrad_deferred(mode, ptr(u), uld, hu, wu, ca, ptr(v), vld, hv, wv, cb, bb, ptr(dw), s_a, s_b, flip,
-                                        bias_ptr, ptr(ws), nbytes, tab.slot(), cur.cuda_stream)
+        rc = invoke('rv_conv_wgrad_deferred', mode, ptr(u), uld, hu, wu, ca, ptr(v), vld, hv, wv, cb, bb, ptr(dw), s_a, s_b, flip,
+                    bias_ptr, ptr(ws), nbytes, tab.slot(), cur.cuda_stream)
         if rc <= 0:
             raise RuntimeError(f'rv_conv_wgrad_deferred failed ({rc}): {_lib.last_error()}')
         tab.n += 1

@@ -1,0 +1,31 @@
+"""Host-side checks of the shipped kernel-configuration table (reconvat_amd/plans.py, tuned_plans.json): it parses, it is the
+default mode, keys have the documented arity, tile codes are well-formed, and the batch-agnostic fall-back resolves."""
+import os
+
+
+def test_table_parses_and_is_default():
+    from reconvat_amd import plans
+    assert os.path.exists(plans.PLAN_FILE)
+    assert plans.default_mode() == 'table' or os.environ.get('RV_AUTOTUNE') is not None
+    conv, wgrad = plans.conv_entries(), plans.wgrad_entries()
+    assert len(conv) >= 40 and len(wgrad) >= 20 and plans.digest()
+    for key, algo in conv.items():
+        assert len(key) == 10 and key[0] in (0, 1, 2, 3) and key[1] == 8
+        fam, nt, mt, th = (algo >> 8) & 15, (algo >> 4) & 15, algo & 15, algo >> 12
+        assert algo in (0, 1, 2) or (fam in (1, 2, 3, 4, 7) and 1 <= nt <= 4 and 1 <= mt <= 8 and 0 <= th < 256), hex(algo)
+        if key[0] != 0:
+            assert fam in (0, 1), 'only the 3x3 mode has LDS tile families'
+    for key, (nw, wgs) in wgrad.items():
+        assert len(key) == 6 and key[0] in (1, 4, 9) and nw in (0, 4, 8) and (wgs == 0 or 32 <= wgs <= 4096)
+
+
+def test_lookup_exact_and_borrowed():
+    from reconvat_amd import plans
+    key, algo = sorted(plans.conv_entries().items())[0]
+    assert plans.lookup_conv(key) == (algo, True)
+    other_b = (key[0], 2) + key[2:]
+    assert plans.lookup_conv(other_b) == (algo, False)            # same layer geometry at another batch size
+    assert plans.lookup_conv((0, 8, 33, 17, 16, 16, 16, 16, 0, 0)) is None
+    wkey, plan = sorted(plans.wgrad_entries().items())[0]
+    assert plans.lookup_wgrad(wkey) == plan and plans.lookup_wgrad((wkey[0], 2) + wkey[2:]) == plan
+    assert plans.lookup_wgrad((9, 8, 33, 17, 16, 16)) is None
