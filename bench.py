@@ -249,10 +249,14 @@ def measure_in_situ(step_fn, device):
             flops += conv_flops(name, args)
         elif name == 'rv_conv_wgrad_deferred':
             flops += conv_flops('rv_conv_wgrad', args)
-    # floor of a bracket: the same two events around a one-workgroup kernel
+    # floor of a bracket: the same two events around a one-workgroup kernel, issued while the queue is still busy (as in the
+    # step, where the host runs ahead of the device): dispatch gap + event markers + a ~1 us kernel
     lib = _lib.load()
     cnt = torch.zeros(1, dtype=torch.int64, device=device)
+    busy = torch.empty(1 << 28, device=device)
     floors = []
+    for _ in range(8):
+        busy.uniform_()                      # ~2-3 ms of queued work: the brackets below are enqueued behind it
     for _ in range(50):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

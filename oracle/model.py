@@ -144,19 +144,23 @@ def l2_normalise(d):
     return d / torch.norm(d, dim=-1, keepdim=True)
 
 
-def vat_onset(params, training, x, xi, eps, d0=None):
+def vat_onset(params, training, x, xi, eps, d0=None, n_power=1):
     """UNet_VAT.forward for the onset model, model/UNet_onset.py:116-162
-    (n_power=1, KL_Div=False).  ``d0`` injects the initial noise (the reference
-    draws torch.randn_like(x))."""
+    (n_power in {0, 1}, KL_Div=False).  ``d0`` injects the initial noise (the reference
+    draws torch.randn_like(x)); with n_power = 0 the loop at :129-142 never runs and d0 itself is normalised into r_adv."""
     with torch.no_grad():
         frame_ref, onset_ref, _ = spec2roll_onset(Net(params, training), x)
     d = (torch.randn_like(x) if d0 is None else d0.clone()).requires_grad_(True)
-    x_adv = (x + xi * l2_normalise(d)).clamp(0, 1)
-    fp, op, _ = spec2roll_onset(Net(params, training), x_adv)
-    loss = F.binary_cross_entropy(fp, frame_ref) + F.binary_cross_entropy(op, onset_ref)
-    # the reference backpropagates into the weights too, then model.zero_grad()s
-    g, = torch.autograd.grad(loss, d)
-    d = g.detach() * 1e10
+    g = None
+    if n_power:
+        x_adv = (x + xi * l2_normalise(d)).clamp(0, 1)
+        fp, op, _ = spec2roll_onset(Net(params, training), x_adv)
+        loss = F.binary_cross_entropy(fp, frame_ref) + F.binary_cross_entropy(op, onset_ref)
+        # the reference backpropagates into the weights too, then model.zero_grad()s
+        g, = torch.autograd.grad(loss, d)
+        d = g.detach() * 1e10
+    else:
+        d = d.detach()
     r_adv = eps * l2_normalise(d)
     assert not torch.isnan(r_adv).any(), "r_adv has nan, please debug tune down the XI for VAT"
     x_adv = (x + r_adv).clamp(0, 1)
@@ -166,15 +170,19 @@ def vat_onset(params, training, x, xi, eps, d0=None):
     return lds, r_adv, l2_normalise(d), g
 
 
-def vat_frame(params, training, x, xi, eps, d0=None):
-    """UNet_VAT.forward for the no-onset model, model/self_attention_VAT.py:162-202."""
+def vat_frame(params, training, x, xi, eps, d0=None, n_power=1):
+    """UNet_VAT.forward for the no-onset model, model/self_attention_VAT.py:162-202 (n_power in {0, 1})."""
     with torch.no_grad():
         y_ref, _ = spec2roll_frame(Net(params, training), x)
     d = (torch.randn_like(x) if d0 is None else d0.clone()).requires_grad_(True)
-    x_adv = (x + xi * l2_normalise(d)).clamp(0, 1)
-    yp, _ = spec2roll_frame(Net(params, training), x_adv)
-    g, = torch.autograd.grad(F.binary_cross_entropy(yp, y_ref), d)
-    d = g.detach() * 1e10
+    g = None
+    if n_power:
+        x_adv = (x + xi * l2_normalise(d)).clamp(0, 1)
+        yp, _ = spec2roll_frame(Net(params, training), x_adv)
+        g, = torch.autograd.grad(F.binary_cross_entropy(yp, y_ref), d)
+        d = g.detach() * 1e10
+    else:
+        d = d.detach()
     r_adv = eps * l2_normalise(d)
     assert not torch.isnan(r_adv).any(), "r_adv has nan, please debug tune down the XI for VAT"
     yp, _ = spec2roll_frame(Net(params, training), (x + r_adv).clamp(0, 1))
@@ -208,7 +216,7 @@ def _spec(params, audio, log=True):
 
 
 def run_on_batch_onset(params, training, batch, batch_ul=None, VAT=False, reconstruction=True,
-                       xi=1e-6, eps=2.0, d0_l=None, d0_ul=None, log=True):
+                       xi=1e-6, eps=2.0, d0_l=None, d0_ul=None, log=True, n_power=1):
     """UNet_Onset.run_on_batch, model/UNet_onset.py:409-542."""
     audio, onset_label, frame_label = batch['audio'], batch['onset'], batch['frame']
     if frame_label.dim() == 2:
@@ -218,12 +226,12 @@ def run_on_batch_onset(params, training, batch, batch_ul=None, VAT=False, recons
     zero = torch.tensor(0.)
     if batch_ul:
         spec_ul = _spec(params, batch_ul['audio'].reshape(-1, audio.shape[-1]), log)
-        lds_ul, _, r_norm_ul, _ = vat_onset(params, training, spec_ul, xi, eps, d0_ul)
+        lds_ul, _, r_norm_ul, _ = vat_onset(params, training, spec_ul, xi, eps, d0_ul, n_power)
     else:
         lds_ul, r_norm_ul = {'frame': zero, 'onset': zero}, zero
     spec = _spec(params, audio, log)
     if VAT:
-        lds_l, r_adv, r_norm_l, _ = vat_onset(params, training, spec, xi, eps, d0_l)
+        lds_l, r_adv, r_norm_l, _ = vat_onset(params, training, spec, xi, eps, d0_l, n_power)
         r_adv = r_adv.squeeze(1)
     else:
         r_adv, lds_l, r_norm_l = None, {'frame': zero, 'onset': zero}, zero
@@ -257,7 +265,7 @@ def run_on_batch_onset(params, training, batch, batch_ul=None, VAT=False, recons
 
 
 def run_on_batch_frame(params, training, batch, batch_ul=None, VAT=False, reconstruction=True,
-                       xi=1e-6, eps=2.0, d0_l=None, d0_ul=None, log=True):
+                       xi=1e-6, eps=2.0, d0_l=None, d0_ul=None, log=True, n_power=1):
     """UNet.run_on_batch, model/self_attention_VAT.py:1090-1203."""
     audio, frame_label = batch['audio'], batch['frame']
     if frame_label.dim() == 2:
@@ -265,12 +273,12 @@ def run_on_batch_frame(params, training, batch, batch_ul=None, VAT=False, recons
     zero = torch.tensor(0.)
     if batch_ul:
         spec_ul = _spec(params, batch_ul['audio'].reshape(-1, audio.shape[-1]), log)
-        lds_ul, _, r_norm_ul, _ = vat_frame(params, training, spec_ul, xi, eps, d0_ul)
+        lds_ul, _, r_norm_ul, _ = vat_frame(params, training, spec_ul, xi, eps, d0_ul, n_power)
     else:
         lds_ul, r_norm_ul = zero, zero
     spec = _spec(params, audio, log)
     if VAT:
-        lds_l, r_adv, r_norm_l, _ = vat_frame(params, training, spec, xi, eps, d0_l)
+        lds_l, r_adv, r_norm_l, _ = vat_frame(params, training, spec, xi, eps, d0_l, n_power)
         r_adv = r_adv.squeeze(1)
     else:
         r_adv, lds_l, r_norm_l = None, zero, zero
@@ -298,7 +306,7 @@ def run_on_batch_frame(params, training, batch, batch_ul=None, VAT=False, recons
     return pred, losses, spec.squeeze(1)
 
 
-def run_on_batch_application(params, training, batch, batch_ul, VAT=False, xi=1e-6, eps=2.0, d0_l=None, d0_ul=None, log=True):
+def run_on_batch_application(params, training, batch, batch_ul, VAT=False, xi=1e-6, eps=2.0, d0_l=None, d0_ul=None, log=True, n_power=1):
     """UNet.run_on_batch_application, model/self_attention_VAT.py:1205-1291 (reconstruction=True model; the reference needs
     `batch_ul`: without it `spec` is read before assignment, :1225).  Adds the unlabelled consistency term
     `loss/ul_consistency_wrt1` = BCE(ul_frame2, ul_frame.detach())."""
@@ -307,11 +315,11 @@ def run_on_batch_application(params, training, batch, batch_ul, VAT=False, xi=1e
         frame_label = frame_label.unsqueeze(0)
     zero = torch.tensor(0.)
     spec_ul = _spec(params, batch_ul['audio'].reshape(-1, audio.shape[-1]), log)
-    lds_ul, _, r_norm_ul, _ = vat_frame(params, training, spec_ul, xi, eps, d0_ul)
+    lds_ul, _, r_norm_ul, _ = vat_frame(params, training, spec_ul, xi, eps, d0_ul, n_power)
     _, ul_roll, ul_roll2, _ = forward_frame(params, training, spec_ul, True)
     spec = _spec(params, audio, log)
     if VAT:
-        lds_l, r_adv, r_norm_l, _ = vat_frame(params, training, spec, xi, eps, d0_l)
+        lds_l, r_adv, r_norm_l, _ = vat_frame(params, training, spec, xi, eps, d0_l, n_power)
         r_adv = r_adv.squeeze(1)
     else:
         r_adv, lds_l, r_norm_l = None, zero, zero

@@ -300,8 +300,12 @@ class UNet_VAT(nn.Module):
                 loss = term if loss is None else loss + term
             g, = torch.autograd.grad(loss, d)
             g = g.detach()
-        # d = d.grad * 1e10 ; r_adv = eps * d / ||d||   (model/UNet_onset.py:141-151)
-        x_adv, r_adv, d_norm = ops.vat_adversarial(x, g, 1e10, float(self.epsilon), self.nan_flag)
+        # d = d.grad * 1e10 ; r_adv = eps * d / ||d||   (model/UNet_onset.py:141-151).  n_power = 0: the loop body never runs in the
+        # reference either, d stays the random draw and r_adv = eps * d / ||d|| (a RANDOM, not adversarial, perturbation)
+        if g is None:
+            x_adv, r_adv, d_norm = ops.vat_adversarial(x, d.detach(), 1.0, float(self.epsilon), self.nan_flag)
+        else:
+            x_adv, r_adv, d_norm = ops.vat_adversarial(x, g, 1e10, float(self.epsilon), self.nan_flag)
         return x_adv, r_adv, d_norm, refs
 
     def check_nan(self):

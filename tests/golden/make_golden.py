@@ -445,6 +445,61 @@ def g_train_step():
     save('train_step', **out)
 
 
+def g_lds_backward():
+    """The backward of the LDS terms ALONE with an injected perturbation.  At XI = 1e-6 the power
+    iteration's direction is rounding noise, so gradients through it are not comparable between implementations -- but the
+    backward GIVEN a perturbation is deterministic: with `n_power = 0` the reference's loop (model/UNet_onset.py:129-142)
+    never runs, `d = torch.randn_like(x)` (patched: a closed-form tensor) goes straight into
+    r_adv = eps * d / ||d|| (:145), and alpha/2 * sum(LDS terms) back-propagates through
+    transcriber(clamp(x + r_adv)) against the no_grad targets -- soft-target BCE, the clamp, every transcriber layer.
+    Stored: the reference's LDS values and its parameter gradients of 0.5 * sum(LDS) (digests); the oracle must agree."""
+    out = {}
+    real_randn_like = torch.randn_like
+    for kind in ('onset', 'frame'):
+        net, params = build_ref(kind, True)
+        net.vat_loss.n_power = 0
+        bl, bul = _batch(2, 64, 'L'), _batch(2, 64, 'UL')
+        noises = [fx.fixture_noise((2, 1, 64, 229), 'radv_ul'), fx.fixture_noise((2, 1, 64, 229), 'radv_l')]
+        seq = [n.clone() for n in noises]
+
+        def fake(t, **kw):
+            d = seq.pop(0)
+            return d.requires_grad_(True) if kw.get('requires_grad') else d
+        torch.randn_like = fake
+        try:
+            pr, lr, _ = net.run_on_batch(bl, bul, True)
+        finally:
+            torch.randn_like = real_randn_like
+        lds_keys = [k for k in lr if 'LDS' in k]
+        (0.5 * sum(lr[k] for k in lds_keys)).backward()
+        for k in om.trainable_keys(params):
+            params[k].requires_grad_(True)
+        fn = om.run_on_batch_onset if kind == 'onset' else om.run_on_batch_frame
+        po, lo, _ = fn(params, True, bl, bul, True, True, d0_ul=noises[0], d0_l=noises[1], n_power=0)
+        (0.5 * sum(lo[k] for k in lds_keys)).backward()
+        for k in lr:
+            close(lo[k], lr[k], 2e-5, 'lds_backward ' + k)              # deterministic now: tight also on the LDS terms
+        close(po['r_adv'], pr['r_adv'], 1e-6, 'r_adv')
+        named = dict(net.named_parameters())
+        gmax = max(p.grad.abs().max().item() for p in named.values() if p.grad is not None)
+        worst = 0.0
+        for k, p in named.items():
+            if p.grad is None:
+                assert params[k].grad is None, k
+                continue
+            err = (params[k].grad - p.grad).abs().max().item()
+            assert err <= 5e-3 * p.grad.abs().max().item() + 1e-5 * gmax, ('grad ' + k, err)
+            worst = max(worst, err / gmax)
+            out[f'{kind}_g:' + k] = digest(p.grad, 32)
+        print(kind, 'LDS-only gradients: oracle vs reference worst abs err / gmax =', worst)
+        out[f'{kind}_gmax'] = gmax
+        out[f'{kind}_keys'] = np.array(list(lr.keys()))
+        out[f'{kind}_losses'] = np.array([v.item() for v in lr.values()])
+        out[f'{kind}_radv'] = digest(pr['r_adv'], 256)
+        out[f'{kind}_nograd'] = np.array([k for k, p in named.items() if p.grad is None])
+    save('lds_backward', **out)
+
+
 def g_dataset():
     """The reference's PianoRollAudioDataset.__getitem__ (model/dataset.py:35-69) on in-memory tracks: crop positions
     of a RandomState(42) stream over 12 consecutive items, and the decoded crops themselves (exact)."""
@@ -725,7 +780,7 @@ def g_onset_frames():
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['frontend', 'unet', 'attention', 'networks', 'vat', 'run_on_batch', 'train_step', 'dataset',
-                             'decoding', 'onset_frames', 'ingest', 'lds_spread', 'application']
+                             'decoding', 'onset_frames', 'ingest', 'lds_spread', 'application', 'lds_backward']
     for w in which:
         print('==', w)
         globals()['g_' + w]()

@@ -194,26 +194,91 @@ def test_train_step_golden(dev, kind):
         parity_tol.check(f'{kind}_T64_step', k, v, ref, 'train_step')
     assert abs(opt.current_lr() - float(g[f'{kind}_lr'])) < 1e-12
     named = dict(m.named_parameters())
-    gmax = float(g[f'{kind}_gmax'])
     nograd = set(g[f'{kind}_nograd'])
-    agree = total = 0
     for k, p in named.items():
         if k in nograd:
             assert float(p.grad.abs().max()) == 0.0, k          # never touched -> zero gradient, no update
+    # The gradients of this step contain the LDS terms' backward through an adversarial direction that is rounding-noise driven at
+    # XI = 1e-6: they are not comparable between implementations.  The backward of the LDS terms GIVEN a perturbation is
+    # deterministic and is held to the tight bar in test_lds_backward_injected_radv; the rest of the backward in
+    # test_backward_vs_oracle.
+
+
+def _grad_bar_check(kind, m, p64, p32, what, exceptions=None):
+    """Every parameter gradient of `m` against the fp64 oracle evaluation: e_gpu <= 2 x e_cpu32 + 2e-3 (relative L2; BatchNorm
+    biases 3 x + 5e-3, see test_backward_vs_oracle) -- 'at least as accurate as the reference's own fp32 CPU path'."""
+    exceptions = exceptions or {}
+    gmax = max(float(p.grad.abs().max()) for p in p64.values() if p.grad is not None)
+    rows, violators = [], []
+    for k, p in m.named_parameters():
+        g64 = p64[k].grad
+        if g64 is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
-        gd = g[f'{kind}_g:' + k]
-        d = digest(p.grad, 32)
-        # the LDS terms back-propagate through an adversarial direction that is rounding-noise driven at
-        # XI = 1e-6, so these gradients agree only to a fraction of each tensor's scale; the
-        # exact backward check is test_backward_vs_oracle (VAT off) below
-        assert np.abs(d[1:] - gd[1:]).max() <= 0.25 * np.abs(gd[1:]).max() + 1e-4 * gmax, k
-        pd = g[f'{kind}_p:' + k]
-        dp = digest(p, 32)
-        agree += int((np.abs(dp[1:] - pd[1:]) < 1e-5).sum())
-        total += len(pd) - 1
-    # Adam's first update is lr*sign(g): wherever the (chaotic) LDS contribution decides the sign of a small
-    # gradient the weight moves the other way by 2*lr -- ~15 % of the sampled weights on this fixture
-    assert agree / total > 0.75, (agree, total)
+        den = max(g64.norm().item(), 1e-4 * gmax * g64.numel() ** 0.5)
+        e_gpu = (p.grad.cpu().double() - g64).norm().item() / den
+        e_cpu = (p32[k].grad.double() - g64).norm().item() / den
+        rows.append({'param': k, 'e_gpu': e_gpu, 'e_cpu32': e_cpu})
+        bn_bias = k.endswith('.bias') and ('.bn' in k)
+        bar = 3.0 * e_cpu + 5e-3 if bn_bias else 2.0 * e_cpu + 2e-3
+        if k in exceptions:
+            assert e_gpu <= exceptions[k], (k, e_gpu, e_cpu)
+        elif e_gpu > bar:
+            violators.append((k, round(e_gpu, 5), round(e_cpu, 5)))
+    try:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+        os.makedirs(out, exist_ok=True)
+        import json
+        with open(os.path.join(out, f'grad_errors_{what}_{kind}.json'), 'w') as fh:
+            json.dump(rows, fh, indent=0)
+    except OSError:
+        pass
+    assert not violators, violators
+    return rows
+
+
+@pytest.mark.parametrize('kind', ['onset', 'frame'])
+def test_lds_backward_injected_radv(dev, kind):
+    """The backward of alpha/2 * sum(LDS terms) ALONE, with the perturbation injected (n_power = 0: the reference's power-iteration
+    loop never runs and the patched noise goes straight into r_adv = eps * d / ||d||, model/UNet_onset.py:129-151) -- soft-target
+    BCE backward through clamp(x + r_adv) into every transcriber layer at the real graph, labelled and unlabelled branch.
+    Deterministic, so held to the bar of test_backward_vs_oracle (e_gpu <= 2 x e_cpu32 + 2e-3 against the fp64 oracle), and the
+    LDS values and gradient digests to the reference's own (tests/golden/lds_backward.npz)."""
+    from oracle import fixture as fx, model as om
+    g = gold('lds_backward')
+    bl, bul = _batches(dev)
+    noises = [fx.fixture_noise((2, 1, 64, 229), 'radv_ul'), fx.fixture_noise((2, 1, 64, 229), 'radv_l')]
+    m = build(kind, True, dev)
+    m.vat_loss.n_power = 0
+    seq = [n.to(dev) for n in noises]
+    m.vat_loss.noise = lambda t: seq.pop(0).clone()
+    pred, losses, _ = m.run_on_batch(bl, bul, True)
+    assert list(losses.keys()) == list(g[f'{kind}_keys'])
+    for (k, v), ref in zip(losses.items(), g[f'{kind}_losses']):
+        assert abs(float(v.detach()) - float(ref)) <= 1e-3 * abs(float(ref)), (k, float(v.detach()), float(ref))       # LDS terms included
+    close_digest(pred['r_adv'], g[f'{kind}_radv'], 1e-5, 256)
+    lds_keys = [k for k in losses if 'LDS' in k]
+    (0.5 * sum(losses[k] for k in lds_keys)).backward()
+    nograd = set(g[f'{kind}_nograd'])
+    gmax = float(g[f'{kind}_gmax'])
+    for k, p in m.named_parameters():
+        if k in nograd:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            # the reference's own fp32 gradient values: themselves only 0.2 .. 3 % accurate on this BN-heavy network (see
+            # test_backward_vs_oracle), hence 2e-2 here; the tight bar is the fp64 comparison below
+            close_digest(p.grad, g[f'{kind}_g:' + k], 2e-2, 32, floor=2e-5 * gmax)
+    fn = om.run_on_batch_onset if kind == 'onset' else om.run_on_batch_frame
+    ref = {}
+    for dt in (torch.float64, torch.float32):
+        params = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in fx.fixture_params(kind, True).items()}
+        for k in om.trainable_keys(params):
+            params[k].requires_grad_(True)
+        cast = lambda b: {k: v.cpu().to(dt) for k, v in b.items()}
+        _, lo, _ = fn(params, True, cast(bl), cast(bul), True, True, d0_ul=noises[0].to(dt), d0_l=noises[1].to(dt), n_power=0)
+        (0.5 * sum(lo[k] for k in lds_keys)).backward()
+        ref[dt] = params
+    _grad_bar_check(kind, m, ref[torch.float64], ref[torch.float32], 'lds')
 
 
 # Parameter tensors whose fp32 gradient on this fixture is a heavily cancelling sum: the listed bound replaces the generic bar
