@@ -109,12 +109,18 @@ int rv_bn_lrelu_bwd(const float* dy, int dy_ld, const float* z, int z_ld, long P
 
 /* ---- linear layers (nn.Linear / torch.sigmoid call sites, model/UNet_onset.py:50-52,62-64,275,
  * 292-293,307-313,324,330): C[m*scm+n*scn] (+)= act(sum_k A[m*sam+k*sak]*B[k*sbk+n*sbn] + bias[n]);
- * splitk > 1: the reduction is split over workgroups (atomic accumulation); batch > 1: problem z of `batch` equal-shape
- * problems lives at A + z*bsa, B + z*bsb, C + z*bsc (the per-head relative-position gradient of the attention).  a_rowsum (nullable, batch == 1): a_rowsum[m] += sum_k A[m][k] (fp32 atomics): the bias
- * gradient of a linear layer rides on its weight-gradient GEMM (A = dY^T). */
+ * splitk > 1: the reduction is split over workgroups DETERMINISTICALLY -- every k slice parks its partial tile in splitk_ws
+ * (rv_gemm_splitk_workspace_bytes, uninitialised), the last slice of a tile to arrive (splitk_tickets:
+ * rv_gemm_splitk_ticket_bytes, ZERO on entry, left zero) folds them in k order and runs the epilogue, so the result does not
+ * depend on arrival order and no atomics touch C; batch > 1: problem z of `batch` equal-shape problems lives at A + z*bsa,
+ * B + z*bsb, C + z*bsc (the per-head relative-position gradient of the attention).  a_rowsum (nullable, batch == 1):
+ * a_rowsum[m] += sum_k A[m][k] (k slices folded in order): the bias gradient of a linear layer rides on its weight-gradient
+ * GEMM (A = dY^T). */
+long rv_gemm_splitk_workspace_bytes(int M, int N, int splitk, int batch);
+long rv_gemm_splitk_ticket_bytes(int M, int N, int splitk, int batch);
 int rv_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm, long scn, float* C2,
             long sc2m, long sc2n, const float* bias, int M, int N, int K, int act, int accumulate, int splitk, int batch,
-            long bsa, long bsb, long bsc, float* a_rowsum, void* stream);
+            long bsa, long bsb, long bsc, float* a_rowsum, void* splitk_ws, void* splitk_tickets, void* stream);
 int rv_sigmoid_bwd(const float* g1, int ld1, const float* g2, int ld2, const float* y, int ldy, float* dz, int ldz, long M,
                    int N, void* stream);
 int rv_colsum(const float* x, int ld, long M, int N, float* out, int accumulate, void* stream);

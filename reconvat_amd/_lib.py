@@ -41,7 +41,9 @@ SIGNATURES = {
     'rv_bn_running_update': (I, [P, P, P, P, I, F, P]),
     'rv_bn_running_update_table': (I, [P, I, F, P]),
     'rv_bn_lrelu_bwd': (I, [P, I, P, I, L, I, P, F, I, P, I, P, P, I, P, I, P]),
-    'rv_gemm': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, I, I, I, I, I, I, I, L, L, L, P, P]),
+    'rv_gemm_splitk_workspace_bytes': (L, [I, I, I, I]),
+    'rv_gemm_splitk_ticket_bytes': (L, [I, I, I, I]),
+    'rv_gemm': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, I, I, I, I, I, I, I, L, L, L, P, P, P, P]),
     'rv_sigmoid_bwd': (I, [P, I, P, I, P, I, P, I, L, I, P]),
     'rv_colsum': (I, [P, I, L, I, P, I, P]),
     'rv_local_attn_fwd': (I, [P, P, P, L, P, P, P, I, I, I, I, P]),

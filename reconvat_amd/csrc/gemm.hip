@@ -28,11 +28,15 @@ struct GemmArgs {
     int M, N, K;
     int act;            // 0 none, 1 sigmoid
     int accumulate;     // C += (plain read-modify-write; requires splitk == 1)
-    int splitk;         // >1: K split over blockIdx.z, atomicAdd epilogue (C pre-zeroed by the host wrapper)
+    int splitk;         // >1: K split over blockIdx.z; partial tiles go to `part`, the LAST block of a tile to arrive (ticket) folds
+                        // them in k order and runs the epilogue: deterministic, no atomics on C
+    float* part;        // [batch][splitk][tiles][4][256] f32x4 slots (accumulator layout), uninitialised
+    int* tickets;       // [batch][tiles] zero on entry, left zero on exit
+    float* rs_part;     // [splitk][M] partial row sums of A (a_rowsum with splitk > 1)
     int a_vec, b_vec;   // 16-byte loads along the contiguous dimension are legal
     int batch;          // independent problems over blockIdx.z / splitk: A += z*bsa, B += z*bsb, C += z*bsc
     long bsa, bsb, bsc;
-    float* a_rowsum;    // optional: a_rowsum[m] += sum_k A[m][k] (fp32 atomics; the bias gradient riding on a weight-gradient GEMM)
+    float* a_rowsum;    // optional: a_rowsum[m] += sum_k A[m][k] (the bias gradient riding on a weight-gradient GEMM; k slices folded in order)
 };
 
 // One operand tile: `rows` (m or n) x GBK.  KFAST: memory is contiguous along k -> LDS layout [row][k];
@@ -142,8 +146,42 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a_in) {
         }
     }
 
-    if (a.a_rowsum && blockIdx.x == 0 && tid < GBM && m0 + tid < a.M) atomicAdd(&a.a_rowsum[m0 + tid], rowsum);
-    const bool vec_ok = a.scn == 1 && (a.scm & 3) == 0 && ((((uintptr_t)a.C) & 15) == 0) && a.splitk == 1 && !a.C2;
+    if (a.splitk > 1) {
+        // deterministic split-K: park this slice's accumulators, take a ticket; the last slice of the tile to arrive folds all
+        // slices in k order (whoever it is, the summation order is the same) and runs the epilogue
+        const int ntiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
+        f32x4* mine = reinterpret_cast<f32x4*>(a.part) + (((long)bz * a.splitk + kz) * ntiles + tile) * (4 * 256);
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) mine[(x * 2 + y) * 256 + tid] = acc[x][y];
+        if (a.a_rowsum && blockIdx.x == 0 && tid < GBM && m0 + tid < a.M) a.rs_part[(long)kz * a.M + m0 + tid] = rowsum;
+        __threadfence();
+        __shared__ int last;
+        __syncthreads();
+        if (tid == 0) last = (atomicAdd(&a.tickets[bz * ntiles + tile], 1) == a.splitk - 1);
+        __syncthreads();
+        if (!last) return;
+        __threadfence();
+        if (tid == 0) a.tickets[bz * ntiles + tile] = 0;                 // self-clearing: the buffer may serve the next launch
+        const f32x4* all = reinterpret_cast<const f32x4*>(a.part) + ((long)bz * a.splitk * ntiles + tile) * (4 * 256);
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                f32x4 sum = __builtin_nontemporal_load(all + (x * 2 + y) * 256 + tid);
+                for (int z = 1; z < a.splitk; ++z) sum += __builtin_nontemporal_load(all + (long)z * ntiles * (4 * 256) + (x * 2 + y) * 256 + tid);
+                acc[x][y] = sum;
+            }
+        if (a.a_rowsum && blockIdx.x == 0 && tid < GBM && m0 + tid < a.M) {
+            float r = a.rs_part[m0 + tid];
+            for (int z = 1; z < a.splitk; ++z) r += a.rs_part[(long)z * a.M + m0 + tid];
+            a.a_rowsum[m0 + tid] += r;
+        }
+    } else if (a.a_rowsum && blockIdx.x == 0 && tid < GBM && m0 + tid < a.M) {
+        a.a_rowsum[m0 + tid] += rowsum;                                  // one workgroup per row block: plain read-modify-write
+    }
+    const bool vec_ok = a.scn == 1 && (a.scm & 3) == 0 && ((((uintptr_t)a.C) & 15) == 0) && !a.C2;
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -152,7 +190,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a_in) {
             const int nb = n0 + wn + x * 16 + 4 * g;
             if (m >= a.M || nb >= a.N) continue;
             f32x4 v = acc[x][y];
-            if (a.bias && (a.splitk == 1 || kz == 0)) {
+            if (a.bias) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (nb + r < a.N) v[r] += a.bias[nb + r];
@@ -170,53 +208,53 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a_in) {
                 for (int r = 0; r < 4; ++r) {
                     if (nb + r >= a.N) continue;
                     float* cc = c + (long)r * a.scn;
-                    if (a.splitk > 1) atomicAdd(cc, v[r]);
-                    else *cc = a.accumulate ? *cc + v[r] : v[r];
+                    *cc = a.accumulate ? *cc + v[r] : v[r];
                     if (a.C2) a.C2[(long)m * a.sc2m + (long)(nb + r) * a.sc2n] = v[r];
                 }
             }
         }
 }
 
-__global__ void zero_strided_k(float* c, long scm, long scn, int M, int N) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)M * N) return;
-    long m = i / N; int n = (int)(i - m * N);
-    c[m * scm + n * scn] = 0.f;
-}
-
 extern "C" {
 
 // C[m*scm + n*scn] (+)= act(sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] + bias[n]);  act: 0 none, 1 sigmoid.
-// splitk > 1 splits the reduction over extra workgroups (atomic fp32 accumulation; act must be 0, C2 must be null):
-// with accumulate == 0 C is zeroed first, with accumulate != 0 the atomics add straight into C's contents (gradient
-// accumulation).  C2 (nullable) receives a second copy with its own strides.
+// splitk > 1 splits the reduction over extra workgroups, DETERMINISTICALLY: every k slice parks its partial tile in
+// `splitk_ws` (rv_gemm_splitk_workspace_bytes, uninitialised) and the last slice of a tile to arrive -- ticket in
+// `splitk_tickets` (rv_gemm_splitk_ticket_bytes, ZERO on entry, left zero) -- folds them in k order and runs the ordinary
+// epilogue (bias, act, accumulate, C2 all allowed): results do not depend on the arrival order, no atomics touch C.
+// C2 (nullable) receives a second copy with its own strides.
 // batch > 1: `batch` independent problems of the same shape, problem z at A + z*bsa, B + z*bsb, C + z*bsc (C2 must be null).
-// a_rowsum (nullable, batch == 1): a_rowsum[m] += sum_k A[m][k] by fp32 atomics -- the bias gradient of a linear layer for free
-// on its weight-gradient GEMM (A = dY^T).
+// a_rowsum (nullable, batch == 1): a_rowsum[m] += sum_k A[m][k] -- the bias gradient of a linear layer for free on its
+// weight-gradient GEMM (A = dY^T); also folded in k order.
+long rv_gemm_splitk_workspace_bytes(int M, int N, int splitk, int batch) {
+    if (splitk <= 1) return 0;
+    return ((long)batch * splitk * cdiv(M, GBM) * cdiv(N, GBN) * (4 * 256 * 16)) + (long)splitk * M * 4;
+}
+long rv_gemm_splitk_ticket_bytes(int M, int N, int splitk, int batch) {
+    if (splitk <= 1) return 0;
+    return (long)batch * cdiv(M, GBM) * cdiv(N, GBN) * 4;
+}
+
 int rv_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm, long scn, float* C2,
             long sc2m, long sc2n, const float* bias, int M, int N, int K, int act, int accumulate, int splitk, int batch,
-            long bsa, long bsb, long bsc, float* a_rowsum, void* stream) {
+            long bsa, long bsb, long bsc, float* a_rowsum, void* splitk_ws, void* splitk_tickets, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     RV_CHECK_ARG(M > 0 && N > 0 && K > 0, "rv_gemm: empty problem");
     RV_CHECK_ARG(!a_rowsum || batch == 1, "rv_gemm: a_rowsum excludes batch");
     RV_CHECK_ARG(splitk >= 1, "rv_gemm: splitk must be >= 1");
     RV_CHECK_ARG(batch >= 1 && (batch == 1 || !C2) && (long)batch * splitk < 65536, "rv_gemm: bad batch %d", batch);
-    if (splitk > 1) RV_CHECK_ARG(act == 0 && !C2, "rv_gemm: splitk excludes act/C2");
+    if (splitk > 1) RV_CHECK_ARG(splitk_ws && splitk_tickets, "rv_gemm: splitk > 1 needs the partial-tile workspace and zeroed tickets");
     GemmArgs a;
     a.A = A; a.sam = sam; a.sak = sak; a.B = B; a.sbk = sbk; a.sbn = sbn; a.C = C; a.scm = scm; a.scn = scn;
     a.C2 = C2; a.sc2m = sc2m; a.sc2n = sc2n; a.bias = bias; a.M = M; a.N = N; a.K = K; a.act = act;
     a.accumulate = accumulate; a.splitk = splitk; a.batch = batch; a.bsa = bsa; a.bsb = bsb; a.bsc = bsc; a.a_rowsum = a_rowsum;
+    a.part = (float*)splitk_ws; a.tickets = (int*)splitk_tickets;
+    a.rs_part = splitk > 1 ? (float*)splitk_ws + (long)batch * splitk * cdiv(M, GBM) * cdiv(N, GBN) * (4 * 256 * 4) : nullptr;
     const bool a_kfast = (sak <= sam), b_kfast = (sbk <= sbn);
     // 16-byte loads need a unit stride along the fast dimension, a 16-byte multiple along the slow one and an
     // aligned base; K-split offsets are multiples of GBK so they preserve alignment
     a.a_vec = ((a_kfast ? sak : sam) == 1) && (((a_kfast ? sam : sak) & 3) == 0) && ((((uintptr_t)A) & 15) == 0) && (batch == 1 || (bsa & 3) == 0);
     a.b_vec = ((b_kfast ? sbk : sbn) == 1) && (((b_kfast ? sbn : sbk) & 3) == 0) && ((((uintptr_t)B) & 15) == 0) && (batch == 1 || (bsb & 3) == 0);
-    if (splitk > 1 && !accumulate) {
-        RV_CHECK_ARG(batch == 1, "rv_gemm: batched split-K needs accumulate (zero C yourself)");
-        hipLaunchKernelGGL(zero_strided_k, dim3(cdiv((long)M * N, 256)), dim3(256), 0, st, C, scm, scn, M, N);
-        RV_LAUNCH_CHECK("rv_gemm(zero)");
-    }
     dim3 grid(cdiv(N, GBN), cdiv(M, GBM), splitk * batch);
     if (a_kfast && b_kfast) hipLaunchKernelGGL((gemm_mfma_k<true, true>), grid, dim3(256), 0, st, a);
     else if (a_kfast && !b_kfast) hipLaunchKernelGGL((gemm_mfma_k<true, false>), grid, dim3(256), 0, st, a);

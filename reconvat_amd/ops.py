@@ -843,8 +843,14 @@ def gemm(a, b_kn, c, bias=None, act=0, accumulate=False, splitk=1, c2=None, batc
         pc2, _, _, s2m, s2n = _mat(c2)
     else:
         pc2, s2m, s2n = None, 0, 0
+    ws = tk = None
+    if splitk > 1:
+        # deterministic split-K: partial tiles are parked in `ws`, the last k slice of a tile (zeroed ticket word) folds them in order
+        lib = _lib.load()
+        ws = torch.empty(lib.rv_gemm_splitk_workspace_bytes(m, n, splitk, batch) // 4, device=c.device, dtype=torch.float32)
+        tk = ARENA.take((lib.rv_gemm_splitk_ticket_bytes(m, n, splitk, batch) + 7) // 8, c.device)
     call('rv_gemm', pa, sam, sak, pb, sbk, sbn, pc, scm, scn, pc2, s2m, s2n, ptr(bias), m, n, k, act,
-         1 if accumulate else 0, splitk, batch, bstrides[0], bstrides[1], bstrides[2], ptr(a_rowsum), stream())
+         1 if accumulate else 0, splitk, batch, bstrides[0], bstrides[1], bstrides[2], ptr(a_rowsum), ptr(ws), ptr(tk), stream())
 
 
 def colsum(x2d, out=None, accumulate=False):
