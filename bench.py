@@ -260,7 +260,7 @@ def measure_in_situ(step_fn, device):
     for _ in range(50):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        lib.rv_counter_add(cnt.data_ptr(), 1, torch.cuda.current_stream().cuda_stream)
+        lib.rv_counter_add(cnt.data_ptr(), 1, None, torch.cuda.current_stream().cuda_stream)
         e1.record()
         floors.append((e0, e1))
     torch.cuda.synchronize()

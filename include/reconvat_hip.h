@@ -154,7 +154,7 @@ int rv_loss_bwd(int kind, const float* p, const float* t, long n, const float* g
  * when *skip != 0 (a kernel of this step flagged its results invalid, see rv_lstm_fwd) the update is not applied. */
 int rv_adam_step(float* p, const float* g, float* m, float* v, long n, const long* step, float lr0, long decay_steps,
                  float decay_rate, float beta1, float beta2, float eps, float grad_scale, const int* skip, void* stream);
-int rv_counter_add(long* counter, long inc, void* stream);
+int rv_counter_add(long* counter, long inc, const int* skip_if_set, void* stream);   /* skip_if_set nullable: no add while *skip != 0 */
 int rv_clip_scale(float* g, long n, const float* total_norm, float max_norm, void* stream);
 
 /* ---- data feed: PianoRollAudioDataset.__getitem__ (model/dataset.py:35-69) for a whole batch on the device.

@@ -54,7 +54,7 @@ SIGNATURES = {
     'rv_reduce_mean': (I, [I, P, P, L, P, P, P, P]),
     'rv_loss_bwd': (I, [I, P, P, L, P, P, P]),
     'rv_adam_step': (I, [P, P, P, P, L, P, F, L, F, F, F, F, F, P, P]),
-    'rv_counter_add': (I, [P, L, P]),
+    'rv_counter_add': (I, [P, L, P, P]),
     'rv_clip_scale': (I, [P, L, P, F, P]),
     'rv_crop_segments': (I, [P, P, P, P, P, I, L, I, I, P, P, P, P, P, P]),
     'rv_lstm_flag_bytes': (L, [I]),

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void adam_k(AdamArgs a) {
     }
 }
 
-__global__ void counter_add_k(long* c, long inc) { *c += inc; }
+__global__ void counter_add_k(long* c, long inc, const int* skip) { if (!skip || *skip == 0) *c += inc; }
 
 __global__ __launch_bounds__(256) void scale_by_clip_k(float* g, long n, const float* total_norm, float max_norm) {
     // torch.nn.utils.clip_grad_norm_: coef = clamp(max_norm / (total_norm + 1e-6), max=1)
@@ -338,7 +338,7 @@ int rv_colsum(const float* x, int ld, long M, int N, float* out, int accumulate,
 }
 
 // One Adam step on flat buffers; lr = lr0 * decay_rate^(step // decay_steps) (StepLR); *step is NOT modified
-// (call rv_counter_add afterwards).  grad_scale multiplies g on the fly (1/world_size after an all-reduce sum).
+// (call rv_counter_add afterwards, with the same skip word).  grad_scale multiplies g on the fly (1/world_size after an all-reduce sum).
 int rv_adam_step(float* p, const float* g, float* m, float* v, long n, const long* step, float lr0, long decay_steps,
                  float decay_rate, float beta1, float beta2, float eps, float grad_scale, const int* skip, void* stream) {
     AdamArgs a;
@@ -350,8 +350,10 @@ int rv_adam_step(float* p, const float* g, float* m, float* v, long n, const lon
     return RV_OK;
 }
 
-int rv_counter_add(long* counter, long inc, void* stream) {
-    hipLaunchKernelGGL(counter_add_k, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, inc);
+// skip (nullable): the per-device "this step is invalid" word -- while it is set the counter does not move either, so a step
+// whose update rv_adam_step skipped advances neither StepLR nor the bias correction.
+int rv_counter_add(long* counter, long inc, const int* skip, void* stream) {
+    hipLaunchKernelGGL(counter_add_k, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, inc, skip);
     RV_LAUNCH_CHECK("rv_counter_add");
     return RV_OK;
 }

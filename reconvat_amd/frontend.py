@@ -67,8 +67,10 @@ class MelSpectrogram(nn.Module):
     def __init__(self, sr=SAMPLE_RATE, n_fft=WINDOW_LENGTH, n_mels=N_BINS, hop_length=HOP_LENGTH, fmin=MEL_FMIN,
                  fmax=MEL_FMAX):
         super().__init__()
-        if n_fft != 2048:
-            raise ValueError('the fused front-end kernel is built for n_fft = 2048')
+        if n_fft != 2048 or hop_length != 512 or n_mels > 256:
+            raise ValueError('the fused front-end kernel (csrc/mel.hip: four frames per workgroup sharing one audio chunk, one thread '
+                             f'per mel band) is built for n_fft = 2048, hop_length = 512, n_mels <= 256; got n_fft={n_fft}, '
+                             f'hop_length={hop_length}, n_mels={n_mels} (the reference scripts use 2048 / 512 / 229)')
         self.n_fft, self.hop, self.n_mels = n_fft, hop_length, n_mels
         self.stft = STFT(n_fft)
         self.register_buffer('mel_basis', torch.from_numpy(slaney_mel_basis(sr, n_fft, n_mels, fmin, fmax)))
@@ -86,7 +88,13 @@ class MelSpectrogram(nn.Module):
         start = nz.argmax(1).astype(np.int32)
         last = (basis.shape[1] - 1 - nz[:, ::-1].argmax(1)).astype(np.int32)
         length = np.where(nz.any(1), last - start + 1, 0).astype(np.int32)
-        ld = int(max(32, length.max()))
+        if int(length.max()) > 32:
+            raise ValueError(f'the fused front-end kernel keeps 32 filter taps per mel band in registers; the widest band of this '
+                             f'filterbank spans {int(length.max())} FFT bins (fewer mel bands / a higher fmax than the reference '
+                             "scripts' 229 bands over 30 .. 8000 Hz widen the bands)")
+        # taps past a band's end are stored as zeros and still multiplied: like the reference's dense `mel_basis @ spec`
+        # (0 * inf = nan there poisons EVERY band), a non-finite power bin is not contained to its own bands -- finite audio assumed
+        ld = 32
         w = np.zeros((basis.shape[0], ld), dtype=np.float32)
         for i in range(basis.shape[0]):
             w[i, :length[i]] = basis[i, start[i]:start[i] + length[i]]

@@ -170,6 +170,7 @@ class OnsetsAndFrames_VAT_full(_Base):
         return self._front(audio, ref_len).squeeze(1)
 
     side_streams = 2           # TrainStep: twin gradient buckets to provide
+    has_recurrence = True      # BiLSTM time-out flag: data-parallel ranks agree on skipped steps (train.allreduce_gradients)
     defer_wgrad_reductions = False   # few conv layers, three chains: one reduction launch per chain end measured slower (91.5 vs 87.5 ms)
 
     def _two_streams(self, audio_ul, audio_l, VAT):
@@ -298,6 +299,7 @@ class stepwise_VAT_frame_stack(nn.Module):
 class Frame_stack_VAT(_Base):
     """model/onset_frame_VAT.py:417-514 (`model_name='frame'` of the baseline script): ConvStack -> Linear -> sigmoid ->
     BiLSTM(88 -> 768) -> Linear -> sigmoid."""
+    has_recurrence = True
 
     def __init__(self, input_features, output_features, model_complexity=48, log=True, mode='imagewise', spec='Mel', XI=1e-5,
                  eps=10, VAT_mode='all'):
@@ -339,6 +341,7 @@ class Frame_stack_VAT(_Base):
 class Onset_stack_VAT(_Base):
     """model/onset_frame_VAT.py:516-601 (`model_name='onset'`): the onset stack alone.  Its VAT branch references undefined
     names in the reference (stepwise_VAT_onset_stack, :305-306), so only VAT=False exists."""
+    has_recurrence = True
 
     def __init__(self, input_features, output_features, model_complexity=48, log=True, mode='imagewise', spec='Mel', XI=1e-5,
                  eps=10, VAT_mode='all'):

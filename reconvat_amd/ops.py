@@ -1252,7 +1252,7 @@ def drop_epoch(device):
 
 
 def bump_drop_epoch(device):
-    call('rv_counter_add', ptr(drop_epoch(device)), 1, stream())
+    call('rv_counter_add', ptr(drop_epoch(device)), 1, None, stream())
 
 
 _LSTM_ERR = {}

@@ -141,6 +141,7 @@ class FlatAdam:
         ops.step_error_word(dev)                # create the per-device error word outside any graph capture
         # the ONE all-reduce call site of a step is step(); None = whenever a process group with world > 1 is up
         self.data_parallel = data_parallel
+        self.sync_error_word = False            # TrainStep sets it for models with a recurrence (see allreduce_gradients)
         ops.invalidate_weight_cache()
 
     @staticmethod
@@ -174,7 +175,8 @@ class FlatAdam:
         call('rv_adam_step', ptr(self.flat_param), ptr(self.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n,
              ptr(self.step_count), self.lr, self.step_size, self.gamma, self.betas[0], self.betas[1], self.eps,
              self.grad_scale, ptr(ops.step_error_word(self.flat_grad.device)), stream())
-        call('rv_counter_add', ptr(self.step_count), 1, stream())
+        # (same skip word: a step whose update was skipped advances neither StepLR nor the bias correction)
+        call('rv_counter_add', ptr(self.step_count), 1, ptr(ops.step_error_word(self.flat_grad.device)), stream())
         ops.invalidate_weight_cache()
 
     def clip_grad_norm_(self, max_norm):
@@ -235,6 +237,10 @@ def allreduce_gradients(opt):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(opt.flat_grad, op=dist.ReduceOp.SUM)
         opt.grad_scale = 1.0 / dist.get_world_size()
+        if getattr(opt, 'sync_error_word', False):
+            # models with a recurrence (BiLSTM time-out flag): every rank must skip the same steps, or the replicas diverge and the
+            # rank that raises in check() leaves its peers blocked in the next collective -- MAX the flag along with the gradients
+            dist.all_reduce(ops.step_error_word(opt.flat_grad.device), op=dist.ReduceOp.MAX)
 
 
 class TrainStep:
@@ -254,6 +260,8 @@ class TrainStep:
         self.pack_plan = None
         self.dual_stream = dual_stream        # the two VAT chains on two HIP streams (model._vat_two_streams)
         self._dual_ready = False              # ... from the second step on: the first one packs weights and autotunes
+        if getattr(model, 'has_recurrence', False):
+            opt.sync_error_word = True
         if dual_stream and self.batch['audio'].is_cuda:
             ops.prepare_replay_pool()
         if graph and self.batch['audio'].is_cuda:

@@ -154,7 +154,8 @@ def fake_call(name, *a):
         bc1, bc2 = 1 - b1 ** (t + 1), 1 - b2 ** (t + 1)
         p.sub_((lr / bc1) * m / (v.sqrt() / math.sqrt(bc2) + eps))
     elif name == 'rv_counter_add':
-        a[0].add_(a[1])
+        if a[2] is None or int(a[2].item()) == 0:
+            a[0].add_(a[1])
     else:
         raise AssertionError(name)
 tr.call, tr.ptr, tr.stream = fake_call, (lambda t: t), (lambda: None)
