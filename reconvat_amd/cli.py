@@ -40,7 +40,7 @@ def base_config(o, onset_script):
         step_size_up=100, max_lr=1e-4, learning_rate=1e-3, learning_rate_decay_steps=1000,
         learning_rate_decay_rate=0.98, leave_one_out=None, clip_gradient_norm=3, refresh=False,
         # MI355X-side extras (not in the reference)
-        graph=True, fused_optimizer=True, saving_freq=saving_freq, device_feed=True,
+        graph=True, fused_optimizer=True, saving_freq=saving_freq, logging_freq=logging_freq, device_feed=True,
     )
     c.update(o)
     if torch.cuda.is_available() and torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory < 10e9:
@@ -73,7 +73,7 @@ def baseline_config(o):
         model_name='onset_frame', VAT_start=0, small=True, supersmall=False, batch_size=8, train_batch_size=8,
         sequence_length=327680, epoches=20000, learning_rate=5e-4, learning_rate_decay_steps=10000,
         learning_rate_decay_rate=0.98, leave_one_out=None, clip_gradient_norm=3, refresh=False, reconstruction=False,
-        graph=True, fused_optimizer=True, saving_freq=saving_freq, device_feed=True,
+        graph=True, fused_optimizer=True, saving_freq=saving_freq, logging_freq=logging_freq, device_feed=True,
     )
     c.update(o)
     if c['model_name'] not in ('onset_frame', 'frame', 'onset'):
@@ -104,11 +104,34 @@ class ScalarLog:
         self.f.flush()
 
 
+def log_validation(model, val_set, l_loader, ep, writer, reconstruction, onset_script, VAT, VAT_start):
+    """The scalar half of tensorboard_log (model/helper_functions.py:120-141): `evaluate_wo_velocity(validation_dataset, model,
+    reconstruction=reconstruction, VAT=False)` -- precision / recall / f1 of every non-chroma metric logged under its key -- then
+    `eval_model(model, ep, supervised_loader, VAT_start, VAT)` -- the mean of every eval-mode loss key."""
+    from .evaluate import evaluate_wo_velocity
+    from .train import eval_model
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        metrics = evaluate_wo_velocity(val_set, model, reconstruction=reconstruction, VAT=False)
+    for key, values in metrics.items():
+        if key.startswith('metric/') and values:
+            _, category, name = key.split('/')
+            print(f'{category:>32} {name:25}: {np.mean(values):.3f} \u00b1 {np.std(values):.3f}')
+            if ('precision' in name or 'recall' in name or 'f1' in name) and 'chroma' not in name:
+                writer.add_scalar(key, float(np.mean(values)), ep)
+    test_losses = eval_model(model, ep, l_loader, VAT_start, VAT)
+    for key, values in test_losses.items():
+        if key.startswith('loss/'):
+            writer.add_scalar(key, float(np.mean(values)), ep)
+    model.train(was_training)
+
+
 def run_training(onset_script, spec, resume_iteration, train_on, batch_size, sequence_length, small, supersmall,
                  train_batch_size, learning_rate, learning_rate_decay_steps, learning_rate_decay_rate, alpha,
                  clip_gradient_norm, validation_length, refresh, device, epoches, logdir, log, iteration, VAT_start, VAT,
                  XI, eps, reconstruction, graph, fused_optimizer, saving_freq, device_feed=True, model_complexity=48, model_name='onset_frame', VAT_mode='all',
-                 **_unused):
+                 logging_freq=logging_freq, **_unused):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if not str(device).startswith('cuda') or not torch.cuda.is_available():
@@ -119,11 +142,14 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
         device = f'cuda:{local}'
         torch.cuda.set_device(local)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device(device))
+        # rank 0 alone runs the validation passes (whole songs can take minutes) while its peers wait at a barrier: a generous
+        # collective timeout keeps the watchdog from firing on that wait
+        from datetime import timedelta
+        dist.init_process_group('nccl', device_id=torch.device(device), timeout=timedelta(hours=4))
     elif str(device).startswith('cuda'):
         torch.cuda.set_device(torch.device(device))
 
-    l_set, ul_set, val_set, _full = prepare_VAT_dataset(sequence_length=sequence_length, validation_length=validation_length,
+    l_set, ul_set, val_set, full_validation = prepare_VAT_dataset(sequence_length=sequence_length, validation_length=validation_length,
                                                         refresh=refresh, device=device, small=small, supersmall=supersmall,
                                                         dataset=train_on, rank=rank)
     if device_feed and hasattr(l_set, 'data') and str(device).startswith('cuda'):
@@ -134,6 +160,14 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
     else:
         ul_loader = DataLoader(ul_set, batch_size, shuffle=True, drop_last=True) if VAT else None
         l_loader = DataLoader(l_set, train_batch_size, shuffle=True, drop_last=True)
+
+    # which recordings this rank trains on (labelled / unlabelled corpus and this rank's shard of each)
+    os.makedirs(logdir, exist_ok=True)
+    with open(os.path.join(logdir, f'corpus_rank{rank}.json'), 'w') as fh:
+        paths = lambda ds: [str(d['path']) for d in getattr(ds, 'data', [])]
+        json.dump({'train_on': train_on, 'rank': rank, 'world': world, 'labelled': paths(l_set), 'unlabelled': paths(ul_set),
+                   'labelled_shard': list(getattr(l_loader, 'paths', [])), 'unlabelled_shard': list(getattr(ul_loader, 'paths', [])),
+                   'validation': paths(val_set), 'full_validation': paths(full_validation)}, fh, indent=0)
 
     torch.manual_seed(0)                                   # identical initial weights on every rank
     if onset_script == 'baseline':
@@ -203,27 +237,41 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
             from . import ops
             ops.lstm_check(torch.device(device))          # eager loop: a timed-out recurrence launch fails the epoch loudly
         if rank == 0:
+            # the scalar part of the reference's tensorboard_log (model/helper_functions.py:120-141; the figures are out of scope):
+            # every `logging_freq` epochs (and after the first) note / frame metrics on the validation segments and the eval-mode
+            # loss terms over the labelled loader
+            if ep % logging_freq == 0 or ep == 1:
+                log_validation(model, val_set, l_loader, ep, writer, reconstruction, onset_script, VAT and ep >= VAT_start, VAT_start)
             for key, value in losses.items():
                 writer.add_scalar(key, float(value), ep)
             if ep % saving_freq == 0:
                 torch.save(model.state_dict(), os.path.join(logdir, f'model-{ep}.pt'))
                 torch.save(optimizer.state_dict(), os.path.join(logdir, 'last-optimizer-state.pt'))
+        if world > 1 and (ep % logging_freq == 0 or ep == 1):
+            dist.barrier()                                 # the other ranks wait for rank 0's validation pass
     if rank == 0:
         torch.save(model.state_dict(), os.path.join(logdir, 'model-final.pt'))
-        # final evaluation as in the reference scripts (train_UNet_Onset_VAT.py:140-160): note / frame metrics on the
-        # validation segments (reconvat_amd/evaluate.py)
+        # final evaluation exactly as the reference scripts end (train_UNet_Onset_VAT.py:156-170): WHOLE songs of the test split
+        # (`full_validation`, sequence_length=None), transcriptions written to <logdir>/MIDI_results, metrics pickled to
+        # <logdir>/result_dict
+        import pickle
         from .evaluate import evaluate_wo_velocity
+        print('Training finished, now evaluating on the test split (full songs)')
         model.eval()
         with torch.no_grad():
-            loader = DataLoader(val_set, 1, shuffle=False)
-            metrics = evaluate_wo_velocity((b for i, b in enumerate(loader) if i < 4), model, reconstruction=reconstruction,
-                                           onset=bool(onset_script), VAT=True)
-        for key, values in sorted(metrics.items()):
-            if key.startswith('metric/') and values:
+            metrics = evaluate_wo_velocity(full_validation, model, reconstruction=False, save_path=os.path.join(logdir, 'MIDI_results'))
+        for key, values in metrics.items():
+            if key.startswith('metric/'):
+                _, category, name = key.split('/')
+                print(f'{category:>32} {name:25}: {np.mean(values):.3f} \u00b1 {np.std(values):.3f}')
                 writer.add_scalar('validation/' + key, float(np.mean(values)), epoches)
+        with open(os.path.join(logdir, 'result_dict'), 'wb') as fh:
+            pickle.dump(dict(metrics), fh)
         f1 = float(np.mean(metrics['metric/frame/f1'])) if metrics['metric/frame/f1'] else float('nan')
         print(f'Training finished.  validation frame F1 {f1:.4f}, note F1 '
               f"{float(np.mean(metrics['metric/note/f1'])) if metrics['metric/note/f1'] else float('nan'):.4f}")
+    if world > 1:
+        dist.barrier()                                     # nobody tears the process group down while rank 0 still evaluates
     if world > 1:
         dist.destroy_process_group()
     return model

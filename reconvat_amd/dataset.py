@@ -329,6 +329,8 @@ class SyntheticSegments(Dataset):
         return self._tracks
 
     def __getitem__(self, index):
+        if not 0 <= index < self.n:
+            raise IndexError(index)                        # `for item in dataset` stops here, like a list-backed dataset
         g = torch.Generator().manual_seed(self.seed * 1000003 + index)
         steps = self.sequence_length // HOP_LENGTH
         audio = torch.rand(self.sequence_length, generator=g) * 0.2 - 0.1

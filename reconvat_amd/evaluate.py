@@ -7,16 +7,19 @@ definitions -- PARITY UNPINNED for these two functions (no reference output avai
 argument conventions and the metric keys follow the reference, and tests/test_decoding.py checks them on cases with
 known answers.  ``average_precision_score`` is scikit-learn's, as in the reference.
 """
+import os
 import sys
 from collections import defaultdict
 
 import numpy as np
+import torch
 from scipy.sparse import csr_matrix
 from scipy.sparse.csgraph import maximum_bipartite_matching
 from scipy.stats import hmean
 
 from .constants import HOP_LENGTH, SAMPLE_RATE, MIN_MIDI
 from .decoding import extract_notes_wo_velocity, notes_to_frames
+from .midi import save_midi
 
 eps = sys.float_info.epsilon
 N_DECIMALS = 4          # mir_eval rounds time differences to 0.1 ms before comparing with a tolerance
@@ -146,7 +149,8 @@ def evaluate_wo_velocity(data, model, onset_threshold=0.5, frame_threshold=0.5, 
                          onset=True, pseudo_onset=False, rule='rule2', VAT=False):
     """model/evaluate_functions.py:20-127: whole-song evaluation; returns a dict of lists with the reference's keys
     (losses, metric/note/*, metric/note-with-offsets/*, metric/frame/*, metric/MusicNet/micro_avg_P, and the *_2
-    variants of the reconstruction pass).  ``save_path`` (piano-roll images / MIDI) is outside the hot-path build."""
+    variants of the reconstruction pass).  ``save_path``: per song `<basename>.pred.mid` (the transcription, reconvat_amd/midi.py)
+    and the `<basename>.label.png` / `.pred.png` piano rolls (model/utils.py:61-80), as the reference writes them (:119-126)."""
     from sklearn.metrics import average_precision_score
     metrics = defaultdict(list)
     for label in data:
@@ -195,4 +199,27 @@ def evaluate_wo_velocity(data, model, onset_threshold=0.5, frame_threshold=0.5, 
                 average_precision_score(lab_fr.cpu().flatten().numpy(), pred['frame2'].cpu().flatten().numpy()))
         for key, value in frame_metrics.items():
             metrics['metric/frame/' + key.lower().replace(' ', '_')].append(value)
+        if save_path is not None:
+            os.makedirs(save_path, exist_ok=True)
+            path = label['path'][0] if isinstance(label['path'], (list, tuple)) else label['path']
+            stem = os.path.join(save_path, os.path.basename(str(path)))
+            save_pianoroll(stem + '.label.png', lab_on, lab_fr)
+            save_pianoroll(stem + '.pred.png', pred['onset'] if pred.get('onset') is not None else pred['frame'], pred['frame'])
+            save_midi(stem + '.pred.mid', p_est, i_est, [127] * len(p_est))
     return metrics
+
+
+def save_pianoroll(path, onsets, frames, onset_threshold=0.5, frame_threshold=0.5, zoom=4):
+    """model/utils.py:61-80: RGB piano-roll diagram (onsets / frames / both, pitch upwards, `zoom` x stretched).  Needs PIL; without
+    it the diagram is skipped (the MIDI file and the metrics do not depend on it)."""
+    try:
+        from PIL import Image
+    except ImportError:
+        return False
+    on = (1 - (onsets.t() > onset_threshold).to(torch.uint8)).cpu()
+    fr = (1 - (frames.t() > frame_threshold).to(torch.uint8)).cpu()
+    both = 1 - (1 - on) * (1 - fr)
+    image = torch.stack([on, fr, both], dim=2).flip(0).mul(255).numpy()
+    image = Image.fromarray(image, 'RGB')
+    image.resize((image.size[0], image.size[1] * zoom)).save(path)
+    return True

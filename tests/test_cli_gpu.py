@@ -16,9 +16,9 @@ SMALL = ['train_on=Synthetic', 'small=True', 'supersmall=True', 'sequence_length
          'iteration=2']
 
 
-def run(script, *args, expect_ok=True, timeout=900):
+def run(script, *args, expect_ok=True, timeout=900, cwd=ROOT):
     env = dict(os.environ, PYTHONPATH=ROOT)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, script), 'with', *args], capture_output=True, text=True, cwd=ROOT,
+    p = subprocess.run([sys.executable, os.path.join(ROOT, script), 'with', *args], capture_output=True, text=True, cwd=cwd,
                        env=env, timeout=timeout)
     if expect_ok:
         assert p.returncode == 0, p.stdout[-3000:] + '\n---\n' + p.stderr[-3000:]
@@ -60,8 +60,9 @@ def test_onset_script_checkpoint_resume_final_eval(dev, tmp_path):
             'loss/train_LDS_l_frame', 'loss/train_LDS_l_onset', 'loss/train_LDS_ul_frame', 'loss/train_LDS_ul_onset',
             'loss/train_r_norm_l', 'loss/train_r_norm_ul'}
     for ep in (1, 2):
-        assert {r['tag'] for r in rows if r['step'] == ep and r['tag'].startswith('loss/')} == keys
+        assert {r['tag'] for r in rows if r['step'] == ep and r['tag'].startswith('loss/train_')} == keys
     assert any(r['tag'] == 'validation/metric/frame/f1' for r in rows)
+    _check_evaluation_contract(logdir, rows, n_songs=4, first_epoch_logged=True)
     # resume from epoch 1: runs epoch 2 only, continues the optimiser (step 2 -> 4) and the StepLR position
     p = run('train_UNet_Onset_VAT.py', *SMALL, 'reconstruction=True', 'epoches=2', 'saving_freq=1', f'logdir={logdir}',
             'resume_iteration=2', 'epoches=3')
@@ -69,6 +70,74 @@ def test_onset_script_checkpoint_resume_final_eval(dev, tmp_path):
     assert 'Train Epoch: 3' in p.stdout and 'Train Epoch: 2\t' not in p.stdout and 'Train Epoch: 1\t' not in p.stdout
     osd = torch.load(os.path.join(logdir, 'last-optimizer-state.pt'), map_location='cpu')
     assert {float(st['step']) for st in osd['state'].values()} == {6.0}
+
+
+METRIC_KEYS = {f'metric/{c}/{n}' for c in ('note', 'note-with-offsets') for n in ('precision', 'recall', 'f1', 'overlap')} | \
+    {'metric/frame/f1', 'metric/MusicNet/micro_avg_P', 'metric/frame/precision', 'metric/frame/recall', 'metric/frame/accuracy',
+     'metric/frame/substitution_error', 'metric/frame/miss_error', 'metric/frame/false_alarm_error', 'metric/frame/total_error',
+     'metric/frame/chroma_precision', 'metric/frame/chroma_recall', 'metric/frame/chroma_accuracy',
+     'metric/frame/chroma_substitution_error', 'metric/frame/chroma_miss_error', 'metric/frame/chroma_false_alarm_error',
+     'metric/frame/chroma_total_error'}
+
+
+def _check_evaluation_contract(logdir, rows, n_songs, first_epoch_logged):
+    """What the reference scripts leave behind (train_UNet_Onset_VAT.py:136-170, model/helper_functions.py:120-141):
+    <logdir>/result_dict = pickle of the whole-song metrics dict, <logdir>/MIDI_results/<song>.pred.mid (+ piano-roll PNGs),
+    and -- every logging_freq epochs and after epoch 1 -- the validation precision / recall / f1 scalars plus the eval-mode
+    loss terms of eval_model."""
+    import pickle
+    from reconvat_amd.midi import parse_midi
+    with open(os.path.join(logdir, 'result_dict'), 'rb') as fh:
+        metrics = pickle.load(fh)
+    assert METRIC_KEYS <= set(metrics), METRIC_KEYS - set(metrics)
+    assert all(len(metrics[k]) == n_songs for k in METRIC_KEYS)
+    assert any(k.startswith('loss/test_') for k in metrics)
+    mids = sorted(f for f in os.listdir(os.path.join(logdir, 'MIDI_results')) if f.endswith('.pred.mid'))
+    assert len(mids) == n_songs, mids
+    parse_midi(os.path.join(logdir, 'MIDI_results', mids[0]))                  # a well-formed standard MIDI file
+    pngs = [f for f in os.listdir(os.path.join(logdir, 'MIDI_results')) if f.endswith('.png')]
+    assert len(pngs) in (0, 2 * n_songs)                                         # label + prediction rolls when PIL is present
+    if first_epoch_logged:
+        ep1 = {r['tag'] for r in rows if r['step'] == 1}
+        assert {'metric/note/f1', 'metric/frame/f1', 'metric/note-with-offsets/precision'} <= ep1, ep1
+        assert not any('chroma' in t for t in ep1 if t.startswith('metric/'))
+        assert any(t.startswith('loss/test_') for t in ep1), ep1              # eval_model over the labelled loader
+
+
+def test_config5_string_corpus_on_device(dev, tmp_path):
+    """BASELINE config 5 end to end on the device: `train_UNet_Onset_VAT.py with train_on=String small=True reconstruction=True`
+    over a MusicNet-layout corpus (labelled = first recording of each string ensemble, unlabelled = the rest,
+    model/dataset.py:238-342) ingested from wav + tsv, resident in HBM (DeviceCorpus), trained for two steps, evaluated on the
+    four whole test_violin recordings.  The corpus split must equal what the REFERENCE's MusicNet class produced on the same
+    files (tests/golden/ingest.npz), and data-parallel rank shards must be disjoint and complete."""
+    import numpy as np
+    from oracle import dataset as od
+    corpus = str(tmp_path / 'corpus')
+    od.ingest_corpus(corpus)
+    logdir = str(tmp_path / 'string')
+    p = run('train_UNet_Onset_VAT.py', 'train_on=String', 'small=True', 'reconstruction=True', 'epoches=1', 'iteration=2',
+            'sequence_length=8192', 'batch_size=2', 'train_batch_size=2', 'saving_freq=1', f'logdir={logdir}', cwd=corpus)
+    assert 'Training finished.' in p.stdout and 'Train Epoch: 1' in p.stdout
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'ingest.npz'))
+    with open(os.path.join(logdir, 'corpus_rank0.json')) as fh:
+        info = json.load(fh)
+    rel = lambda paths: [os.path.splitext(os.path.relpath(os.path.join(corpus, q) if not os.path.isabs(q) else q, corpus))[0] for q in paths]
+    assert rel(info['labelled']) == list(g['mn_train_string_l_paths'])
+    assert rel(info['unlabelled']) == list(g['mn_train_string_ul_paths'])
+    assert rel(info['full_validation']) == list(g['mn_test_violin_paths'])
+    assert sorted(info['labelled_shard']) == sorted(info['labelled'])             # world 1: the whole corpus on this rank
+    rows = scalar_tags(logdir)
+    _check_evaluation_contract(logdir, rows, n_songs=4, first_epoch_logged=True)
+    # rank shards of the device feed (what `torch.distributed.run --nproc-per-node 2` hands each rank): disjoint, complete
+    from reconvat_amd.dataset import MusicNet
+    from reconvat_amd.feed import device_loader
+    for group, bs in (('train_string_l', 2), ('train_string_ul', 2)):
+        ds = MusicNet(os.path.join(corpus, 'MusicNet'), [group], sequence_length=8192)
+        shards = [device_loader(ds, bs, dev, rank=r, world=2, seed=42 + r).paths for r in range(2)]
+        assert not set(shards[0]) & set(shards[1])
+        assert sorted(shards[0] + shards[1]) == sorted(d['path'] for d in ds.data)
+        batch = next(iter(device_loader(ds, bs, dev, rank=1, world=2, seed=43)))
+        assert batch['audio'].shape == (bs, 8192) and batch['audio'].is_cuda and set(batch['path']) <= set(shards[1])
 
 
 def test_plumbing_config_on_gpu_and_cpu_device_message(dev, tmp_path):
@@ -79,7 +148,7 @@ def test_plumbing_config_on_gpu_and_cpu_device_message(dev, tmp_path):
             f'logdir={logdir}')
     assert 'Training finished.' in p.stdout
     rows = scalar_tags(logdir)
-    assert {r['tag'] for r in rows if r['tag'].startswith('loss/')} == {'loss/train_frame', 'loss/train_LDS_l', 'loss/train_LDS_ul',
+    assert {r['tag'] for r in rows if r['tag'].startswith('loss/train_')} == {'loss/train_frame', 'loss/train_LDS_l', 'loss/train_LDS_ul',
                                                                            'loss/train_r_norm_l', 'loss/train_r_norm_ul'}
     p = run('train_UNet_VAT.py', *SMALL, 'VAT=False', 'reconstruction=False', 'epoches=1', 'device=cpu', expect_ok=False)
     assert p.returncode != 0 and 'MI355X only' in (p.stderr + p.stdout) and 'Traceback' not in p.stderr
