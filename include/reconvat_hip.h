@@ -109,7 +109,8 @@ int rv_bn_lrelu_bwd(const float* dy, int dy_ld, const float* z, int z_ld, long P
 
 /* ---- linear layers (nn.Linear / torch.sigmoid call sites, model/UNet_onset.py:50-52,62-64,275,
  * 292-293,307-313,324,330): C[m*scm+n*scn] (+)= act(sum_k A[m*sam+k*sak]*B[k*sbk+n*sbn] + bias[n]);
- * splitk > 1: the reduction is split over workgroups DETERMINISTICALLY -- every k slice parks its partial tile in splitk_ws
+ * splitk > 1: the reduction is split over workgroups; splitk_ws == NULL: fp32 atomic accumulation (arrival-order rounding; act 0,
+ * no C2; the parameter-gradient GEMMs); splitk_ws != NULL: DETERMINISTICALLY -- every k slice parks its partial tile in splitk_ws
  * (rv_gemm_splitk_workspace_bytes, uninitialised), the last slice of a tile to arrive (splitk_tickets:
  * rv_gemm_splitk_ticket_bytes, ZERO on entry, left zero) folds them in k order and runs the epilogue, so the result does not
  * depend on arrival order and no atomics touch C; batch > 1: problem z of `batch` equal-shape problems lives at A + z*bsa,
@@ -121,6 +122,15 @@ long rv_gemm_splitk_ticket_bytes(int M, int N, int splitk, int batch);
 int rv_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm, long scn, float* C2,
             long sc2m, long sc2n, const float* bias, int M, int N, int K, int act, int accumulate, int splitk, int batch,
             long bsa, long bsb, long bsc, float* a_rowsum, void* splitk_ws, void* splitk_tickets, void* stream);
+/* grouped launch of independent ACCUMULATING problems of one operand orientation (the parameter-gradient GEMMs of a backward
+ * pass, each too small to fill the chip): fill HOST entries (returns the orientation code, <0 on error), finalize (returns the
+ * total workgroup count), copy the table to the device, run.  Split-K inside a table is the atomic kind. */
+long rv_gemm_table_entry_bytes(void);
+long rv_gemm_table_fill(void* entry_host, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm,
+                        long scn, const float* bias, int M, int N, int K, int splitk, int batch, long bsa, long bsb, long bsc,
+                        float* a_rowsum);
+long rv_gemm_table_finalize(void* table_host, int count);
+int rv_gemm_table_run(const void* table_dev, int count, long total_blocks, int orientation, void* stream);
 int rv_sigmoid_bwd(const float* g1, int ld1, const float* g2, int ld2, const float* y, int ldy, float* dz, int ldz, long M,
                    int N, void* stream);
 int rv_colsum(const float* x, int ld, long M, int N, float* out, int accumulate, void* stream);

@@ -36,6 +36,8 @@ struct GemmArgs {
     int a_vec, b_vec;   // 16-byte loads along the contiguous dimension are legal
     int batch;          // independent problems over blockIdx.z / splitk: A += z*bsa, B += z*bsb, C += z*bsc
     long bsa, bsb, bsc;
+    int atomic_out;     // C (and a_rowsum) are updated by atomics even without split-K: several problems of a grouped launch may
+                        // accumulate into the same destination (the same layer's gradient from two passes)
     float* a_rowsum;    // optional: a_rowsum[m] += sum_k A[m][k] (the bias gradient riding on a weight-gradient GEMM; k slices folded in order)
 };
 
@@ -89,16 +91,16 @@ struct TileIO {
     }
 };
 
+// One 64 x 64 output tile of one problem: (bx, by) = tile, bzi = batch index * splitk + k slice, (gdx, gdy) = tiles of the problem.
 template <bool AK, bool BK_>
-__global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a_in) {
-    GemmArgs a = a_in;
-    const int bz = blockIdx.z / a.splitk, kz = blockIdx.z - bz * a.splitk;
+__device__ __forceinline__ void gemm_tile(GemmArgs a, const int bx, const int by, const int bzi, const int gdx, const int gdy) {
+    const int bz = bzi / a.splitk, kz = bzi - bz * a.splitk;
     a.A += (long)bz * a.bsa; a.B += (long)bz * a.bsb; a.C += (long)bz * a.bsc;
     __shared__ __attribute__((aligned(16))) float As[GBM * LDK > GBK * LDM ? GBM * LDK : GBK * LDM];
     __shared__ __attribute__((aligned(16))) float Bs[GBN * LDK > GBK * LDM ? GBN * LDK : GBK * LDM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const int m0 = by * GBM, n0 = bx * GBN;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const int kper = ((a.K + a.splitk - 1) / a.splitk + GBK - 1) / GBK * GBK;
     const int k_begin = kz * kper;
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a_in) {
             ta.load(a.A, a.sam, a.sak, m0, a.M, k0 + GBK, k_end, a.a_vec, tid);
             tb.load(a.B, a.sbn, a.sbk, n0, a.N, k0 + GBK, k_end, a.b_vec, tid);
         }
-        if (a.a_rowsum && blockIdx.x == 0 && tid < GBM) {       // the first column of workgroups also sums the rows of A
+        if (a.a_rowsum && bx == 0 && tid < GBM) {       // the first column of workgroups also sums the rows of A
 #pragma unroll
             for (int kk = 0; kk < GBK; ++kk) rowsum += TileIO<AK>::at(As, tid, kk);      // (out-of-range elements are staged as 0)
         }
@@ -146,16 +148,16 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a_in) {
         }
     }
 
-    if (a.splitk > 1) {
+    if (a.splitk > 1 && a.part) {
         // deterministic split-K: park this slice's accumulators, take a ticket; the last slice of the tile to arrive folds all
         // slices in k order (whoever it is, the summation order is the same) and runs the epilogue
-        const int ntiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
+        const int ntiles = gdx * gdy, tile = by * gdx + bx;
         f32x4* mine = reinterpret_cast<f32x4*>(a.part) + (((long)bz * a.splitk + kz) * ntiles + tile) * (4 * 256);
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
             for (int y = 0; y < 2; ++y) mine[(x * 2 + y) * 256 + tid] = acc[x][y];
-        if (a.a_rowsum && blockIdx.x == 0 && tid < GBM && m0 + tid < a.M) a.rs_part[(long)kz * a.M + m0 + tid] = rowsum;
+        if (a.a_rowsum && bx == 0 && tid < GBM && m0 + tid < a.M) a.rs_part[(long)kz * a.M + m0 + tid] = rowsum;
         __threadfence();
         __shared__ int last;
         __syncthreads();
@@ -164,24 +166,37 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a_in) {
         if (!last) return;
         __threadfence();
         if (tid == 0) a.tickets[bz * ntiles + tile] = 0;                 // self-clearing: the buffer may serve the next launch
-        const f32x4* all = reinterpret_cast<const f32x4*>(a.part) + ((long)bz * a.splitk * ntiles + tile) * (4 * 256);
+        const f32x4* all = reinterpret_cast<const f32x4*>(a.part) + ((long)bz * a.splitk * ntiles + tile) * (4 * 256) + tid;
+        const long zs = (long)ntiles * (4 * 256);
+        // slices are added in k order; the loads of four slices x four fragments (16 independent 16-byte loads) are in flight together
+        for (int z0 = 0; z0 < a.splitk; z0 += 4) {
+            f32x4 v[4][4];
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int y = 0; y < 2; ++y) {
-                f32x4 sum = __builtin_nontemporal_load(all + (x * 2 + y) * 256 + tid);
-                for (int z = 1; z < a.splitk; ++z) sum += __builtin_nontemporal_load(all + (long)z * ntiles * (4 * 256) + (x * 2 + y) * 256 + tid);
-                acc[x][y] = sum;
+                for (int q = 0; q < 4; ++q)
+                    v[j][q] = (z0 + j < a.splitk) ? __builtin_nontemporal_load(all + (long)(z0 + j) * zs + q * 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (z0 + j >= a.splitk) break;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (z0 + j == 0) acc[q >> 1][q & 1] = v[j][q];
+                    else acc[q >> 1][q & 1] += v[j][q];
+                }
             }
-        if (a.a_rowsum && blockIdx.x == 0 && tid < GBM && m0 + tid < a.M) {
+        }
+        if (a.a_rowsum && bx == 0 && tid < GBM && m0 + tid < a.M) {
             float r = a.rs_part[m0 + tid];
             for (int z = 1; z < a.splitk; ++z) r += a.rs_part[(long)z * a.M + m0 + tid];
             a.a_rowsum[m0 + tid] += r;
         }
-    } else if (a.a_rowsum && blockIdx.x == 0 && tid < GBM && m0 + tid < a.M) {
-        a.a_rowsum[m0 + tid] += rowsum;                                  // one workgroup per row block: plain read-modify-write
+    } else if (a.a_rowsum && bx == 0 && tid < GBM && m0 + tid < a.M) {
+        if (a.splitk > 1 || a.atomic_out) atomicAdd(&a.a_rowsum[m0 + tid], rowsum);
+        else a.a_rowsum[m0 + tid] += rowsum;                             // one workgroup per row block: plain read-modify-write
     }
-    const bool vec_ok = a.scn == 1 && (a.scm & 3) == 0 && ((((uintptr_t)a.C) & 15) == 0) && !a.C2;
+    const bool atomic_k = (a.splitk > 1 && !a.part) || a.atomic_out;     // atomic split-K (parameter gradients: order-dependent rounding is acceptable)
+    const bool vec_ok = a.scn == 1 && (a.scm & 3) == 0 && ((((uintptr_t)a.C) & 15) == 0) && !a.C2 && !atomic_k;
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -190,7 +205,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a_in) {
             const int nb = n0 + wn + x * 16 + 4 * g;
             if (m >= a.M || nb >= a.N) continue;
             f32x4 v = acc[x][y];
-            if (a.bias) {
+            if (a.bias && (!(a.splitk > 1 && !a.part) || kz == 0)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (nb + r < a.N) v[r] += a.bias[nb + r];
@@ -208,6 +223,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a_in) {
                 for (int r = 0; r < 4; ++r) {
                     if (nb + r >= a.N) continue;
                     float* cc = c + (long)r * a.scn;
+                    if (atomic_k) { atomicAdd(cc, v[r]); continue; }
                     *cc = a.accumulate ? *cc + v[r] : v[r];
                     if (a.C2) a.C2[(long)m * a.sc2m + (long)(nb + r) * a.sc2n] = v[r];
                 }
@@ -215,10 +231,38 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a_in) {
         }
 }
 
+template <bool AK, bool BK_>
+__global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a) {
+    gemm_tile<AK, BK_>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
+}
+
+// Grouped launch: a device table of independent problems (all of the same operand orientation), one 1-D grid over the tiles of
+// all of them.  The parameter-gradient GEMMs of a backward pass (M or N of 31 .. 229, K = B*T = 5120: a few dozen workgroups
+// each, latency-bound alone) then run side by side in ONE launch instead of one under-filled launch each.
+struct GemmEntry { GemmArgs a; int block0, gx, gy, pad; };
+template <bool AK, bool BK_>
+__global__ __launch_bounds__(256) void gemm_table_k(const GemmEntry* tab, int count) {
+    int e = 0;
+    while (e + 1 < count && (int)blockIdx.x >= tab[e + 1].block0) ++e;            // wave-uniform scan (scalar loads), count <= 64
+    const GemmEntry& t = tab[e];
+    const int local = blockIdx.x - t.block0;
+    const int bx = local % t.gx, rest = local / t.gx;
+    gemm_tile<AK, BK_>(t.a, bx, rest % t.gy, rest / t.gy, t.gx, t.gy);
+}
+
+__global__ void zero_strided_k(float* c, long scm, long scn, int M, int N) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)M * N) return;
+    long m = i / N; int n = (int)(i - m * N);
+    c[m * scm + n * scn] = 0.f;
+}
+
 extern "C" {
 
 // C[m*scm + n*scn] (+)= act(sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] + bias[n]);  act: 0 none, 1 sigmoid.
-// splitk > 1 splits the reduction over extra workgroups, DETERMINISTICALLY: every k slice parks its partial tile in
+// splitk > 1 splits the reduction over extra workgroups.  With splitk_ws == NULL the slices accumulate by fp32 atomics (C zeroed
+// first unless accumulate; act must be 0, C2 null; rounding depends on arrival order -- used for parameter gradients).  With
+// splitk_ws the split is DETERMINISTIC: every k slice parks its partial tile in
 // `splitk_ws` (rv_gemm_splitk_workspace_bytes, uninitialised) and the last slice of a tile to arrive -- ticket in
 // `splitk_tickets` (rv_gemm_splitk_ticket_bytes, ZERO on entry, left zero) -- folds them in k order and runs the ordinary
 // epilogue (bias, act, accumulate, C2 all allowed): results do not depend on the arrival order, no atomics touch C.
@@ -235,32 +279,89 @@ long rv_gemm_splitk_ticket_bytes(int M, int N, int splitk, int batch) {
     return (long)batch * cdiv(M, GBM) * cdiv(N, GBN) * 4;
 }
 
-int rv_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm, long scn, float* C2,
-            long sc2m, long sc2n, const float* bias, int M, int N, int K, int act, int accumulate, int splitk, int batch,
-            long bsa, long bsb, long bsc, float* a_rowsum, void* splitk_ws, void* splitk_tickets, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
+static int gemm_args_make(GemmArgs& a, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm, long scn,
+                          float* C2, long sc2m, long sc2n, const float* bias, int M, int N, int K, int act, int accumulate, int splitk,
+                          int batch, long bsa, long bsb, long bsc, float* a_rowsum, void* splitk_ws, void* splitk_tickets) {
     RV_CHECK_ARG(M > 0 && N > 0 && K > 0, "rv_gemm: empty problem");
     RV_CHECK_ARG(!a_rowsum || batch == 1, "rv_gemm: a_rowsum excludes batch");
     RV_CHECK_ARG(splitk >= 1, "rv_gemm: splitk must be >= 1");
     RV_CHECK_ARG(batch >= 1 && (batch == 1 || !C2) && (long)batch * splitk < 65536, "rv_gemm: bad batch %d", batch);
-    if (splitk > 1) RV_CHECK_ARG(splitk_ws && splitk_tickets, "rv_gemm: splitk > 1 needs the partial-tile workspace and zeroed tickets");
-    GemmArgs a;
+    if (splitk > 1 && splitk_ws) RV_CHECK_ARG(splitk_tickets, "rv_gemm: deterministic split-K needs zeroed tickets");
+    if (splitk > 1 && !splitk_ws) RV_CHECK_ARG(act == 0 && !C2, "rv_gemm: atomic split-K excludes act/C2");
     a.A = A; a.sam = sam; a.sak = sak; a.B = B; a.sbk = sbk; a.sbn = sbn; a.C = C; a.scm = scm; a.scn = scn;
     a.C2 = C2; a.sc2m = sc2m; a.sc2n = sc2n; a.bias = bias; a.M = M; a.N = N; a.K = K; a.act = act;
     a.accumulate = accumulate; a.splitk = splitk; a.batch = batch; a.bsa = bsa; a.bsb = bsb; a.bsc = bsc; a.a_rowsum = a_rowsum;
-    a.part = (float*)splitk_ws; a.tickets = (int*)splitk_tickets;
-    a.rs_part = splitk > 1 ? (float*)splitk_ws + (long)batch * splitk * cdiv(M, GBM) * cdiv(N, GBN) * (4 * 256 * 4) : nullptr;
+    a.part = (float*)splitk_ws; a.tickets = (int*)splitk_tickets; a.atomic_out = 0;
+    a.rs_part = (splitk > 1 && splitk_ws) ? (float*)splitk_ws + (long)batch * splitk * cdiv(M, GBM) * cdiv(N, GBN) * (4 * 256 * 4) : nullptr;
     const bool a_kfast = (sak <= sam), b_kfast = (sbk <= sbn);
     // 16-byte loads need a unit stride along the fast dimension, a 16-byte multiple along the slow one and an
     // aligned base; K-split offsets are multiples of GBK so they preserve alignment
     a.a_vec = ((a_kfast ? sak : sam) == 1) && (((a_kfast ? sam : sak) & 3) == 0) && ((((uintptr_t)A) & 15) == 0) && (batch == 1 || (bsa & 3) == 0);
     a.b_vec = ((b_kfast ? sbk : sbn) == 1) && (((b_kfast ? sbn : sbk) & 3) == 0) && ((((uintptr_t)B) & 15) == 0) && (batch == 1 || (bsb & 3) == 0);
+    return RV_OK;
+}
+
+int rv_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm, long scn, float* C2,
+            long sc2m, long sc2n, const float* bias, int M, int N, int K, int act, int accumulate, int splitk, int batch,
+            long bsa, long bsb, long bsc, float* a_rowsum, void* splitk_ws, void* splitk_tickets, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs a;
+    const int rc = gemm_args_make(a, A, sam, sak, B, sbk, sbn, C, scm, scn, C2, sc2m, sc2n, bias, M, N, K, act, accumulate, splitk, batch,
+                                  bsa, bsb, bsc, a_rowsum, splitk_ws, splitk_tickets);
+    if (rc != RV_OK) return rc;
+    const bool a_kfast = (sak <= sam), b_kfast = (sbk <= sbn);
+    if (splitk > 1 && !splitk_ws && !accumulate) {
+        RV_CHECK_ARG(batch == 1, "rv_gemm: batched atomic split-K needs accumulate (zero C yourself)");
+        hipLaunchKernelGGL(zero_strided_k, dim3(cdiv((long)M * N, 256)), dim3(256), 0, st, C, scm, scn, M, N);
+        RV_LAUNCH_CHECK("rv_gemm(zero)");
+    }
     dim3 grid(cdiv(N, GBN), cdiv(M, GBM), splitk * batch);
     if (a_kfast && b_kfast) hipLaunchKernelGGL((gemm_mfma_k<true, true>), grid, dim3(256), 0, st, a);
     else if (a_kfast && !b_kfast) hipLaunchKernelGGL((gemm_mfma_k<true, false>), grid, dim3(256), 0, st, a);
     else if (!a_kfast && b_kfast) hipLaunchKernelGGL((gemm_mfma_k<false, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((gemm_mfma_k<false, false>), grid, dim3(256), 0, st, a);
     RV_LAUNCH_CHECK("rv_gemm");
+    return RV_OK;
+}
+
+// Grouped form (see gemm_table_k): fill HOST entries one by one with the arguments of rv_gemm -- accumulate must be 1 and split-K
+// is the atomic kind (the problems ADD into their destinations: gradient accumulation), all entries of one table must have the
+// same operand orientation (rv_gemm_table_fill returns it: bit 0 = A k-fast, bit 1 = B k-fast; negative = error) --, finalize
+// (prefix sums of the workgroup counts; returns the total), copy the table to the device and run it.
+long rv_gemm_table_entry_bytes(void) { return (long)sizeof(GemmEntry); }
+
+long rv_gemm_table_fill(void* entry_host, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm,
+                        long scn, const float* bias, int M, int N, int K, int splitk, int batch, long bsa, long bsb, long bsc,
+                        float* a_rowsum) {
+    if (!entry_host) { rv_set_error("rv_gemm_table_fill: null entry"); return RV_EINVAL; }
+    GemmEntry* e = (GemmEntry*)entry_host;
+    const int rc = gemm_args_make(e->a, A, sam, sak, B, sbk, sbn, C, scm, scn, nullptr, 0, 0, bias, M, N, K, 0, 1, splitk, batch, bsa, bsb,
+                                  bsc, a_rowsum, nullptr, nullptr);
+    if (rc != RV_OK) return rc;
+    e->a.atomic_out = 1;
+    e->gx = cdiv(N, GBN); e->gy = cdiv(M, GBM); e->block0 = e->gx * e->gy * splitk * batch; e->pad = 0;     // block0: count until finalize
+    return ((sak <= sam) ? 1 : 0) | ((sbk <= sbn) ? 2 : 0);
+}
+
+long rv_gemm_table_finalize(void* table_host, int count) {
+    GemmEntry* t = (GemmEntry*)table_host;
+    long total = 0;
+    for (int i = 0; i < count; ++i) { const int n = t[i].block0; t[i].block0 = (int)total; total += n; }
+    return total;
+}
+
+int rv_gemm_table_run(const void* table_dev, int count, long total_blocks, int orientation, void* stream) {
+    RV_CHECK_ARG(count > 0 && count <= 64 && total_blocks > 0 && total_blocks < (1L << 31), "rv_gemm_table_run: empty or oversized table");
+    hipStream_t st = (hipStream_t)stream;
+    const GemmEntry* t = (const GemmEntry*)table_dev;
+    dim3 grid((unsigned)total_blocks);
+    switch (orientation & 3) {
+        case 3: hipLaunchKernelGGL((gemm_table_k<true, true>), grid, dim3(256), 0, st, t, count); break;
+        case 1: hipLaunchKernelGGL((gemm_table_k<true, false>), grid, dim3(256), 0, st, t, count); break;
+        case 2: hipLaunchKernelGGL((gemm_table_k<false, true>), grid, dim3(256), 0, st, t, count); break;
+        default: hipLaunchKernelGGL((gemm_table_k<false, false>), grid, dim3(256), 0, st, t, count); break;
+    }
+    RV_LAUNCH_CHECK("rv_gemm_table_run");
     return RV_OK;
 }
 

@@ -831,9 +831,52 @@ def _mat(t):
     return ptr(t), t.shape[0], t.shape[1], t.stride(0), t.stride(1)
 
 
-def gemm(a, b_kn, c, bias=None, act=0, accumulate=False, splitk=1, c2=None, batch=1, bstrides=(0, 0, 0), a_rowsum=None):
+_gemm_splitk = {}          # (M, N, K, batch, A k-fast, B k-fast, act, accumulate) -> split-K factor in use
+
+
+def _splitk_for(m_out, n_out, k):
+    """Library-default split-K heuristic (shapes outside the plan table): enough workgroups to cover the chip twice."""
+    blocks = ((m_out + 63) // 64) * ((n_out + 63) // 64)
+    if blocks >= 256 or k < 512:
+        return 1
+    return max(1, min(16, 512 // blocks, k // 128))
+
+
+def _tune_gemm(key, launch, m, n, k, cands=(1, 2, 3, 4, 6, 8, 12, 16, 24, 32)):
+    """Time the split-K candidates of one GEMM shape (HIP events on the launch stream, scratch output) and keep the fastest.
+    Split-K is deterministic for a given factor (in-order fold), so the choice only fixes the summation grouping."""
+    st = torch.cuda.current_stream()
+    blocks = ((m + 63) // 64) * ((n + 63) // 64)
+    best, choice = None, 1
+    for s in cands:
+        if s > 1 and (k // s < 64 or blocks * s > 4096):
+            continue
+        launch(s)
+        t = None
+        for _rep in range(2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(3):
+                launch(s)
+            e1.record(st)
+            e1.synchronize()
+            dt = e0.elapsed_time(e1)
+            t = dt if t is None else min(t, dt)
+        if best is None or t < best * 0.97:               # a larger factor must win by 3 %: ties go to fewer slices
+            best, choice = t, s
+    _tune_us[('gemm', key)] = best / 3 * 1e3
+    if os.environ.get('RV_TUNE_LOG'):
+        print(f'[tune] gemm {key}: splitk={choice} {best / 3 * 1e3:.1f} us', file=sys.stderr)
+    return choice
+
+
+def gemm(a, b_kn, c, bias=None, act=0, accumulate=False, splitk=None, c2=None, batch=1, bstrides=(0, 0, 0), a_rowsum=None,
+         deterministic=True):
     """c[m,n] (+)= act(sum_k a[m,k] * b_kn[k,n] + bias[n]) on arbitrary 2-D views.  batch > 1: `batch` problems of this
-    shape, problem z offset by z * bstrides (elements) from a / b_kn / c."""
+    shape, problem z offset by z * bstrides (elements) from a / b_kn / c.  splitk None: the shipped plan table's factor for this
+    shape (ops.AUTOTUNE == 'table'), the on-line tuner's (True), else the library heuristic; the reduction over k slices is
+    folded in order inside the kernel (deterministic=True: forward / input-gradient chains, whose results feed the chaotic VAT
+    direction and must be reproducible) or accumulated by fp32 atomics (deterministic=False: parameter gradients; faster)."""
     need_gpu(a, b_kn, c)
     pa, m, k, sam, sak = _mat(a)
     pb, k2, n, sbk, sbn = _mat(b_kn)
@@ -843,14 +886,138 @@ def gemm(a, b_kn, c, bias=None, act=0, accumulate=False, splitk=1, c2=None, batc
         pc2, _, _, s2m, s2n = _mat(c2)
     else:
         pc2, s2m, s2n = None, 0, 0
-    ws = tk = None
-    if splitk > 1:
-        # deterministic split-K: partial tiles are parked in `ws`, the last k slice of a tile (zeroed ticket word) folds them in order
-        lib = _lib.load()
-        ws = torch.empty(lib.rv_gemm_splitk_workspace_bytes(m, n, splitk, batch) // 4, device=c.device, dtype=torch.float32)
-        tk = ARENA.take((lib.rv_gemm_splitk_ticket_bytes(m, n, splitk, batch) + 7) // 8, c.device)
-    call('rv_gemm', pa, sam, sak, pb, sbk, sbn, pc, scm, scn, pc2, s2m, s2n, ptr(bias), m, n, k, act,
-         1 if accumulate else 0, splitk, batch, bstrides[0], bstrides[1], bstrides[2], ptr(a_rowsum), ptr(ws), ptr(tk), stream())
+    lib = _lib.load()
+
+    def launch(s, pc_=pc, rs=ptr(a_rowsum), raise_=True):
+        ws = tk = None
+        if s > 1 and deterministic:
+            # deterministic split-K: partial tiles are parked in `ws`, the last k slice of a tile (zeroed ticket word) folds them in order
+            ws = torch.empty(lib.rv_gemm_splitk_workspace_bytes(m, n, s, batch) // 4, device=c.device, dtype=torch.float32)
+            tk = ARENA.take((lib.rv_gemm_splitk_ticket_bytes(m, n, s, batch) + 7) // 8, c.device)
+        call('rv_gemm', pa, sam, sak, pb, sbk, sbn, pc_, scm, scn, pc2, s2m, s2n, ptr(bias), m, n, k, act,
+             1 if accumulate else 0, s, batch, bstrides[0], bstrides[1], bstrides[2], rs, ptr(ws), ptr(tk), stream())
+
+    deferrable = accumulate and not deterministic and bias is None and act == 0 and c2 is None and _GEMM_DEFER[0] is not None
+    if splitk is None:
+        key = (m, n, k, batch, int(sak <= sam), int(sbk <= sbn), act, int(bool(accumulate)) + 2 * int(bool(deterministic)))
+        splitk = _gemm_splitk.get(key)
+        if splitk is None:
+            if AUTOTUNE == 'table':
+                splitk = plans.lookup_gemm(key)
+            elif AUTOTUNE and c2 is None and not torch.cuda.is_current_stream_capturing():
+                # time on scratch outputs: the real C may be a gradient that is being accumulated into
+                extent = (m - 1) * scm + (n - 1) * scn + 1 + (batch - 1) * bstrides[2]
+                tmp = torch.zeros(extent, device=c.device, dtype=torch.float32)
+                rs_tmp = torch.zeros(m, device=c.device, dtype=torch.float32) if a_rowsum is not None else None
+                splitk = _tune_gemm(key, lambda s: launch(s, ptr(tmp), ptr(rs_tmp)), m, n, k,
+                                    (1, 2, 3, 4, 6, 8, 12, 16, 24, 32) if (deterministic or act == 0) else (1,))
+            if splitk is None:
+                splitk = _splitk_for(m, n, k)
+            _gemm_splitk[key] = splitk
+    if deferrable and _defer_gemm(a, b_kn, c, splitk, batch, bstrides, a_rowsum):
+        return
+    launch(splitk)
+
+
+# --------------------------------------------------------------------------------------------
+# deferred parameter-gradient GEMMs: one grouped launch per stream and backward pass
+# --------------------------------------------------------------------------------------------
+_GEMM_DEFER = [None]
+_GEMM_POOL = []            # pre-allocated pinned host tables for hipGraph capture (never recycled once captured)
+_GEMM_KEEP = []
+_GEMM_MAX = 64             # entries per table (rv_gemm_table_run's scan limit)
+KEEP_TABLES = [False]      # measurement mode (bench.py): flushed device tables and their operands stay alive for re-launching
+GEMM_TABLE_WORK = {}       # device table pointer -> (flops, algorithmic bytes) of the grouped launch (filled in measurement mode)
+
+
+def prepare_gemm_tables(n=3):
+    """Pinned host tables for deferred_param_gemms under hipGraph capture (call outside capture)."""
+    eb = _lib.load().rv_gemm_table_entry_bytes()
+    while len(_GEMM_POOL) < n:
+        _GEMM_POOL.append(torch.empty(_GEMM_MAX * eb, dtype=torch.uint8).pin_memory())
+
+
+class _GemmTable:
+    """The pending accumulating GEMMs of one (stream, operand orientation)."""
+
+    def __init__(self, device, torch_stream, orientation):
+        self.eb = _lib.load().rv_gemm_table_entry_bytes()
+        self.device, self.stream, self.orientation, self.n, self.keep = device, torch_stream, orientation, 0, []
+        self.flops = self.bytes = 0.0
+        if torch.cuda.is_current_stream_capturing():
+            if not _GEMM_POOL:
+                raise RuntimeError('deferred_param_gemms: no pinned table left for hipGraph capture')
+            self.host = _GEMM_POOL.pop()
+            _GEMM_KEEP.append(self.host)
+            self.pinned = True
+        else:
+            self.host = torch.empty(_GEMM_MAX * self.eb, dtype=torch.uint8)
+            self.pinned = False
+
+    def flush(self):
+        if self.n == 0:
+            return
+        total = _lib.load().rv_gemm_table_finalize(self.host.data_ptr(), self.n)
+        used = self.host[:self.n * self.eb]
+        with torch.cuda.stream(self.stream):
+            src = used if self.pinned else used.pin_memory()
+            table = src.to(self.device, non_blocking=True)
+            call('rv_gemm_table_run', ptr(table), self.n, total, self.orientation, self.stream.cuda_stream)
+            table.record_stream(self.stream)
+            if self.pinned:
+                _GEMM_KEEP.append(table)       # captured: keep the device copy's memory out of the graph pool's reuse
+            if KEEP_TABLES[0]:
+                _GEMM_KEEP.append((table, self.keep))
+                GEMM_TABLE_WORK[table.data_ptr()] = (self.flops, self.bytes)
+        self.n, self.keep = 0, []
+        self.flops = self.bytes = 0.0
+
+
+class deferred_param_gemms:
+    """While active, linear-layer / attention parameter-gradient GEMMs that accumulate into param.grad are only REGISTERED; all of
+    them run as one grouped launch per stream at ``flush()`` (after backward, before the gradients are read).  Alone each of them
+    is a few dozen workgroups with a 5 120-long reduction: latency-bound, 25-90 us; side by side they fill the chip."""
+
+    def __enter__(self):
+        self.prev = _GEMM_DEFER[0]
+        self.tables = {}
+        _GEMM_DEFER[0] = self.tables
+        return self
+
+    def __exit__(self, *exc):
+        _GEMM_DEFER[0] = self.prev
+
+    def flush(self):
+        for t in self.tables.values():
+            t.flush()
+
+
+def _defer_gemm(a, b_kn, c, splitk, batch, bstrides, a_rowsum):
+    """Register c += a @ b_kn (atomic split-K) with the active deferred_param_gemms context; False if none is active."""
+    tables = _GEMM_DEFER[0]
+    if tables is None:
+        return False
+    pa, m, k, sam, sak = _mat(a)
+    pb, _, n, sbk, sbn = _mat(b_kn)
+    pc, _, _, scm, scn = _mat(c)
+    cur = torch.cuda.current_stream(c.device)
+    orient = (1 if sak <= sam else 0) | (2 if sbk <= sbn else 0)
+    key = (cur.cuda_stream, orient)
+    tab = tables.get(key)
+    if tab is None:
+        tab = tables[key] = _GemmTable(c.device, cur, orient)
+    if tab.n >= _GEMM_MAX:
+        return False
+    rc = _lib.load().rv_gemm_table_fill(tab.host.data_ptr() + tab.n * tab.eb, pa, sam, sak, pb, sbk, sbn, pc, scm, scn, None, m, n, k,
+                                        splitk, batch, bstrides[0], bstrides[1], bstrides[2], ptr(a_rowsum))
+    if rc < 0:
+        raise RuntimeError(f'rv_gemm_table_fill failed ({rc}): {_lib.last_error()}')
+    assert rc == orient
+    tab.n += 1
+    tab.flops += 2.0 * m * n * k * batch
+    tab.bytes += 4.0 * batch * (m * k + k * n + m * n)
+    tab.keep += [a, b_kn, c, a_rowsum]          # operands stay alive (and their memory un-reused) until the grouped launch
+    return True
 
 
 def colsum(x2d, out=None, accumulate=False):
@@ -861,7 +1028,7 @@ def colsum(x2d, out=None, accumulate=False):
     return out
 
 
-def _param_wgrad(a_t, b, param, splitk, bias_param=None):
+def _param_wgrad(a_t, b, param, splitk=None, bias_param=None):
     """d(param) = a_t @ b.  Under direct_param_grads() the product is accumulated straight into param.grad (split-K
     atomics add onto it: no zero fill, no temporary, no autograd add) and None is returned.  bias_param: the layer's
     bias -- its gradient (the row sums of a_t = dY^T) then rides on the same GEMM; returns (None, True) in that case."""
@@ -869,14 +1036,14 @@ def _param_wgrad(a_t, b, param, splitk, bias_param=None):
     if bias_param is not None:
         gb = _grad_buf(bias_param)
         if g is not None and gb is not None:
-            gemm(a_t, b, g.view(a_t.shape[0], b.shape[1]), accumulate=True, splitk=splitk, a_rowsum=gb)
+            gemm(a_t, b, g.view(a_t.shape[0], b.shape[1]), accumulate=True, splitk=splitk, a_rowsum=gb, deterministic=False)
             return None, True
         return _param_wgrad(a_t, b, param, splitk), False
     if g is not None:
-        gemm(a_t, b, g.view(a_t.shape[0], b.shape[1]), accumulate=True, splitk=splitk)
+        gemm(a_t, b, g.view(a_t.shape[0], b.shape[1]), accumulate=True, splitk=splitk, deterministic=False)
         return None
     dw = torch.empty((a_t.shape[0], b.shape[1]), device=b.device, dtype=torch.float32)
-    gemm(a_t, b, dw, splitk=splitk)
+    gemm(a_t, b, dw, splitk=splitk, deterministic=False)
     return dw.view_as(param)
 
 
@@ -886,13 +1053,6 @@ def _param_bgrad(dz2d, param):
         colsum(dz2d, g, accumulate=True)
         return None
     return colsum(dz2d)
-
-
-def _splitk_for(m_out, n_out, k):
-    blocks = ((m_out + 63) // 64) * ((n_out + 63) // 64)
-    if blocks >= 256 or k < 512:
-        return 1
-    return max(1, min(16, 512 // blocks, k // 128))      # (tools/bench_gemm_splitk.py: beyond 16 slices the atomics cost more than they hide)
 
 
 class LinearFn(Function):
@@ -927,9 +1087,9 @@ class LinearFn(Function):
         bias_done = False
         if ctx.needs_input_grad[1]:
             if ctx.needs_input_grad[2]:
-                dw, bias_done = _param_wgrad(dz.t(), x, ctx.params[0], _splitk_for(n, k, m), ctx.params[1])
+                dw, bias_done = _param_wgrad(dz.t(), x, ctx.params[0], None, ctx.params[1])
             else:
-                dw = _param_wgrad(dz.t(), x, ctx.params[0], _splitk_for(n, k, m))
+                dw = _param_wgrad(dz.t(), x, ctx.params[0], None)
         if ctx.needs_input_grad[2] and not bias_done:
             db = _param_bgrad(dz, ctx.params[1])
         return dx, dw, db, None
@@ -974,11 +1134,11 @@ class OnsetHeadsFn(Function):
             gemm(dzf, _lin_t(wf).t(), d2[..., 1])
         pwo, pbo, pwf, pbf = ctx.params
         if ctx.needs_input_grad[1]:
-            dwo, done = _param_wgrad(dzo.t(), y2[..., 0], pwo, _splitk_for(88, nb, m), pbo)
+            dwo, done = _param_wgrad(dzo.t(), y2[..., 0], pwo, None, pbo)
             if not done:
                 dbo = _param_bgrad(dzo, pbo)
         if ctx.needs_input_grad[3]:
-            dwf, done = _param_wgrad(dzf.t(), y2[..., 1], pwf, _splitk_for(88, nb, m), pbf)
+            dwf, done = _param_wgrad(dzf.t(), y2[..., 1], pwf, None, pbf)
             if not done:
                 dbf = _param_bgrad(dzf, pbf)
         return dy, dwo, dbo, dwf, dbf
@@ -1056,7 +1216,7 @@ class LocalAttnFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x2)
             if fused:
-                gemm(dqkv, _lin_t(torch.as_strided(wk, (3 * f, fin), (fin, 1))).t(), dx, splitk=_splitk_for(m, fin, 3 * f))
+                gemm(dqkv, _lin_t(torch.as_strided(wk, (3 * f, fin), (fin, 1))).t(), dx)
             else:
                 gemm(dq, _lin_t(wq).t(), dx)
                 gemm(dk, _lin_t(wk).t(), dx, accumulate=True)
@@ -1066,14 +1226,13 @@ class LocalAttnFn(Function):
         if ctx.needs_input_grad[1]:
             gk, gq, gv = _grad_buf(pwk), _grad_buf(pwq), _grad_buf(pwv)
             if fused and _adjacent(gk, gq, gv):
-                gemm(dqkv.t(), x2, torch.as_strided(gk, (3 * f, fin), (fin, 1)), accumulate=True,
-                     splitk=_splitk_for(3 * f, fin, m))
+                gemm(dqkv.t(), x2, torch.as_strided(gk, (3 * f, fin), (fin, 1)), accumulate=True, deterministic=False)
             elif fused:
                 dw3 = torch.empty((3 * f, fin), device=x2.device, dtype=torch.float32)
-                gemm(dqkv.t(), x2, dw3, splitk=_splitk_for(3 * f, fin, m))
+                gemm(dqkv.t(), x2, dw3, deterministic=False)
                 dwk, dwq, dwv = dw3[:f], dw3[f:2 * f], dw3[2 * f:]
             else:
-                sk = _splitk_for(f, fin, m)
+                sk = None
                 dwq = _param_wgrad(dq.t(), x2, pwq, sk)
                 dwk = _param_wgrad(dk.t(), x2, pwk, sk)
                 dwv = _param_wgrad(dv.t(), x2, pwv, sk)
@@ -1084,7 +1243,7 @@ class LocalAttnFn(Function):
             drel = grel.view(f, 31) if direct else torch.zeros((f, 31), device=q.device, dtype=torch.float32)
             de2 = de.view(m, g, 31)
             # one batched split-K launch over the heads: head h reads q[:, h*dh:], de[:, h, :], writes drel[h*dh:]
-            gemm(q[:, :dh].t(), de2[:, 0, :], drel[:dh], accumulate=True, splitk=16, batch=g, bstrides=(dh, 31, dh * 31))
+            gemm(q[:, :dh].t(), de2[:, 0, :], drel[:dh], accumulate=True, deterministic=False, batch=g, bstrides=(dh, 31, dh * 31))
             drel = None if direct else drel.view_as(rel)
         return dx, dwq, dwk, dwv, drel, None
 
@@ -1338,14 +1497,14 @@ class BiLstmFn(Function):
             ih_bias = hh_bias = False
             if ctx.needs_input_grad[base]:
                 if ctx.needs_input_grad[base + 2]:
-                    grads[base], ih_bias = _param_wgrad(dz.t(), x2, p_ih, _splitk_for(4 * h, i, bb * t), p_bi)
+                    grads[base], ih_bias = _param_wgrad(dz.t(), x2, p_ih, None, p_bi)
                 else:
-                    grads[base] = _param_wgrad(dz.t(), x2, p_ih, _splitk_for(4 * h, i, bb * t))
+                    grads[base] = _param_wgrad(dz.t(), x2, p_ih, None)
             if ctx.needs_input_grad[base + 1]:
                 if ctx.needs_input_grad[base + 3]:
-                    grads[base + 1], hh_bias = _param_wgrad(dz.t(), hprev[:, d, :], p_hh, _splitk_for(4 * h, h, bb * t), p_bh)
+                    grads[base + 1], hh_bias = _param_wgrad(dz.t(), hprev[:, d, :], p_hh, None, p_bh)
                 else:
-                    grads[base + 1] = _param_wgrad(dz.t(), hprev[:, d, :], p_hh, _splitk_for(4 * h, h, bb * t))
+                    grads[base + 1] = _param_wgrad(dz.t(), hprev[:, d, :], p_hh, None)
             if ctx.needs_input_grad[base + 2] and not ih_bias:
                 grads[base + 2] = _param_bgrad(dz, p_bi)
             if ctx.needs_input_grad[base + 3] and not hh_bias:

@@ -21,8 +21,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 PLAN_FILE = os.environ.get('RV_PLAN_FILE', os.path.join(HERE, 'tuned_plans.json'))
 
-_state = {'loaded': False, 'conv': {}, 'conv_nob': {}, 'wgrad': {}, 'wgrad_nob': {}, 'digest': None, 'meta': {}}
-HITS = {'conv': set(), 'wgrad': set()}         # table keys actually used in this process (tests assert coverage with it)
+_state = {'loaded': False, 'conv': {}, 'conv_nob': {}, 'wgrad': {}, 'wgrad_nob': {}, 'gemm': {}, 'digest': None, 'meta': {}}
+HITS = {'conv': set(), 'wgrad': set(), 'gemm': set()}         # table keys actually used in this process (tests assert coverage with it)
 
 
 def default_mode():
@@ -51,6 +51,8 @@ def _load():
         key = tuple(int(x) for x in k.split(','))           # (taps, B, Hv, Wv, Ca, Cb)
         _state['wgrad'][key] = (int(v[0]), int(v[1]))
         _state['wgrad_nob'].setdefault((key[0],) + key[2:], (key, (int(v[0]), int(v[1]))))
+    for k, v in doc.get('gemm', {}).items():
+        _state['gemm'][tuple(int(x) for x in k.split(','))] = int(v)   # (M, N, K, batch, a k-fast, b k-fast, act, accumulate) -> splitk
 
 
 def digest():
@@ -102,9 +104,25 @@ def lookup_wgrad(key):
     return None
 
 
-def dump(conv, wgrad, meta_, path):
-    """Write a table: conv {key tuple: algo}, wgrad {key tuple: (nw, wgs)}."""
+def gemm_entries():
+    _load()
+    return dict(_state['gemm'])
+
+
+def lookup_gemm(key):
+    """split-K factor for a GEMM key (M, N, K, batch, A k-fast, B k-fast, act, accumulate) or None."""
+    _load()
+    key = tuple(int(x) for x in key)
+    v = _state['gemm'].get(key)
+    if v is not None:
+        HITS['gemm'].add(key)
+    return v
+
+
+def dump(conv, wgrad, meta_, path, gemm=None):
+    """Write a table: conv {key tuple: algo}, wgrad {key tuple: (nw, wgs)}, gemm {key tuple: splitk}."""
     doc = {'meta': meta_,
+           'gemm': {','.join(str(int(x)) for x in k): int(v) for k, v in sorted((gemm or {}).items())},
            'conv': {','.join(str(int(x)) for x in k): int(v) for k, v in sorted(conv.items())},
            'wgrad': {','.join(str(int(x)) for x in k): [int(v[0]), int(v[1])] for k, v in sorted(wgrad.items())}}
     with open(path, 'w') as fh:

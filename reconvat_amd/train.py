@@ -266,6 +266,7 @@ class TrainStep:
             ops.prepare_replay_pool()
         if graph and self.batch['audio'].is_cuda:
             ops.prepare_wgrad_tables(len(ops._WGRAD_POOL) + 3)
+            ops.prepare_gemm_tables(len(ops._GEMM_POOL) + 6)
 
     def _fwd_bwd(self):
         self.opt.zero_grad()
@@ -281,13 +282,18 @@ class TrainStep:
             ops.SIDE_GRADS[0] = (self.opt.flat_grad, {ops.side_stream(dev, i).cuda_stream: twins[i] for i in range(n_side)})
         try:
             defer = os.environ.get('RV_DEFER_WGRAD', '1') != '0' and getattr(self.model, 'defer_wgrad_reductions', True)
-            with ops.direct_param_grads(), (ops.deferred_wgrad_reductions() if defer else contextlib.nullcontext()) as pending:
-                # conv grads accumulate straight into the flat bucket; their partial sums are folded by ONE launch per stream
+            defer_g = os.environ.get('RV_DEFER_GEMM', '1') != '0' and getattr(self.model, 'defer_param_gemms', True)
+            with ops.direct_param_grads(), (ops.deferred_wgrad_reductions() if defer else contextlib.nullcontext()) as pending, \
+                    (ops.deferred_param_gemms() if defer_g else contextlib.nullcontext()) as pending_g:
+                # conv grads accumulate straight into the flat bucket; their partial sums are folded by ONE launch per stream, and the
+                # linear / attention parameter-gradient GEMMs run as ONE grouped launch per stream
                 _, losses, _ = self.model.run_on_batch(self.batch, self.batch_ul, self.VAT)
                 loss = weighted_loss(losses, self.alpha)
                 loss.backward()
                 if pending is not None:
                     pending.flush()
+                if pending_g is not None:
+                    pending_g.flush()
             if dual:
                 # the side stream ran the reconstruction branch's backward into its own bucket: join, then fold
                 for i in range(n_side):

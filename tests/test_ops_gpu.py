@@ -499,3 +499,32 @@ def test_gemm_k_contiguous_full_size(dev, M, N, K, kw):
         c3 = torch.empty((M, N), device=dev)
         ops.gemm(pad[:, 1:], bg.t(), c3, bias.to(dev) if bias is not None else None, act=kw.get('act', 0))
         assert rel_err(c3, c) < 2e-5
+
+
+def test_grouped_deferred_gemms_vs_torch(dev):
+    """ops.deferred_param_gemms: accumulating GEMMs of different shapes (one batched, one with the row-sum rider, split-K and not)
+    registered and run as ONE grouped launch (rv_gemm_table_run) -- each destination must equal its start value + A @ B."""
+    from reconvat_amd import ops
+    torch.manual_seed(0)
+    cases = [(88, 229, 1280, 1, 4), (88, 768, 1280, 1, 8), (300, 176, 640, 1, 1), (128, 31, 1280, 3, 4)]
+    items = []
+    for m, n, k, batch, sk in cases:
+        at = torch.randn(batch, k, m, device=dev)            # A = at^T (M-fast, like dY^T)
+        b = torch.randn(batch, k, n, device=dev)
+        c = torch.randn(batch, m, n, device=dev)
+        items.append((at, b, c, c.clone(), sk, batch))
+    rs = torch.randn(88, device=dev)
+    rs0 = rs.clone()
+    with ops.deferred_param_gemms() as pend:
+        for i, (at, b, c, c0, sk, batch) in enumerate(items):
+            ops.gemm(at[0].t(), b[0], c[0], accumulate=True, splitk=sk, deterministic=False, batch=batch,
+                     bstrides=(at.stride(0), b.stride(0), c.stride(0)), a_rowsum=rs if i == 0 else None)
+        torch.cuda.synchronize()
+        assert all(torch.equal(c, c0) for _, _, c, c0, _, _ in items), 'nothing may run before flush()'
+        assert sum(t.n for t in pend.tables.values()) == len(items)
+        pend.flush()
+    torch.cuda.synchronize()
+    for at, b, c, c0, sk, batch in items:
+        want = c0.double() + torch.einsum('zkm,zkn->zmn', at.double(), b.double())
+        assert rel_err(c, want.float()) < 1e-5
+    assert rel_err(rs, (rs0.double() + items[0][0][0].double().sum(0)).float()) < 1e-5

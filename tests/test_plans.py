@@ -15,6 +15,8 @@ def test_table_parses_and_is_default():
         assert algo in (0, 1, 2) or (fam in (1, 2, 3, 4, 7) and 1 <= nt <= 4 and 1 <= mt <= 8 and 0 <= th < 256), hex(algo)
         if key[0] != 0:
             assert fam in (0, 1), 'only the 3x3 mode has LDS tile families'
+    gemm = plans.gemm_entries()
+    assert len(gemm) >= 20 and all(len(k) == 8 and 1 <= v <= 32 for k, v in gemm.items())
     for key, (nw, wgs) in wgrad.items():
         assert len(key) == 6 and key[0] in (1, 4, 9) and nw in (0, 4, 8) and (wgs == 0 or 32 <= wgs <= 4096)
 

@@ -42,7 +42,7 @@ def main():
     import reconvat_amd as ra
     from reconvat_amd import ops, plans
     dev = torch.device('cuda:0')
-    best_conv, best_wgrad = {}, {}
+    best_conv, best_wgrad, best_gemm = {}, {}, {}
     log = []
     real_print = print
 
@@ -52,6 +52,7 @@ def main():
         ops._wgrad_tuned.clear()
         ops._wgrad_plans.clear()
         ops._tune_us.clear()
+        ops._gemm_splitk.clear()
         for name, model, bl, bul in workloads(dev):
             torch.manual_seed(7)
             opt = ra.FlatAdam(model.parameters(), lr=1e-3)
@@ -73,7 +74,13 @@ def main():
             log.append(f'round {rnd} wgrad {k}: plan={ops._wgrad_plans[k]} {us:.1f} us')
             if k not in best_wgrad or us < best_wgrad[k][1]:
                 best_wgrad[k] = (ops._wgrad_plans[k], us)
-        real_print(f'[tune_plans] round {rnd}: {len(conv_keys)} conv shapes, {len(wg_keys)} weight-gradient shapes', file=sys.stderr)
+        gm_keys = [k for (what, k) in ops._tune_us if what == 'gemm']
+        for k in gm_keys:
+            us = ops._tune_us[('gemm', k)]
+            log.append(f'round {rnd} gemm {k}: splitk={ops._gemm_splitk[k]} {us:.1f} us')
+            if k not in best_gemm or us < best_gemm[k][1]:
+                best_gemm[k] = (ops._gemm_splitk[k], us)
+        real_print(f'[tune_plans] round {rnd}: {len(conv_keys)} conv shapes, {len(wg_keys)} weight-gradient shapes, {len(gm_keys)} GEMM shapes', file=sys.stderr)
     try:
         git = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
     except OSError:
@@ -82,13 +89,16 @@ def main():
             'workloads': 'UNet_Onset, UNet (VAT + reconstruction), OnsetsAndFrames_VAT_full; B_l = B_ul = 8 x 327680 samples',
             'conv_key': 'mode,B,H,W,cin,cout,in_ld,out_ld,bn_stats,bn_bwd -> algo (rv_conv_fwd)',
             'wgrad_key': 'taps,B,Hv,Wv,Ca,Cb -> [waves per workgroup, workgroups] (rv_conv_wgrad_set_plan)',
+            'gemm_key': 'M,N,K,batch,A k-fast,B k-fast,act,accumulate -> split-K factor (rv_gemm; slices folded in order)',
             'us': {'conv': {','.join(str(int(x)) for x in k): v[1] for k, v in sorted(best_conv.items())},
-                   'wgrad': {','.join(str(int(x)) for x in k): v[1] for k, v in sorted(best_wgrad.items())}}}
+                   'wgrad': {','.join(str(int(x)) for x in k): v[1] for k, v in sorted(best_wgrad.items())},
+                   'gemm': {','.join(str(int(x)) for x in k): v[1] for k, v in sorted(best_gemm.items())}}}
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
-    plans.dump({k: v[0] for k, v in best_conv.items()}, {k: v[0] for k, v in best_wgrad.items()}, meta, args.out)
+    plans.dump({k: v[0] for k, v in best_conv.items()}, {k: v[0] for k, v in best_wgrad.items()}, meta, args.out,
+               gemm={k: v[0] for k, v in best_gemm.items()})
     with open(os.path.splitext(args.out)[0] + '_log.txt', 'w') as fh:
         fh.write('\n'.join(log))
-    real_print(f'[tune_plans] wrote {args.out}: {len(best_conv)} conv entries, {len(best_wgrad)} weight-gradient entries', file=sys.stderr)
+    real_print(f'[tune_plans] wrote {args.out}: {len(best_conv)} conv entries, {len(best_wgrad)} weight-gradient entries, {len(best_gemm)} GEMM entries', file=sys.stderr)
 
 
 if __name__ == '__main__':
