@@ -518,6 +518,9 @@ def main():
     ap.add_argument('--single-stream', action='store_true', help='disable the two-stream step schedule (A/B)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--bf16-backward', action='store_true',
+                    help='BASELINE config 3 as an opt-in experiment (NOT the headline): bf16 operands in the backward 3x3 convs of the final '
+                         'graphs; every forward pass and the power iteration stay fp32 (loss terms / posteriorgrams unchanged)')
     ap.add_argument('--no-parity', action='store_true', help='skip the post-run parity leg (frozen-weight step vs the reference fixture)')
     ap.add_argument('--verbose', action='store_true', help='dump the per-launch conv table to stderr')
     args = ap.parse_args()
@@ -547,7 +550,7 @@ def main():
     batch, batch_ul = synthetic_batch(args.batch, gen, device), synthetic_batch(args.batch, gen, device)
     torch.manual_seed(77 + rank)                  # VAT noise stream
     step = ra.TrainStep(model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=not args.no_graph,
-                        dual_stream=not args.single_stream)
+                        dual_stream=not args.single_stream, bf16_backward=args.bf16_backward)
     used_graph = not args.no_graph
     if used_graph:
         try:
@@ -594,7 +597,9 @@ def main():
     line = {
         'metric': 'training audio-sec/sec (node)', 'value': round(audio_s, 2), 'unit': 'audio-s/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32' if not args.bf16_backward else 'f32 forward + power iteration, bf16-operand / f32-accumulate backward 3x3 convs (opt-in experiment)',
+        'data': 'synthetic',
         'config': {'workload': f'ReconVAT UNet_Onset VAT=True reconstruction=True, per-GPU B_l={args.batch} + '
                                f'B_ul={args.batch} segments of 327680 samples (640 frames x 229 mel), Adam+StepLR, fp32',
                    'parallelism': f'dp{world}', 'hipgraph': used_graph, 'two_stream_schedule': not args.single_stream, 'labelled_only_audio_s_per_s': round(audio_s / 2, 2),

@@ -41,6 +41,7 @@ def base_config(o, onset_script):
         learning_rate_decay_rate=0.98, leave_one_out=None, clip_gradient_norm=3, refresh=False,
         # MI355X-side extras (not in the reference)
         graph=True, fused_optimizer=True, saving_freq=saving_freq, logging_freq=logging_freq, device_feed=True,
+        dtype='fp32',          # 'bf16': opt-in experiment -- bf16-operand backward convs of the final graphs (forward stays fp32)
     )
     c.update(o)
     if torch.cuda.is_available() and torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory < 10e9:
@@ -131,7 +132,7 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
                  train_batch_size, learning_rate, learning_rate_decay_steps, learning_rate_decay_rate, alpha,
                  clip_gradient_norm, validation_length, refresh, device, epoches, logdir, log, iteration, VAT_start, VAT,
                  XI, eps, reconstruction, graph, fused_optimizer, saving_freq, device_feed=True, model_complexity=48, model_name='onset_frame', VAT_mode='all',
-                 logging_freq=logging_freq, **_unused):
+                 logging_freq=logging_freq, dtype='fp32', **_unused):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if not str(device).startswith('cuda') or not torch.cuda.is_available():
@@ -222,7 +223,8 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
                 bl = next(li)
                 bul = next(ui) if use_vat else None
                 if step_runner is None or step_runner.VAT != use_vat:
-                    step_runner = TrainStep(model, optimizer, bl, bul, alpha=alpha, VAT=use_vat, clip=clip_gradient_norm, graph=True)
+                    step_runner = TrainStep(model, optimizer, bl, bul, alpha=alpha, VAT=use_vat, clip=clip_gradient_norm, graph=True,
+                                            bf16_backward=str(dtype).lower() in ('bf16', 'bfloat16'))
                 else:
                     step_runner.load(bl, bul)
                 total += float(step_runner())

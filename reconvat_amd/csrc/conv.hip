@@ -326,8 +326,24 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N > 15 ? 15 : N) : "memory");
 }
 
-template <int R, int NT, int MTW, int NW>
+// BF (R == 4 only; opt-in experiment, BASELINE config 3): the operands are rounded to bf16 (round-to-nearest-even,
+// v_cvt_pk_bf16_f32) on their way from LDS to the matrix pipe and ONE v_mfma_f32_16x16x16_bf16 replaces the four f32 MFMAs of a
+// 16-channel chunk (a lane's four channels 4g .. 4g+3 are exactly the four consecutive k the bf16 MFMA wants from lane (j, g));
+// accumulation, bias, statistics and stores stay fp32.  Everything else -- staging, layouts, epilogue -- is shared.
+// (compiler-visible conversions, not inline asm: the VALU-write -> MFMA-read hazard slots are the compiler's to insert)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 to_bf16x4(const f32x4& v) {
+    const bf16x2_t lo = __builtin_convertvector((f32x2){v[0], v[1]}, bf16x2_t);      // v_cvt_pk_bf16_f32 (round to nearest even)
+    const bf16x2_t hi = __builtin_convertvector((f32x2){v[2], v[3]}, bf16x2_t);
+    const bf16x4_t q = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+    return __builtin_bit_cast(s16x4, q);
+}
+
+template <int R, int NT, int MTW, int NW, bool BF = false>
 __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
+    static_assert(!BF || R == 4, "the bf16 path needs 16-channel chunks");
     constexpr int NTHR = NW * 64;
     typedef typename VecR<R>::T vec;
     constexpr int KC = 4 * R;                    // channels per chunk
@@ -538,6 +554,18 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (BF) {
+                s16x4 wb[NT], xb[MTW];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) wb[n] = to_bf16x4(wf[tap & 1][n]);
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) xb[m] = to_bf16x4(xf[tap & 1][m]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wb[n], xb[m], acc[m][n], 0, 0, 0);
+            } else {
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -545,6 +573,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
 #pragma unroll
                     for (int m = 0; m < MTW; ++m)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tap & 1][n][r], xf[tap & 1][m][r], acc[m][n], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (late && !(ABL(aa) & 2)) ahead = (sg_u < nunits) ? stage() : 0;
@@ -1067,7 +1096,11 @@ struct WgradArgs {
 // A/B fragments with ds_read_b32 (lane (i, g): channel i of pixel x0+g, which is what the f32 MFMA wants).
 // Accumulators stay in registers across all rows; at the end the four waves are folded through LDS and
 // ONE partial per workgroup goes to the workspace (deterministic second pass: wgrad_reduce_k).
-template <int KH, int KW, int S, int P, int TA, int TB, int NW>
+// BF (opt-in experiment, BASELINE config 3): both operands are rounded to bf16 on their way from LDS to the matrix pipe and one
+// v_mfma_f32_16x16x16_bf16 covers a k-step of SIXTEEN pixels: lane (i, g) supplies channel i of pixels x0 + g + 4e, e = 0..3 (any
+// k <-> pixel assignment works as long as both operands use the same one; this one keeps the bank pattern of the f32 kernel).  Rows
+// are padded to a multiple of 16 pixels in LDS; accumulation, the bias gradient and the fold stay fp32.
+template <int KH, int KW, int S, int P, int TA, int TB, int NW, bool BF = false>
 __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
     constexpr int TAPS = KH * KW, CA = TA * 16, CB = TB * 16;
     // 8-wave workgroups put two waves on every SIMD.  With the full 32x32 channel group the accumulators of one
@@ -1088,7 +1121,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
     const int nrows = a.B * a.Hv;
     const int row0 = blockIdx.x * a.rows_per_wave;          // rows per WORKGROUP here
     const int row1 = min(row0 + a.rows_per_wave, nrows);
-    const int Wv4 = (a.Wv + 3) & ~3;
+    const int Wv4 = BF ? ((a.Wv + 15) & ~15) : ((a.Wv + 3) & ~3);
     const int UP = S * (Wv4 - 1) + KW;                       // pixels per staged input row (incl. zero padding)
     float* ubuf = smem;                                      // [NSLOT][UP][CA]
     float* vbuf = smem + NSLOT * UP * CA;                    // [2][Wv4][CB]
@@ -1256,6 +1289,46 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
             }
         };
         constexpr int DX = 4 * NXG;
+        if constexpr (BF) {
+            for (int xb0 = xg * 16; xb0 < Wv4; xb0 += 16 * NXG) {
+                const int x = xb0 + g;
+                float vraw[TB][4], uraw[TAPS][TAW][4];
+#pragma unroll
+                for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vraw[tb][e] = vrow[(x + 4 * e) * CB + tb * 16 + i];
+#pragma unroll
+                for (int ky = 0; ky < KH; ++ky) {
+                    const float* ur = ubuf + slot_of[ky] * UP * CA + (S * x) * CA + i;
+#pragma unroll
+                    for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+                        for (int ta = 0; ta < TAW; ++ta)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) uraw[ky * KW + kx][ta][e] = ur[(S * 4 * e + kx) * CA + (hp * TAW + ta) * 16];
+                }
+                s16x4 vb16[TB], ub16[TAPS][TAW];
+#pragma unroll
+                for (int tb = 0; tb < TB; ++tb) vb16[tb] = to_bf16x4((f32x4){vraw[tb][0], vraw[tb][1], vraw[tb][2], vraw[tb][3]});
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                    for (int ta = 0; ta < TAW; ++ta)
+                        ub16[t][ta] = to_bf16x4((f32x4){uraw[t][ta][0], uraw[t][ta][1], uraw[t][ta][2], uraw[t][ta][3]});
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                    for (int ta = 0; ta < TAW; ++ta)
+#pragma unroll
+                        for (int tb = 0; tb < TB; ++tb)
+                            acc[t][ta][tb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ub16[t][ta], vb16[tb], acc[t][ta][tb], 0, 0, 0);
+                if (do_bias) {
+#pragma unroll
+                    for (int tb = 0; tb < TB; ++tb) accbs[tb] += (vraw[tb][0] + vraw[tb][1]) + (vraw[tb][2] + vraw[tb][3]);
+                }
+            }
+            continue;
+        }
         // the prefetch of a step past the end of the row reads the row's last (valid, staged) k-step instead: no branch
         // around the loads, so each [prefetch ; multiply] pair stays one straight-line block the scheduler can interleave
         const int xlast = Wv4 - 4;
@@ -1769,7 +1842,7 @@ static size_t conv3x3_lds_bytes(int R, int NT, int TH, int W, int nchunk, int nb
     return ((size_t)nbuf * (TH + 2) * (W + 2) * 4 * R + (size_t)(nchunk > 1 ? nbuf : 1) * 9 * NT * 64 * R) * sizeof(float);
 }
 
-template <int R, int NW>
+template <int R, int NW, bool BF = false>
 static int launch_conv3x3_lds_r(const ConvArgs& a, int NT, int MTW, int TH, int wgs_per_cu, hipStream_t st) {
     ConvLdsArgs aa;
     aa.c = a; aa.TH = TH; aa.nbands = cdiv(a.H, TH);
@@ -1794,7 +1867,7 @@ static int launch_conv3x3_lds_r(const ConvArgs& a, int NT, int MTW, int TH, int 
     dim3 grid(wgs * nsplit), blk(NW * 64);
 #define RV_L3(nt, mt)                                                                              \
     if (NT == nt && MTW == mt) {                                                                  \
-        auto kern = conv3x3_lds_k<R, nt, mt, NW>;                                                 \
+        auto kern = conv3x3_lds_k<R, nt, mt, NW, BF>;                                             \
         static bool attr_done = false;                                                            \
         if (!attr_done) {                                                                         \
             /* the kernel also has 1 KiB of static LDS: dynamic + static must stay within the 160 KiB of a CU */ \
@@ -1821,7 +1894,8 @@ static int launch_conv3x3_lds_r(const ConvArgs& a, int NT, int MTW, int TH, int 
     return RV_EUNSUPPORTED;
 }
 
-static int launch_conv3x3_lds(const ConvArgs& a, int R, hipStream_t st, int force_nt = 0, int force_mt = 0, int nw = 4, int force_th = 0) {
+static int launch_conv3x3_lds(const ConvArgs& a, int R, hipStream_t st, int force_nt = 0, int force_mt = 0, int nw = 4, int force_th = 0,
+                              bool bf = false) {
     static const int mts_pow2[7] = {8, 4, 2, 1, 0, 0, 0}, mts_12[7] = {6, 5, 4, 3, 2, 1, 0};
     const int* mts = nw == 12 ? mts_12 : mts_pow2;
     // search (NT, MTW): prefer large tiles, but need >= ~1.5 units per workgroup slot on the chip
@@ -1855,6 +1929,12 @@ static int launch_conv3x3_lds(const ConvArgs& a, int R, hipStream_t st, int forc
         }
     }
     if (!best_nt) return RV_EUNSUPPORTED;
+    if (bf) {                                  // bf16 operands (16-channel chunks only; the caller checked R == 4)
+        if (nw == 12) return launch_conv3x3_lds_r<4, 12, true>(a, best_nt, best_mt, best_th, best_wpc, st);
+        if (nw == 16) return launch_conv3x3_lds_r<4, 16, true>(a, best_nt, best_mt, best_th, best_wpc, st);
+        if (nw == 8) return launch_conv3x3_lds_r<4, 8, true>(a, best_nt, best_mt, best_th, best_wpc, st);
+        return launch_conv3x3_lds_r<4, 4, true>(a, best_nt, best_mt, best_th, best_wpc, st);
+    }
     if (nw == 12)
         return R == 4 ? launch_conv3x3_lds_r<4, 12>(a, best_nt, best_mt, best_th, best_wpc, st)
                       : launch_conv3x3_lds_r<2, 12>(a, best_nt, best_mt, best_th, best_wpc, st);
@@ -2090,10 +2170,14 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
     // 0x700|NT<<4|MTW = 12 waves (three per SIMD) with MTW in {3, 5, 6}: the band sizes that fit whole 57/114/229-pixel rows.
     // TH<<12 on top of a forced LDS tile: rows per band (<= what the tile slots hold; 0 = as many as they hold).
     // Forced tiles that do not fit the shape return RV_EUNSUPPORTED (the host autotuner skips them).
+    // RV_ALGO_BF16 (bit 20): bf16 operands on the persistent 3x3 kernel (16-channel chunks; ignored -- fp32 -- everywhere else)
+    const bool bf = ((algo >> 20) & 1) && mode == 0 && R == 4;
+    algo &= ~(1 << 20);
     const int fam = (algo >> 8) & 15, f_nt = (algo >> 4) & 15, f_mt = algo & 15, f_th = (algo >> 12) & 255;
     if (mode == 0 && algo != 1 && fam != 1) {
         const bool forced = (fam >= 2 && fam <= 4) || fam == 7;
-        int rc3 = forced ? launch_conv3x3_lds(a, R, st, f_nt, f_mt, fam == 7 ? 12 : (fam == 4 ? 16 : (fam == 3 ? 8 : 4)), f_th) : launch_conv3x3_lds(a, R, st);
+        int rc3 = forced ? launch_conv3x3_lds(a, R, st, f_nt, f_mt, fam == 7 ? 12 : (fam == 4 ? 16 : (fam == 3 ? 8 : 4)), f_th, bf)
+                         : launch_conv3x3_lds(a, R, st, 0, 0, 4, 0, bf);
         if (rc3 == RV_OK) { RV_LAUNCH_CHECK("rv_conv_fwd(lds)"); *sums_done = true; return RV_OK; }
         if (forced) { rv_set_error("rv_conv_fwd: forced LDS tile NT=%d MTW=%d does not fit", f_nt, f_mt); return RV_EUNSUPPORTED; }
     }
@@ -2249,6 +2333,9 @@ int rv_wgrad_reduce_table(const void* table_dev, int count, long total_blocks, v
 static int conv_wgrad_impl(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, const float* V, int v_ld, int Hv, int Wv,
                            int Cb, int B, float* dw, long s_a, long s_b, int flip, float* dbias, int accumulate, void* workspace,
                            long workspace_bytes, void* stream, WreduceEntry* defer) {
+    // mode bit 8 (RV_WGRAD_BF16): bf16 operands on the matrix pipe for the 3x3 MFMA kernel (opt-in experiment; ignored elsewhere)
+    const bool want_bf = (mode & 0x100) != 0;
+    mode &= 0xff;
     hipStream_t st = (hipStream_t)stream;
     RV_CHECK_ARG(mode >= 0 && mode <= 2, "rv_conv_wgrad: bad mode %d", mode);
     const int taps = mode == 0 ? 9 : (mode == 1 ? 1 : 4);
@@ -2320,10 +2407,15 @@ static int conv_wgrad_impl(int mode, const float* U, int u_ld, int Hu, int Wu, i
         const int TA = plan.TA, TB = plan.TB;
         dim3 grid(a.nparts, plan.nga * plan.ngb), blk(256);
         const int KH = mode == 0 ? 3 : (mode == 1 ? 1 : 2), SS = mode == 2 ? 2 : 1;
-        const int Wv4 = (Wv + 3) & ~3;
-        const int UP = SS * (Wv4 - 1) + KH;
+        bool bf = want_bf && mode == 0;
+        int Wv4 = bf ? ((Wv + 15) & ~15) : ((Wv + 3) & ~3);
+        int UP = SS * (Wv4 - 1) + KH;
         const int nslot = SS == 1 ? KH + 1 : 2 * KH;
         size_t lds = ((size_t)nslot * UP * TA * 16 + (size_t)2 * Wv4 * TB * 16) * sizeof(float);
+        if (bf && lds > 156 * 1024) {                      // the 16-pixel padding does not fit: fp32 kernel
+            bf = false; Wv4 = (Wv + 3) & ~3; UP = SS * (Wv4 - 1) + KH;
+            lds = ((size_t)nslot * UP * TA * 16 + (size_t)2 * Wv4 * TB * 16) * sizeof(float);
+        }
         static int nw_env = 0;
         if (!nw_env) { const char* e = getenv("RV_WGRAD_NW"); nw_env = (e && atoi(e) == 4) ? 4 : 8; }
         const int nw = plan.nw ? plan.nw : nw_env;
@@ -2332,6 +2424,20 @@ static int conv_wgrad_impl(int mode, const float* U, int u_ld, int Hu, int Wu, i
         const size_t fold = (size_t)nh_ * (nxg_ / 2) * ((mode == 0 ? 9 : (mode == 1 ? 1 : 4)) * (TA / nh_) * TB + TB) * 4 * 64 * sizeof(float);
         if (lds < fold) lds = fold;
         RV_CHECK_ARG(lds <= 160 * 1024, "rv_conv_wgrad: row of %d pixels x %d channels does not fit LDS", Wv, TA * 16);
+#define RV_WG1B(ta, tb)                                                                           \
+    do {                                                                                         \
+        if (nw == 8) {                                                                           \
+            auto kern = wgrad_mfma_k<3, 3, 1, 1, ta, tb, 8, true>;                               \
+            if (lds > 64 * 1024)                                                                 \
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);                               \
+        } else {                                                                                 \
+            auto kern = wgrad_mfma_k<3, 3, 1, 1, ta, tb, 4, true>;                               \
+            if (lds > 64 * 1024)                                                                 \
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL(kern, grid, blk, lds, st, a);                                     \
+        }                                                                                        \
+    } while (0)
 #define RV_WG1(kh, kw, ss, pp, ta, tb)                                                            \
     do {                                                                                         \
         if (nw == 8) {                                                                           \
@@ -2353,11 +2459,17 @@ static int conv_wgrad_impl(int mode, const float* U, int u_ld, int Hu, int Wu, i
         else if (TA == 2 && TB == 1) RV_WG1(kh, kw, ss, pp, 2, 1);                               \
         else RV_WG1(kh, kw, ss, pp, 2, 2);                                                       \
     } while (0)
-        if (mode == 0) RV_WG(3, 3, 1, 1);
+        if (bf) {
+            if (TA == 1 && TB == 1) RV_WG1B(1, 1);
+            else if (TA == 1 && TB == 2) RV_WG1B(1, 2);
+            else if (TA == 2 && TB == 1) RV_WG1B(2, 1);
+            else RV_WG1B(2, 2);
+        } else if (mode == 0) RV_WG(3, 3, 1, 1);
         else if (mode == 1) RV_WG(1, 1, 1, 0);
         else RV_WG(2, 2, 2, 0);
 #undef RV_WG
 #undef RV_WG1
+#undef RV_WG1B
     }
 reduce:
     RV_LAUNCH_CHECK("rv_conv_wgrad");

@@ -249,7 +249,7 @@ class TrainStep:
     captured once into a hipGraph and replayed; the all-reduce and the optimiser kernel stay outside the
     graph so that the collective is an ordinary RCCL call."""
 
-    def __init__(self, model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=True, dual_stream=True):
+    def __init__(self, model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=True, dual_stream=True, bf16_backward=False):
         self.model, self.opt, self.alpha, self.VAT, self.clip = model, opt, alpha, VAT, clip
         self.batch = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
         self.batch_ul = {k: v.clone() for k, v in batch_ul.items() if torch.is_tensor(v)} if batch_ul else None
@@ -258,6 +258,9 @@ class TrainStep:
         self.loss = None
         self.use_graph = graph
         self.pack_plan = None
+        # opt-in experiment (BASELINE config 3): bf16 operands on the matrix pipe for the BACKWARD 3x3 convs of the final graphs; every
+        # forward pass and the whole power iteration stay fp32, so all loss terms / posteriorgrams are unchanged (ops.BF16)
+        self.bf16_backward = bool(bf16_backward)
         self.dual_stream = dual_stream        # the two VAT chains on two HIP streams (model._vat_two_streams)
         self._dual_ready = False              # ... from the second step on: the first one packs weights and autotunes
         if getattr(model, 'has_recurrence', False):
@@ -283,7 +286,8 @@ class TrainStep:
         try:
             defer = os.environ.get('RV_DEFER_WGRAD', '1') != '0' and getattr(self.model, 'defer_wgrad_reductions', True)
             defer_g = os.environ.get('RV_DEFER_GEMM', '1') != '0' and getattr(self.model, 'defer_param_gemms', True)
-            with ops.direct_param_grads(), (ops.deferred_wgrad_reductions() if defer else contextlib.nullcontext()) as pending, \
+            with ops.bf16_final_graphs(fwd=False, bwd=self.bf16_backward), ops.direct_param_grads(), \
+                    (ops.deferred_wgrad_reductions() if defer else contextlib.nullcontext()) as pending, \
                     (ops.deferred_param_gemms() if defer_g else contextlib.nullcontext()) as pending_g:
                 # conv grads accumulate straight into the flat bucket; their partial sums are folded by ONE launch per stream, and the
                 # linear / attention parameter-gradient GEMMs run as ONE grouped launch per stream

@@ -528,3 +528,56 @@ def test_grouped_deferred_gemms_vs_torch(dev):
         want = c0.double() + torch.einsum('zkm,zkn->zmn', at.double(), b.double())
         assert rel_err(c, want.float()) < 1e-5
     assert rel_err(rs, (rs0.double() + items[0][0][0].double().sum(0)).float()) < 1e-5
+
+
+@pytest.mark.parametrize('cin,cout,h,w,algo', [(16, 16, 40, 57, 0), (32, 64, 20, 28, 0x713), (64, 32, 24, 57, 0x422), (128, 128, 10, 14, 0x321),
+                                               (48, 96, 16, 57, 0x212), (192, 96, 10, 28, 0)])
+def test_conv3x3_bf16_operands_vs_torch(dev, cin, cout, h, w, algo):
+    """The opt-in bf16-operand variant of the persistent 3x3 kernel (rv_conv_fwd algo bit 20): equals a plain fp32 convolution of
+    the bf16-ROUNDED operands (products of bf16 numbers are exact in fp32; accumulation is fp32 in both), and differs from the
+    fp32 kernel by about 2^-9 relative -- i.e. the bit really selects the bf16 matrix instructions."""
+    import torch.nn.functional as F
+    from reconvat_amd import ops
+    B = 3
+    x = rnd(B, h, w, cin, seed=1).to(dev)
+    wt = (rnd(cout, cin, 3, 3, seed=2) * (1.0 / (9 * cin) ** 0.5)).to(dev)
+    bias = rnd(cout, seed=3).to(dev)
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    ref_bf = F.conv2d(rb(x).cpu().permute(0, 3, 1, 2), rb(wt).cpu(), bias.cpu(), padding=1).permute(0, 2, 3, 1)
+    ref_32 = F.conv2d(x.cpu().permute(0, 3, 1, 2), wt.cpu(), bias.cpu(), padding=1).permute(0, 2, 3, 1)
+    out = torch.empty(B, h, w, cout, device=dev)
+    pack = ops._pack('c3', wt, 'fwd')
+    args = (0, x.data_ptr(), cin, B, h, w, cin, out.data_ptr(), cout, h, w, cout, pack.data_ptr(), bias.data_ptr(), 0)
+    from reconvat_amd import _lib
+    lib = _lib.load()
+    rc = lib.rv_conv_fwd(*args, algo | ops.ALGO_BF16, None, None, 0, None, 0.0, torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        pytest.skip('tile does not fit this shape')
+    torch.cuda.synchronize()
+    assert rel_err(out, ref_bf) < 2e-5
+    d32 = rel_err(out, ref_32)
+    assert 2e-4 < d32 < 2e-2, d32
+
+
+@pytest.mark.parametrize('kind,cin,cout,h,w', [('c3', 16, 16, 24, 229), ('c3', 32, 32, 20, 114), ('t3', 96, 48, 12, 57), ('c3', 64, 128, 10, 28),
+                                              ('t3', 192, 96, 10, 28), ('c3', 48, 24, 9, 114), ('c3', 16, 32, 7, 33)])
+def test_wgrad3x3_bf16_operands_vs_torch(dev, kind, cin, cout, h, w):
+    """The opt-in bf16-operand variant of the 3x3 weight-gradient kernel (rv_conv_wgrad mode bit 8): equals torch's weight gradient
+    of the bf16-ROUNDED operands (fp32 accumulation in both), bias gradient exact fp32, and sits ~2^-9 away from the fp32 kernel."""
+    from reconvat_amd import ops
+    B = 3
+    x, dy = rnd(B, h, w, cin, seed=5), rnd(B, h, w, cout, seed=6)
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+
+    def ref(xx, dd):
+        wt = torch.zeros((cout, cin, 3, 3) if kind == 'c3' else (cin, cout, 3, 3), requires_grad=True)
+        y = F.conv2d(nchw(xx), wt, None, padding=1) if kind == 'c3' else F.conv_transpose2d(nchw(xx), wt, None, padding=1)
+        (y * nchw(dd)).sum().backward()
+        return wt.grad
+    want_bf, want_32 = ref(rb(x), rb(dy)), ref(x, dy)
+    wdev = torch.zeros_like(want_32).to(dev)
+    dw, db = ops.conv_wgrad(kind, x.to(dev), dy.to(dev), wdev, True, bf16=True)
+    torch.cuda.synchronize()
+    assert rel_err(dw, want_bf) < 5e-5
+    assert rel_err(db, dy.reshape(-1, cout).double().sum(0).float()) < 1e-5
+    assert 1e-4 < rel_err(dw, want_32) < 3e-2

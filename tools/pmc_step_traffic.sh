@@ -6,7 +6,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $out/$ctr.log 2>&1
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-parity > $out/$ctr.log 2>&1
 done
 cd $GRAFT_REPO_ROOT
 python3 tools/pmc_traffic.py $out > gpurun_out/pmc_${tag}_traffic.json
