@@ -324,7 +324,10 @@ def measure_families(step_fn, device):
         g = groups.setdefault(sig, {'count': 0, 'name': name, 'args': a})
         g['count'] += 1
     fam = {}
-    for g in groups.values():
+    # the grouped-GEMM device tables were allocated at the END of the recorded step, possibly in memory that an earlier launch of the
+    # step used as its (since freed) output: re-launch them FIRST, before the re-launches below scribble over such memory
+    ordered = sorted(groups.values(), key=lambda g_: g_['name'] != 'rv_gemm_table_run')
+    for g in ordered:
         a = list(g['args'])
         a[-1] = cur
         fn = getattr(lib, g['name'])
