@@ -424,6 +424,10 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
                             if 0 < th < th_max and th < 256:
                                 extra.append(th << 12 | cand)
                     cands += sorted(set(extra))
+                    fams = os.environ.get('RV_TUNE_FAMILIES')          # experiment: restrict the LDS tile families the tuner may pick
+                    if fams:
+                        keep = {int(f, 0) for f in fams.split(',')}
+                        cands = [c for c in cands if ((c >> 8) & 15) in keep or c in (1, 2) and ((1 if c == 1 else 2) in keep)]
                 for cand in cands:
                     if lib.rv_conv_fwd(*targs, cand | bfbit, scratch, *tail, st.cuda_stream) != 0:
                         continue                                   # tile does not fit this shape
