@@ -539,8 +539,13 @@ def main():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
-    if world > 1:
+    if world > 1 or os.environ.get('RV_DP_FORCE_ALLREDUCE') == '1':
+        # (RV_DP_FORCE_ALLREDUCE=1 under a launcher with one rank: a single-rank RCCL group, so that a one-GPU box executes the
+        # gradient all-reduce call for real)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29541')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=device)
 
     import reconvat_amd as ra
@@ -565,7 +570,7 @@ def main():
             step.use_graph, step.graph, used_graph = False, None, False
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -577,7 +582,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -588,7 +593,7 @@ def main():
     # every rank.  Checksum = wrapping int64 sum of the parameter bit patterns; MAX - MIN over ranks must be 0.
     rccl_ranks, replicas_equal = 1, True
     checksum = opt.flat_param.view(torch.int32).sum(dtype=torch.int64).reshape(1)
-    if world > 1:
+    if dist.is_initialized():
         rccl_ranks = dist.get_world_size()
         hi, lo = checksum.clone(), checksum.clone()
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -609,6 +614,7 @@ def main():
                    'kernel_plan_table': plans.digest(), 'kernel_plan_mode': str(ops_mod.AUTOTUNE),
                    'final_loss': round(loss, 5), 'vat_nan_flag': nan_flag, 'losses_last_step': loss_terms},
         'rccl_ranks': rccl_ranks, 'replicas_equal': replicas_equal, 'param_checksum': int(checksum.item()),
+        'rccl_allreduce_calls': int(getattr(opt, 'allreduce_calls', 0)),      # gradient all-reduces issued through RCCL by FlatAdam.step
     }
     if rank == 0 and world == 1:
         if not args.no_roofline:
@@ -672,10 +678,18 @@ def main():
             line['parity'] = parity_leg(device)
         if not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
-    if rank == 0:
-        print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner to the C-level stdout (block-buffered when piped, flushed at exit): push it out NOW so that
+        # the JSON line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        sys.stdout.write(json.dumps(line) + '\n')
+        sys.stdout.flush()
 
 
 if __name__ == '__main__':

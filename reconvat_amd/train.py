@@ -234,9 +234,12 @@ class FlatAdam:
 def allreduce_gradients(opt):
     """ONE RCCL all-reduce (sum) of the flat gradient bucket per optimiser step, after the final backward
     and never inside the VAT power iteration; the 1/world_size mean is folded into the Adam kernel."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    # (RV_DP_FORCE_ALLREDUCE=1: also with a single-rank group -- lets a one-GPU box execute the RCCL call in place, tests/test_cli_gpu.py)
+    min_world = 1 if os.environ.get('RV_DP_FORCE_ALLREDUCE') == '1' else 2
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() >= min_world:
         dist.all_reduce(opt.flat_grad, op=dist.ReduceOp.SUM)
         opt.grad_scale = 1.0 / dist.get_world_size()
+        opt.allreduce_calls = getattr(opt, 'allreduce_calls', 0) + 1
         if getattr(opt, 'sync_error_word', False):
             # models with a recurrence (BiLSTM time-out flag): every rank must skip the same steps, or the replicas diverge and the
             # rank that raises in check() leaves its peers blocked in the next collective -- MAX the flag along with the gradients

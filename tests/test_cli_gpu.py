@@ -175,6 +175,28 @@ def test_bench_self_launch_two_ranks(dev):
     assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['replicas_equal'] is True
 
 
+def test_rccl_allreduce_executes_on_one_gpu(dev):
+    """The builder's lease is ONE GPU and RCCL refuses two ranks on one device ("Duplicate GPU detected"), so the two-rank test
+    above skips there.  This one runs the data-parallel code path for real with a SINGLE-rank RCCL group (RV_DP_FORCE_ALLREDUCE=1):
+    `init_process_group('nccl')`, the barrier, FlatAdam's one `dist.all_reduce` of the 14.6 MB flat bucket per step between the
+    hipGraph replay and the Adam kernel, the MAX / MIN reductions of the replica check, the teardown -- and the step must still
+    train (same loss as without the group; an all-reduce over one rank is the identity)."""
+    outs = []
+    for force in ('0', '1'):
+        env = dict(os.environ, PYTHONPATH=ROOT, RV_DP_FORCE_ALLREDUCE=force, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_PORT='29547')
+        p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
+                            '--no-roofline', '--no-parity'], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+        assert len(lines) == 1, p.stdout[-2000:]
+        assert p.stdout.strip().splitlines()[-1] == lines[0], 'the JSON line must be the LAST line of stdout: ' + p.stdout[-1500:]
+        outs.append(json.loads(lines[0]))
+    plain, rccl = outs
+    assert plain['rccl_allreduce_calls'] == 0 and rccl['rccl_allreduce_calls'] == 4 and rccl['rccl_ranks'] == 1
+    assert rccl['replicas_equal'] is True
+    assert abs(rccl['config']['final_loss'] - plain['config']['final_loss']) <= 2e-3 * abs(plain['config']['final_loss'])
+
+
 def test_bench_refuses_more_gpus_than_present(dev):
     n = torch.cuda.device_count() + 1
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--steps', '1', '--warmup', '0'],
