@@ -131,14 +131,18 @@ template <int R> struct VecR;
 template <> struct VecR<4> { typedef f32x4 T; };
 template <> struct VecR<2> { typedef f32x2 T; };
 
-template <int KH, int KW, int S, int P, int R, int NT, int MT, bool SCATTER>
+// KS = 4 (family 0x5NM): the four waves of a workgroup share ONE set of MT x NT tiles and split the K loop (taps x channel chunks)
+// four ways; the partial accumulators are folded through LDS and the (m, n) tiles are dealt round-robin to the waves for the
+// epilogue.  The deep 2x2 / 1x1 layers (K = 256 .. 512, only a few hundred pixel tiles) are otherwise ONE dependent chain of up to
+// 32 [global load -> MFMA] steps per wave at about one wave per SIMD: latency-bound at 17-25 us for < 1 GFLOP.
+template <int KH, int KW, int S, int P, int R, int NT, int MT, bool SCATTER, int KS = 1>
 __global__ __launch_bounds__(256) void conv_mfma_k(ConvArgs a) {
     typedef typename VecR<R>::T vec;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
     const int bx = xcd_remap(blockIdx.x, gridDim.x);
     const int nt0 = blockIdx.y * NT;
-    const long tile0 = ((long)bx * 4 + wave) * MT;
+    const long tile0 = KS == 1 ? ((long)bx * 4 + wave) * MT : (long)bx * MT;
     if (tile0 * 16 >= a.npix) return;
 
     int py[MT], px[MT], pb[MT];
@@ -167,9 +171,10 @@ __global__ __launch_bounds__(256) void conv_mfma_k(ConvArgs a) {
     const long wstep = (long)a.ntile_n * 64 * R;
     const int nchunk = a.nchunk;
     const int nsteps = KH * KW * nchunk;
+    const int s_lo = KS == 1 ? 0 : (wave * nsteps) / KS, s_hi = KS == 1 ? nsteps : ((wave + 1) * nsteps) / KS;
 
     // loader state (one tap ahead of the MFMAs at most)
-    int l_tap = 0, l_c = 0;
+    int l_tap = s_lo / nchunk, l_c = s_lo - l_tap * nchunk;
     bool ok[MT];
     long toff = 0;
     auto set_tap = [&](int tap) {
@@ -195,10 +200,10 @@ __global__ __launch_bounds__(256) void conv_mfma_k(ConvArgs a) {
     };
 
     vec wcur[NT], xcur[MT], wnxt[NT], xnxt[MT];
-    set_tap(0);
-    load(wcur, xcur, 0);
-    for (int s = 0; s < nsteps; ++s) {
-        if (s + 1 < nsteps) {
+    set_tap(l_tap);
+    if (s_lo < s_hi) load(wcur, xcur, s_lo);
+    for (int s = s_lo; s < s_hi; ++s) {
+        if (s + 1 < s_hi) {
             if (++l_c == nchunk) { l_c = 0; ++l_tap; set_tap(l_tap); }
             load(wnxt, xnxt, s + 1);
         }
@@ -215,6 +220,26 @@ __global__ __launch_bounds__(256) void conv_mfma_k(ConvArgs a) {
         for (int m = 0; m < MT; ++m) xcur[m] = xnxt[m];
     }
 
+    if constexpr (KS > 1) {
+        // fold the K slices: every wave parks its MT x NT accumulators, then tile q = m * NT + n belongs to wave q % KS
+        __shared__ f32x4 part[KS][MT * NT][64];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) part[wave][m * NT + n][lane] = acc[m][n];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int q = m * NT + n;
+                if (q % KS != wave) continue;
+                f32x4 sum = part[0][q][lane];
+#pragma unroll
+                for (int w = 1; w < KS; ++w) sum += part[w][q][lane];
+                acc[m][n] = sum;
+            }
+    }
     // epilogue: lane holds channels co0..co0+3 of pixel j of every (m, n) tile
     f32x4 bv[NT];
 #pragma unroll
@@ -229,6 +254,7 @@ __global__ __launch_bounds__(256) void conv_mfma_k(ConvArgs a) {
         if (!pv[m]) continue;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
+            if (KS > 1 && (m * NT + n) % KS != wave) continue;
             const int ncol = (nt0 + n) * 16 + 4 * g;      // GEMM row index (cout')
             int co0;
             long opix;
@@ -1799,8 +1825,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_table_k(const WreduceEntry* 
 // host dispatch
 // ------------------------------------------------------------------------------------------
 template <int KH, int KW, int S, int P, int R, bool SC>
-static int launch_conv_rt(const ConvArgs& a, int NT, int MT, hipStream_t st) {
+static int launch_conv_rt(const ConvArgs& a, int NT, int MT, hipStream_t st, bool ksplit = false) {
     const long ntiles = (a.npix + 15) / 16;
+    if (ksplit) {                              // K loop split over the four waves of a workgroup (deep layers; R == 4 only)
+        if constexpr (R == 4 && !(KH == 3)) {
+#define RV_CASEK(nt, mt)                                                                         \
+    if (NT == nt && MT == mt) {                                                                  \
+        dim3 grid(cdiv(ntiles, mt), a.ntile_n / nt);                                             \
+        hipLaunchKernelGGL((conv_mfma_k<KH, KW, S, P, R, nt, mt, SC, 4>), grid, dim3(256), 0, st, a); \
+        return RV_OK;                                                                            \
+    }
+            RV_CASEK(1, 1) RV_CASEK(1, 2) RV_CASEK(2, 1) RV_CASEK(2, 2) RV_CASEK(1, 4) RV_CASEK(4, 1)
+#undef RV_CASEK
+        }
+        return RV_EUNSUPPORTED;
+    }
 #define RV_CASE(nt, mt)                                                                          \
     if (NT == nt && MT == mt) {                                                                  \
         dim3 grid(cdiv(ntiles, 4 * mt), a.ntile_n / nt);                                         \
@@ -2183,6 +2222,14 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
     }
     int NT, MT;
     choose_tiles((a.npix + 15) / 16, a.ntile_n, &NT, &MT);
+    const bool ksplit = fam == 5;              // 0x5NM: direct kernel, K loop split over the four waves (1x1 / 2x2 modes, 16-channel chunks)
+    if (ksplit) {
+        if (mode == 0 || R != 4 || f_nt < 1 || a.ntile_n % f_nt || a.nchunk * (mode == 2 ? 4 : 1) < 4) {
+            rv_set_error("rv_conv_fwd: forced split-K direct tile NT=%d MT=%d invalid here", f_nt, f_mt);
+            return RV_EUNSUPPORTED;
+        }
+        NT = f_nt; MT = f_mt;
+    }
     if (fam == 1) {
         if (f_nt < 1 || a.ntile_n % f_nt || !(f_mt == 1 || f_mt == 2 || f_mt == 4) || f_nt > 4) {
             rv_set_error("rv_conv_fwd: forced direct tile NT=%d MT=%d invalid", f_nt, f_mt);
@@ -2193,9 +2240,9 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
     int rc = RV_EUNSUPPORTED;
     if (R == 4) {
         if (mode == 0) rc = launch_conv_rt<3, 3, 1, 1, 4, false>(a, NT, MT, st);
-        else if (mode == 1) rc = launch_conv_rt<1, 1, 1, 0, 4, false>(a, NT, MT, st);
-        else if (mode == 2) rc = launch_conv_rt<2, 2, 2, 0, 4, false>(a, NT, MT, st);
-        else rc = launch_conv_rt<1, 1, 1, 0, 4, true>(a, NT, MT, st);
+        else if (mode == 1) rc = launch_conv_rt<1, 1, 1, 0, 4, false>(a, NT, MT, st, ksplit);
+        else if (mode == 2) rc = launch_conv_rt<2, 2, 2, 0, 4, false>(a, NT, MT, st, ksplit);
+        else rc = launch_conv_rt<1, 1, 1, 0, 4, true>(a, NT, MT, st, ksplit);
     } else {
         if (mode == 0) rc = launch_conv_rt<3, 3, 1, 1, 2, false>(a, NT, MT, st);
         else if (mode == 1) rc = launch_conv_rt<1, 1, 1, 0, 2, false>(a, NT, MT, st);

@@ -402,6 +402,8 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
                     if ntile_n % nt:
                         continue
                     cands += [0x100 | nt << 4 | mt for mt in (1, 2, 4)]     # direct kernel (every mode)
+                    if mode != 0:                                           # ... with the K loop split over the four waves (deep layers)
+                        cands += [0x500 | nt << 4 | mt for mt in (1, 2, 4) if nt * mt <= 4]
                     if mode == 0:                                           # persistent LDS kernel, 4 / 8 / 16 waves
                         cands += [0x200 | nt << 4 | mt for mt in (1, 2, 4, 8)]
                         cands += [0x300 | nt << 4 | mt for mt in (1, 2, 4)]

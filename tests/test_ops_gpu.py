@@ -581,3 +581,33 @@ def test_wgrad3x3_bf16_operands_vs_torch(dev, kind, cin, cout, h, w):
     assert rel_err(dw, want_bf) < 5e-5
     assert rel_err(db, dy.reshape(-1, cout).double().sum(0).float()) < 1e-5
     assert 1e-4 < rel_err(dw, want_32) < 3e-2
+
+
+@pytest.mark.parametrize('kind,cin,cout,H,W,algo', [('down', 128, 128, 10, 14, 0x521), ('down', 64, 64, 12, 28, 0x512), ('down', 192, 64, 9, 21, 0x511),
+                                                    ('c1', 64, 128, 7, 28, 0x522), ('up', 128, 128, 5, 7, 0x541), ('up', 64, 64, 6, 14, 0x514)])
+def test_direct_conv_in_workgroup_splitk_vs_torch(dev, kind, cin, cout, H, W, algo, monkeypatch):
+    """Family 0x5NM of the direct kernel (the four waves of a workgroup split the K loop and fold through LDS): forward and both
+    gradients of the 1x1 / 2x2 conv kinds against torch (the backward uses the same family for the transposed role)."""
+    from reconvat_amd import ops
+    monkeypatch.setenv('RV_FORCE_ALGO', hex(algo))
+    monkeypatch.setenv('RV_FORCE_ALGO_ALL', '1')
+    B = 3
+    x = rnd(B, cin, H, W, seed=1)
+    if kind == 'down':
+        w, ref = rnd(cout, cin, 2, 2, seed=2, scale=0.2), lambda x_, w_, b_: F.conv2d(x_, w_, b_, stride=2)
+    elif kind == 'c1':
+        w, ref = rnd(cout, cin, 1, 1, seed=2, scale=0.2), lambda x_, w_, b_: F.conv2d(x_, w_, b_)
+    else:
+        w, ref = rnd(cin, cout, 2, 2, seed=2, scale=0.2), lambda x_, w_, b_: F.conv_transpose2d(x_, w_, b_, stride=2, output_padding=(0, 1))
+    b = rnd(cout, seed=3)
+    leaves = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    yr = ref(*leaves)
+    cot = rnd(*yr.shape, seed=4)
+    (yr * cot).sum().backward()
+    g = [nhwc(x).to(dev).requires_grad_(True), w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)]
+    size = (yr.shape[2], yr.shape[3]) if kind == 'up' else None
+    yg = ops.ConvFn.apply(g[0], g[1], g[2], kind, size)
+    (yg * nhwc(cot).to(dev)).sum().backward()
+    assert rel_err(nchw(yg), yr) < TOL
+    assert rel_err(nchw(g[0].grad), leaves[0].grad) < TOL_G
+    assert rel_err(g[1].grad, leaves[1].grad) < TOL_G and rel_err(g[2].grad, leaves[2].grad) < TOL_G
