@@ -134,6 +134,9 @@ int rv_gemm_table_run(const void* table_dev, int count, long total_blocks, int o
 int rv_sigmoid_bwd(const float* g1, int ld1, const float* g2, int ld2, const float* y, int ldy, float* dz, int ldz, long M,
                    int N, void* stream);
 int rv_colsum(const float* x, int ld, long M, int N, float* out, int accumulate, void* stream);
+/* out[i] (+)= per-channel sum c0 + i of a statistics workspace a conv's fused epilogue filled (rv_conv_fwd bn_sums, C channels): the
+ * column sums of that conv's output = the bias gradient of the layer consuming it as dY (the 2x2 up-conv), without re-reading it */
+int rv_sums_fold(const double* sums, int C, int c0, int n, float* out, int accumulate, void* stream);
 
 /* ---- 31-frame local multi-head attention (MutliHeadAttention1D.forward, model/UNet_onset.py:56-91)
  * q,k,v (and dq,dk,dv): rows of G*dh floats with row stride ld / dld (column slices of one fused projection buffer

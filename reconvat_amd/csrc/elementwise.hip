@@ -317,6 +317,25 @@ __global__ void zero_floats_k(float* p, int n) {
 }
 
 // out[n] = sum_m x[m*ld + n]   (out is overwritten unless accumulate)
+// out[i] (+)= sum over the RV_BN_NREP replicas of sums[rep][c0 + i], i < n, where `sums` is a BatchNorm statistics workspace of C channels
+// ([rep][2][C] fp64) that a conv's fused epilogue filled (rv_conv_fwd bn_sums): the per-channel sums of what the conv stored ARE the
+// column sums of its output -- the bias gradient of the layer that consumes that output as dY, without another pass over it.
+__global__ void sums_fold_k(const double* sums, int C, int c0, int n, float* out, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < RV_BN_NREP; ++r) s += sums[(long)r * 2 * C + c0 + i];
+    out[i] = accumulate ? out[i] + (float)s : (float)s;
+}
+
+int rv_sums_fold(const double* sums, int C, int c0, int n, float* out, int accumulate, void* stream) {
+    RV_CHECK_ARG(sums && out && n > 0 && c0 >= 0 && c0 + n <= C, "rv_sums_fold: bad channel range");
+    hipLaunchKernelGGL(sums_fold_k, dim3(cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, sums, C, c0, n, out, accumulate);
+    RV_LAUNCH_CHECK("rv_sums_fold");
+    return RV_OK;
+}
+
 int rv_colsum(const float* x, int ld, long M, int N, float* out, int accumulate, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate) hipLaunchKernelGGL(zero_floats_k, dim3(cdiv(N, 256)), dim3(256), 0, st, out, N);   // (a kernel: memset nodes proved unreliable across hipGraph replays)

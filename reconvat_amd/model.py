@@ -20,7 +20,7 @@ import torch.nn.init as init
 from . import ops
 from .constants import N_BINS
 from .frontend import MelSpectrogram, Normalization
-from .ops import (ARENA, BnLink, GradShare, ConvFn, UpCatFn, BnActFn, LinearFn, OnsetHeadsFn, LocalAttnFn, VatPerturbFn, SLOPE, bce_mean,
+from .ops import (ARENA, BnLink, ColsumLink, GradShare, ConvFn, UpCatFn, BnActFn, LinearFn, OnsetHeadsFn, LocalAttnFn, VatPerturbFn, SLOPE, bce_mean,
                   mse_mean, abs_mean)
 
 batchNorm_momentum = 0.1
@@ -34,13 +34,13 @@ def _conv(m, x, kind, detach, size=None, share=None):
     return ConvFn.apply(x, _p(m.weight, detach), _p(m.bias, detach), kind, size, None, None, share)
 
 
-def _conv_bn(conv, bn, x, kind, res, detach, bn_in=None, link=None, share=None):
+def _conv_bn(conv, bn, x, kind, res, detach, bn_in=None, link=None, share=None, dx_colsum=None):
     """lrelu(bn(conv(x))) (+ res).  In training mode the conv leaves the batch statistics of its output in a
     zeroed fp64 slice (fused epilogue) and the BatchNorm skips its own statistics pass.  ``link`` (a fresh
     ops.BnLink) is handed to the ONE conv that consumes the result as ``bn_in``: that conv's input-gradient kernel
     then also produces this BatchNorm's backward reduction."""
     stats = ARENA.take(ops.bn_ws_doubles(bn.num_features), x.device) if bn.training else None
-    z = ConvFn.apply(x, _p(conv.weight, detach), _p(conv.bias, detach), kind, None, stats, bn_in, share)
+    z = ConvFn.apply(x, _p(conv.weight, detach), _p(conv.bias, detach), kind, None, stats, bn_in, share, dx_colsum)
     return BnActFn.apply(z, _p(bn.weight, detach), _p(bn.bias, detach), bn.running_mean, bn.running_var,
                          bn.num_batches_tracked, res, bn.training, SLOPE, stats, link)
 
@@ -84,13 +84,14 @@ class d_block(nn.Module):
         self.isLast = isLast
 
     def forward(self, x, size, skip_src=None, skip_conv=None, detach=False, share=None):
+        cs = ColsumLink()            # conv2d's input-gradient kernel also leaves the column sums of dY(us): the up-conv's bias gradient
         if self.isLast:
-            x = _conv(self.us, x, 'up', detach, size)
+            x = ConvFn.apply(x, _p(self.us.weight, detach), _p(self.us.bias, detach), 'up', size, None, None, None, None, cs)
         else:
             x = UpCatFn.apply(x, _p(self.us.weight, detach), _p(self.us.bias, detach), skip_src,
-                              _p(skip_conv.weight, detach), _p(skip_conv.bias, detach), size, share)
+                              _p(skip_conv.weight, detach), _p(skip_conv.bias, detach), size, share, cs)
         l2 = BnLink()                                                          # the bn2d output feeds conv1d only
-        x = _conv_bn(self.conv2d, self.bn2d, x, 't3', None, detach, link=l2)
+        x = _conv_bn(self.conv2d, self.bn2d, x, 't3', None, detach, link=l2, dx_colsum=cs)
         if self.isLast:
             return ConvFn.apply(x, _p(self.conv1d.weight, detach), _p(self.conv1d.bias, detach), 't3', None, None, l2)
         return _conv_bn(self.conv1d, self.bn1d, x, 't3', None, detach, bn_in=l2)

@@ -468,7 +468,7 @@ def conv_forward_into(kind, x, w, b, out, stats=None, bf16=False):
     _conv_call(_FWD_MODE[kind], x, ild, bb, h, wd, cin, out, old, ho, wo, cout, _pack(kind, w, 'fwd'), b, stats, bf16=bf16)
 
 
-def conv_dgrad_into(kind, dy, w, dx, bn_link=None, accumulate=False, bf16=False):
+def conv_dgrad_into(kind, dy, w, dx, bn_link=None, accumulate=False, bf16=False, sum_ws=None):
     """dx (NHWC view) (+)= input gradient of the conv given dy (NHWC view).  bn_link: the BnLink of the BatchNorm that
     produced the conv's input -- its backward reduction is then computed in this kernel's epilogue."""
     assert not (accumulate and bn_link is not None)
@@ -477,9 +477,11 @@ def conv_dgrad_into(kind, dy, w, dx, bn_link=None, accumulate=False, bf16=False)
     stats = bnbwd = None
     if bn_link is not None and bn_link.usable(dx):
         stats, bnbwd = bn_link.ws, (bn_link.z, bn_link.coef, bn_link.slope)
+    elif sum_ws is not None:
+        stats = sum_ws                           # plain per-channel sums of dx (ColsumLink): the fused statistics epilogue
     _conv_call(_DGRAD_MODE[kind], dy, ild, bb, h, wd, c, dx, old, ho, wo, co, _pack(kind, w, 'dgrad'), None, stats, bnbwd, accumulate,
                bf16=bf16)
-    if stats is not None:
+    if bnbwd is not None:
         bn_link.ready = True
 
 
@@ -499,6 +501,17 @@ class GradShare:
             return self.buf
         conv_dgrad_into(kind, dy, w, self.buf, accumulate=True, bf16=bf16)
         return None
+
+
+class ColsumLink:
+    """Connects the conv whose INPUT gradient is dY of a 2x2 up-conv (d_block: conv2d consumes the up-conv's output) with that
+    up-conv: the column sums of dY -- the up-conv's bias gradient -- are the per-channel sums of what the producer's input-gradient
+    kernel stores, which its fused statistics epilogue provides for free (instead of a colsum pass re-reading dY: 20 launches of
+    ~17 us per step)."""
+
+    def __init__(self):
+        self.sums = None         # fp64 statistics workspace filled by the producer's dgrad
+        self.c = 0               # its channel count
 
 
 class BnLink:
@@ -570,7 +583,7 @@ def _tune_wgrad(lib, mode, taps, u, uld, hu, wu, ca, v, vld, hv, wv, cb, bb, w, 
         print(f'[tune] wgrad taps={taps} {ca}->{cb} {hv}x{wv} B={bb}: nw={choice[0]} wgs={choice[1]} {best / 3 * 1e3:.1f} us', file=sys.stderr)
 
 
-def conv_wgrad(kind, x, dy, w, want_bias=True, dw_acc=None, db_acc=None, bf16=False):
+def conv_wgrad(kind, x, dy, w, want_bias=True, dw_acc=None, db_acc=None, bf16=False, colsum=None):
     """(dw, db) in the PyTorch layouts of `w` / bias; with dw_acc/db_acc the results are ADDED into those buffers."""
     bb, h, wd, cin, xld = _geom(x)
     _, ho, wo, cout, yld = _geom(dy)
@@ -619,7 +632,11 @@ def conv_wgrad(kind, x, dy, w, want_bias=True, dw_acc=None, db_acc=None, bf16=Fa
         call('rv_conv_wgrad', mode, ptr(u), uld, hu, wu, ca, ptr(v), vld, hv, wv, cb, bb, ptr(dw), s_a, s_b, flip,
              bias_ptr, acc, ptr(ws), nbytes, stream())
     if kind == 'up' and want_bias:
-        call('rv_colsum', ptr(dy), yld, bb * ho * wo, cout, ptr(db), acc, stream())
+        if colsum is not None and colsum.sums is not None:
+            # dY's column sums came with the kernel that produced dY (ColsumLink): fold the replicas, no pass over dY
+            call('rv_sums_fold', ptr(colsum.sums), colsum.c, 0, cout, ptr(db), acc, stream())
+        else:
+            call('rv_colsum', ptr(dy), yld, bb * ho * wo, cout, ptr(db), acc, stream())
     return (None, None) if acc else (dw, db)
 
 
@@ -705,7 +722,9 @@ class ConvFn(Function):
     """y = conv(x) for any of the five conv kinds (new contiguous NHWC tensor)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, kind, size, stats=None, bn_in=None, share=None):
+    def forward(ctx, x, w, b, kind, size, stats=None, bn_in=None, share=None, dx_colsum=None, dy_colsum=None):
+        """dx_colsum: a ColsumLink this conv's input-gradient kernel fills (column sums of dx); dy_colsum: a filled-in-backward
+        ColsumLink holding the column sums of this conv's dY (kind 'up': its bias gradient)."""
         bb, h, wd, cin, _ = _geom(x)
         _, cout = _channels(kind, w)
         ho, wo = _out_hw(kind, h, wd, size)
@@ -716,6 +735,7 @@ class ConvFn(Function):
         ctx.xshape = tuple(x.shape)
         ctx.bn_in = bn_in            # BnLink of the BatchNorm whose output is x (single consumer), or None
         ctx.share = share            # GradShare of x (several conv consumers), or None
+        ctx.dx_colsum, ctx.dy_colsum = dx_colsum, dy_colsum
         ctx.save_for_backward(x if ctx.needs_input_grad[1] else None, w)
         ctx.params = (w, b)          # parameter objects (for direct gradient accumulation)
         return y
@@ -731,15 +751,22 @@ class ConvFn(Function):
                 dx = ctx.share.dgrad(ctx.kind, dy, w, ctx.xshape, bf16=bf)
             else:
                 dx = torch.empty(ctx.xshape, device=dy.device, dtype=torch.float32)
-                conv_dgrad_into(ctx.kind, dy, w, dx, ctx.bn_in, bf16=bf)
+                sum_ws = None
+                if ctx.dx_colsum is not None and ctx.live and ctx.bn_in is None:
+                    sum_ws = ARENA.take(bn_ws_doubles(ctx.xshape[3]), dy.device)
+                conv_dgrad_into(ctx.kind, dy, w, dx, ctx.bn_in, bf16=bf, sum_ws=sum_ws)
+                if sum_ws is not None:
+                    ctx.dx_colsum.sums, ctx.dx_colsum.c = sum_ws, ctx.xshape[3]
         if ctx.needs_input_grad[1]:
             pw, pb = ctx.params
             gw, gb = _grad_buf(pw), _grad_buf(pb)
             if gw is not None and (gb is not None or not ctx.needs_input_grad[2]):
-                conv_wgrad(ctx.kind, x, dy, w, ctx.needs_input_grad[2], gw, gb, bf16=bf)
+                conv_wgrad(ctx.kind, x, dy, w, ctx.needs_input_grad[2], gw, gb, bf16=bf, colsum=ctx.dy_colsum)
             else:
-                dw, db = conv_wgrad(ctx.kind, x, dy, w, ctx.needs_input_grad[2], bf16=bf)
-        return dx, dw, db, None, None, None, None, None
+                dw, db = conv_wgrad(ctx.kind, x, dy, w, ctx.needs_input_grad[2], bf16=bf, colsum=ctx.dy_colsum)
+        if ctx.dy_colsum is not None:
+            ctx.dy_colsum.sums = None            # drop the reference
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 class UpCatFn(Function):
@@ -748,7 +775,7 @@ class UpCatFn(Function):
     model/UNet_onset.py:219-220, with the encoder's extra skip conv, :244-246, computed here)."""
 
     @staticmethod
-    def forward(ctx, x, w_up, b_up, s, w_skip, b_skip, size, share=None):
+    def forward(ctx, x, w_up, b_up, s, w_skip, b_skip, size, share=None, dy_colsum=None):
         bb, h, wd, cin, _ = _geom(x)
         cu = w_up.shape[1]
         cs = w_skip.shape[0]
@@ -758,6 +785,7 @@ class UpCatFn(Function):
         conv_forward_into('up', x, w_up, b_up, cat[..., :cu])
         conv_forward_into('c3', s, w_skip, b_skip, cat[..., cu:], bf16=BF16['fwd'] and ctx.live)
         ctx.cu = cu
+        ctx.dy_colsum = dy_colsum    # ColsumLink: column sums of dcat from the kernel that produces it
         ctx.share = share            # GradShare of s (it also feeds the next encoder block)
         ctx.shapes = (tuple(x.shape), tuple(s.shape))
         need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[4]
@@ -786,9 +814,9 @@ class UpCatFn(Function):
         if ctx.needs_input_grad[1]:
             gw, gb = _grad_buf(pwu), _grad_buf(pbu)
             if gw is not None and gb is not None:
-                conv_wgrad('up', x, d_up, w_up, True, gw, gb)
+                conv_wgrad('up', x, d_up, w_up, True, gw, gb, colsum=ctx.dy_colsum)
             else:
-                dwu, dbu = conv_wgrad('up', x, d_up, w_up, True)
+                dwu, dbu = conv_wgrad('up', x, d_up, w_up, True, colsum=ctx.dy_colsum)
         if ctx.needs_input_grad[4]:
             gw, gb = _grad_buf(pws), _grad_buf(pbs)
             bfw = BF16['bwd'] and ctx.live
@@ -796,7 +824,9 @@ class UpCatFn(Function):
                 conv_wgrad('c3', s, d_sk, w_skip, True, gw, gb, bf16=bfw)
             else:
                 dws, dbs = conv_wgrad('c3', s, d_sk, w_skip, True, bf16=bfw)
-        return dx, dwu, dbu, ds, dws, dbs, None, None
+        if ctx.dy_colsum is not None:
+            ctx.dy_colsum.sums = None
+        return dx, dwu, dbu, ds, dws, dbs, None, None, None
 
 
 # --------------------------------------------------------------------------------------------
