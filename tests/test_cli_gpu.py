@@ -154,6 +154,22 @@ def test_plumbing_config_on_gpu_and_cpu_device_message(dev, tmp_path):
     assert p.returncode != 0 and 'MI355X only' in (p.stderr + p.stdout) and 'Traceback' not in p.stderr
 
 
+def test_bf16_backward_and_tuning_modes_from_the_command_line(dev, tmp_path):
+    """`dtype=bf16` (opt-in experiment: bf16-operand backward convs, forward fp32) trains through the script; RV_AUTOTUNE=0 (library
+    default tiles) and RV_AUTOTUNE=1 (on-line tuner) run the same command line as the default plan-table mode."""
+    logdir = str(tmp_path / 'bf16')
+    p = run('train_UNet_Onset_VAT.py', *SMALL, 'reconstruction=True', 'epoches=1', 'saving_freq=1', 'dtype=bf16', f'logdir={logdir}')
+    assert 'Training finished.' in p.stdout
+    rows = scalar_tags(logdir)
+    assert any(r['tag'] == 'loss/train_frame' for r in rows)
+    for mode in ('0', '1'):
+        env = dict(os.environ, PYTHONPATH=ROOT, RV_AUTOTUNE=mode)
+        q = subprocess.run([sys.executable, os.path.join(ROOT, 'train_UNet_VAT.py'), 'with', *SMALL, 'VAT=True', 'reconstruction=False',
+                            'epoches=1', f'logdir={tmp_path / ("tune" + mode)}'], capture_output=True, text=True, cwd=ROOT, env=env,
+                           timeout=900)
+        assert q.returncode == 0 and 'Training finished.' in q.stdout, q.stderr[-2000:]
+
+
 def test_eager_torch_optimizer_path(dev, tmp_path):
     """graph=False fused_optimizer=False: the reference loop verbatim (train_VAT_model + torch.optim.Adam + StepLR)."""
     logdir = str(tmp_path / 'eager')
