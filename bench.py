@@ -416,22 +416,25 @@ def cpu_baseline():
 
 def parity_leg(device):
     """After the timed loop, in the SAME process and kernel configuration: one frozen-weight step of the bench schedule
-    (two-stream hipGraph TrainStep, VAT + reconstruction) on the full-length fixture of tests/golden/lds_spread.npz (case
-    onset_T640: B = 2 segments of 327 680 samples, closed-form weights / inputs / injected VAT noise) against the REFERENCE's own
-    loss values on those inputs.  `oracle.fixture` only regenerates the closed-form fixture tensors (checker input, not a
+    (two-stream hipGraph TrainStep, VAT + reconstruction) on the full-length fixture at the bench's OWN batch (tests/golden/anchor_b8.npz,
+    case onset_T640_B8: B_l = B_ul = 8 segments of 327 680 samples, closed-form weights / inputs / injected VAT noise; falls back to the
+    B = 2 case of lds_spread.npz) against the REFERENCE's own loss values on those inputs.  `oracle.fixture` only regenerates the closed-form fixture tensors (checker input, not a
     compute path)."""
     import numpy as np
     import reconvat_amd as ra
     from reconvat_amd import plans
     from oracle import fixture as fx
-    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'lds_spread.npz'))
-    case = 'onset_T640'
+    b8 = os.path.join(ROOT, 'tests', 'golden', 'anchor_b8.npz')
+    if os.path.exists(b8):                      # the bench's own batch: B_l = B_ul = 8 (the reference at 8 threads / 1 thread, fp32)
+        g, case, nb, src = np.load(b8), 'onset_T640_B8', 8, 'tests/golden/anchor_b8.npz'
+    else:
+        g, case, nb, src = np.load(os.path.join(ROOT, 'tests', 'golden', 'lds_spread.npz')), 'onset_T640', 2, 'tests/golden/lds_spread.npz'
 
     def mk(tag):
-        onset, frame = fx.fixture_labels(2, 640, tag)
-        return {'audio': fx.fixture_audio(2, 640 * 512, tag).to(device), 'onset': onset.to(device), 'frame': frame.to(device)}
+        onset, frame = fx.fixture_labels(nb, 640, tag)
+        return {'audio': fx.fixture_audio(nb, 640 * 512, tag).to(device), 'onset': onset.to(device), 'frame': frame.to(device)}
     bl, bul = mk('L'), mk('UL')
-    noise = [fx.fixture_noise((2, 1, 640, 229), 'd0_ul').to(device), fx.fixture_noise((2, 1, 640, 229), 'd0_l').to(device)]
+    noise = [fx.fixture_noise((nb, 1, 640, 229), 'd0_ul').to(device), fx.fixture_noise((nb, 1, 640, 229), 'd0_l').to(device)]
     m = ra.UNet_Onset((2, 2), (2, 2), log=True, reconstruction=True, mode='imagewise', spec='Mel', XI=1e-6, eps=2)
     m.load_state_dict(fx.fixture_params('onset', True))
     m.to(device).train()
@@ -454,11 +457,12 @@ def parity_leg(device):
         errs[k.split('/')[-1]] = abs(float(step.losses[k]) - float(ref)) / max(abs(float(ref)), 1e-6)
     vat = {k: v for k, v in errs.items() if 'LDS' in k or 'r_norm' in k}
     non = {k: v for k, v in errs.items() if k not in vat}
-    return {'case': f'{case} (tests/golden/lds_spread.npz: the reference at 8 threads fp32), two-stream hipGraph TrainStep, frozen weights',
+    return {'case': f'{case} ({src}: the reference at 8 threads fp32, B_l = B_ul = {nb} full segments), two-stream hipGraph TrainStep, frozen weights',
             'rel_err_non_vat_max': float(f'{max(non.values()):.3e}'), 'rel_err_vat_max': float(f'{max(vat.values()):.3e}'),
             'rel_err': {k: float(f'{v:.3e}') for k, v in errs.items()},
             'reference_own_spread_vat_max': float(f'{max(v for k, v in spread.items() if "LDS" in k or "r_norm" in k):.3e}'),
-            'tolerance': '1e-3 relative (north_star); VAT terms: max(1e-3, 3 x the reference\'s own 1-thread / fp64 spread)',
+            'tolerance': '1e-3 relative (north_star) on every term; (the -m gpu tests widen the VAT terms to max(1e-3, 3 x the reference\'s own '
+                         '8-thread / 1-thread / fp64 movement) on the small fixtures, where the reference itself is noisier than 1e-3)',
             'kernel_plan_table': plans.digest()}
 
 

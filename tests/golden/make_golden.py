@@ -356,6 +356,31 @@ def g_lds_spread():
     save('lds_spread', **out)
 
 
+def g_anchor_b8():
+    """The full-size anchor at the BENCH's own batch: B_l = B_ul = 8 segments of 327 680 samples, UNet_Onset, VAT + reconstruction,
+    injected noise -- the reference's eleven loss values at 8 threads and at 1 thread (fp32; an fp64 run of this size does not fit this
+    container's memory, so the spread of this case is the 1-thread movement only) and digests of its posteriorgrams.  The GPU test and
+    bench.py's parity leg run exactly this shape with exactly the shipped tiles."""
+    out = {}
+    tag, kind, T, B = 'onset_T640_B8', 'onset', 640, 8
+    bl, bul = _batch(B, T, 'L'), _batch(B, T, 'UL')
+    noises = [fx.fixture_noise((B, 1, T, 229), n) for n in ('d0_ul', 'd0_l')]
+    runs = {}
+    for name, threads in (('f32_8t', 8), ('f32_1t', 1)):
+        pr, lr, sr = _ref_losses(kind, True, True, bl, bul, noises, dtype=torch.float32, threads=threads)
+        runs[name] = {k: v.detach() for k, v in pr.items() if torch.is_tensor(v)}
+        out[f'{tag}_{name}'] = np.array([float(v) for v in lr.values()], dtype=np.float64)
+        if name == 'f32_8t':
+            out[f'{tag}_keys'] = np.array(list(lr.keys()))
+        del pr, lr, sr
+    base = out[f'{tag}_f32_8t']
+    out[f'{tag}_spread'] = np.abs(out[f'{tag}_f32_1t'] - base) / np.maximum(np.abs(base), 1e-12)
+    print(tag, {k: f'{s_:.1e}' for k, s_ in zip(out[f'{tag}_keys'], out[f'{tag}_spread'])})
+    for k in ('frame', 'onset', 'frame2', 'reconstruction'):
+        out[f'{tag}_{k}'] = digest(runs['f32_8t'][k], 512)
+    save('anchor_b8', **out)
+
+
 def g_application():
     """UNet.run_on_batch_application (model/self_attention_VAT.py:1205-1291) and UNet.transcribe (:1293-1314), reference run."""
     out = {}
@@ -780,7 +805,7 @@ def g_onset_frames():
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['frontend', 'unet', 'attention', 'networks', 'vat', 'run_on_batch', 'train_step', 'dataset',
-                             'decoding', 'onset_frames', 'ingest', 'lds_spread', 'application', 'lds_backward']
+                             'decoding', 'onset_frames', 'ingest', 'lds_spread', 'application', 'lds_backward', 'anchor_b8']
     for w in which:
         print('==', w)
         globals()['g_' + w]()
