@@ -378,6 +378,24 @@ def g_anchor_b8():
     print(tag, {k: f'{s_:.1e}' for k, s_ in zip(out[f'{tag}_keys'], out[f'{tag}_spread'])})
     for k in ('frame', 'onset', 'frame2', 'reconstruction'):
         out[f'{tag}_{k}'] = digest(runs['f32_8t'][k], 512)
+    # BASELINE config 2 at the script's own batch sizes (train_UNet_VAT.py:54,56: train_batch_size = 1, batch_size = 8): the no-onset
+    # UNet, VAT + reconstruction, ONE labelled and EIGHT unlabelled full segments
+    tag = 'frame_T640_B1_8'
+    bl, bul = _batch(1, T, 'L'), _batch(8, T, 'UL')
+    noises = [fx.fixture_noise((8, 1, T, 229), 'd0_ul'), fx.fixture_noise((1, 1, T, 229), 'd0_l')]
+    runs = {}
+    for name, threads in (('f32_8t', 8), ('f32_1t', 1)):
+        pr, lr, sr = _ref_losses('frame', True, True, bl, bul, noises, dtype=torch.float32, threads=threads)
+        runs[name] = {k: v.detach() for k, v in pr.items() if torch.is_tensor(v)}
+        out[f'{tag}_{name}'] = np.array([float(v) for v in lr.values()], dtype=np.float64)
+        if name == 'f32_8t':
+            out[f'{tag}_keys'] = np.array(list(lr.keys()))
+        del pr, lr, sr
+    base = out[f'{tag}_f32_8t']
+    out[f'{tag}_spread'] = np.abs(out[f'{tag}_f32_1t'] - base) / np.maximum(np.abs(base), 1e-12)
+    print(tag, {k: f'{s_:.1e}' for k, s_ in zip(out[f'{tag}_keys'], out[f'{tag}_spread'])})
+    for k in ('frame', 'frame2', 'reconstruction'):
+        out[f'{tag}_{k}'] = digest(runs['f32_8t'][k], 512)
     save('anchor_b8', **out)
 
 

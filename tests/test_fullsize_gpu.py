@@ -264,3 +264,53 @@ def test_bench_batch_anchor_vs_reference(dev):
     from reconvat_amd import ops
     assert all(tuple(int(x) for x in k) in conv for k in ops._algo_cache if k[1] == 8 and k[2] in (640, 320, 160, 80, 40)), \
         'the B = 8 step must run exact table entries'
+
+
+def test_config2_batch_anchor_vs_reference(dev):
+    """BASELINE config 2 at the script's own batch sizes (train_UNet_VAT.py:54,56): the no-onset UNet, VAT + reconstruction, ONE
+    labelled and EIGHT unlabelled full segments, two-stream hipGraph TrainStep -- against the reference's own loss values and
+    posteriorgram digests (tests/golden/anchor_b8.npz, case frame_T640_B1_8).  A single labelled segment makes the labelled branch's
+    train-mode BatchNorm statistics per-sample, which is also what the reference does."""
+    import os
+    import numpy as np
+    import reconvat_amd as ra
+    import parity_tol
+    from oracle import fixture as fx
+    from test_model_gpu import build, close_digest
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'anchor_b8.npz'))
+    case = 'frame_T640_B1_8'
+
+    def mk(b, tag):
+        onset, frame = fx.fixture_labels(b, 640, tag)
+        return {'audio': fx.fixture_audio(b, 640 * 512, tag).to(dev), 'onset': onset.to(dev), 'frame': frame.to(dev)}
+    bl, bul = mk(1, 'L'), mk(8, 'UL')
+    noise = [fx.fixture_noise((8, 1, 640, 229), 'd0_ul').to(dev), fx.fixture_noise((1, 1, 640, 229), 'd0_l').to(dev)]
+    m = build('frame', True, dev)
+    opt = ra.FlatAdam(m.parameters(), lr=0.0)
+    state = {'i': 0}
+
+    def draw(t):
+        state['i'] += 1
+        return noise[(state['i'] - 1) % 2].clone()
+    m.vat_loss.noise = draw
+    step = ra.TrainStep(m, opt, bl, bul, alpha=1.0, VAT=True, clip=3.0, graph=True, dual_stream=True)
+    step()
+    step()
+    torch.cuda.synchronize()
+    step.check()
+    keys = [str(k) for k in g[case + '_keys']]
+    assert list(step.losses.keys()) == keys
+    own = dict(zip(keys, (float(v) for v in g[case + '_spread'])))
+    noise_est = max(max(v for k, v in own.items() if parity_tol.is_vat_key(k)), parity_tol.spread('frame_T640'))
+    report = {}
+    for k, ref in zip(keys, g[case + '_f32_8t']):
+        err = abs(float(step.losses[k]) - float(ref)) / max(abs(float(ref)), 1e-6)
+        tol = max(1e-3, 3.0 * noise_est) if parity_tol.is_vat_key(k) else 1e-3
+        report[k.split('/')[-1]] = err
+        assert err <= tol, (k, float(step.losses[k]), float(ref), err, tol)
+    print('config 2 anchor (B_l = 1, B_ul = 8), relative errors vs the reference:', {k: f'{e:.1e}' for k, e in report.items()})
+    with torch.no_grad():
+        m.train()
+        pred, _, _ = m.run_on_batch(bl, None, False)
+    for k in ('frame', 'frame2', 'reconstruction'):
+        close_digest(pred[k], g[f'{case}_{k}'], 1e-3, 512)
