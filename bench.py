@@ -521,6 +521,9 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=8, help='labelled AND unlabelled segments per GPU')
+    ap.add_argument('--model', choices=('onset', 'unet'), default='onset',
+                    help="'unet': the no-onset model of train_UNet_VAT.py (BASELINE config 2; with --batch-l 1 the script's own batch sizes)")
+    ap.add_argument('--batch-l', type=int, default=None, help='labelled segments per GPU (default: --batch)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--single-stream', action='store_true', help='disable the two-stream step schedule (A/B)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -555,11 +558,12 @@ def main():
     import reconvat_amd as ra
     from reconvat_amd import plans, ops as ops_mod
     torch.manual_seed(1234)                       # identical initial weights on every rank
-    model = ra.UNet_Onset((2, 2), (2, 2), log=True, reconstruction=True, mode='imagewise', spec='Mel', device=str(device),
-                          XI=1e-6, eps=2).to(device)
+    cls = ra.UNet_Onset if args.model == 'onset' else ra.UNet
+    model = cls((2, 2), (2, 2), log=True, reconstruction=True, mode='imagewise', spec='Mel', device=str(device), XI=1e-6, eps=2).to(device)
+    batch_l = args.batch if args.batch_l is None else args.batch_l
     opt = ra.FlatAdam(model.parameters(), lr=1e-3, step_size=1000, gamma=0.98)
     gen = torch.Generator().manual_seed(1000 + rank)      # distinct data shard per rank
-    batch, batch_ul = synthetic_batch(args.batch, gen, device), synthetic_batch(args.batch, gen, device)
+    batch, batch_ul = synthetic_batch(batch_l, gen, device), synthetic_batch(args.batch, gen, device)
     torch.manual_seed(77 + rank)                  # VAT noise stream
     step = ra.TrainStep(model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=not args.no_graph,
                         dual_stream=not args.single_stream, bf16_backward=args.bf16_backward)
@@ -604,7 +608,7 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         replicas_equal = bool((hi - lo).item() == 0)
     ms = elapsed / args.steps * 1e3
-    audio_s = world * 2 * args.batch * SEG_SECONDS * args.steps / elapsed
+    audio_s = world * (batch_l + args.batch) * SEG_SECONDS * args.steps / elapsed
 
     line = {
         'metric': 'training audio-sec/sec (node)', 'value': round(audio_s, 2), 'unit': 'audio-s/s', 'n_gpus': world,
@@ -612,15 +616,15 @@ def main():
         'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32' if not args.bf16_backward else 'f32 forward + power iteration, bf16-operand / f32-accumulate backward 3x3 convs (opt-in experiment)',
         'data': 'synthetic',
-        'config': {'workload': f'ReconVAT UNet_Onset VAT=True reconstruction=True, per-GPU B_l={args.batch} + '
+        'config': {'workload': f'ReconVAT {cls.__name__} VAT=True reconstruction=True, per-GPU B_l={batch_l} + '
                                f'B_ul={args.batch} segments of 327680 samples (640 frames x 229 mel), Adam+StepLR, fp32',
-                   'parallelism': f'dp{world}', 'hipgraph': used_graph, 'two_stream_schedule': not args.single_stream, 'labelled_only_audio_s_per_s': round(audio_s / 2, 2),
+                   'parallelism': f'dp{world}', 'hipgraph': used_graph, 'two_stream_schedule': not args.single_stream, 'labelled_only_audio_s_per_s': round(audio_s * batch_l / (batch_l + args.batch), 2),
                    'kernel_plan_table': plans.digest(), 'kernel_plan_mode': str(ops_mod.AUTOTUNE),
                    'final_loss': round(loss, 5), 'vat_nan_flag': nan_flag, 'losses_last_step': loss_terms},
         'rccl_ranks': rccl_ranks, 'replicas_equal': replicas_equal, 'param_checksum': int(checksum.item()),
         'rccl_allreduce_calls': int(getattr(opt, 'allreduce_calls', 0)),      # gradient all-reduces issued through RCCL by FlatAdam.step
     }
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and args.model == 'onset' and batch_l == args.batch == 8:       # (the roofline / parity legs are written for the headline workload)
         if not args.no_roofline:
             eager = ra.TrainStep(model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=False)
             conv_ms, conv_flops_total, per_kernel, nlaunch, min_sets = measure_conv_phase(eager, device)
