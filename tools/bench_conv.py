@@ -24,11 +24,14 @@ taps = {'c3': 9, 't3': 9, 'c1': 1, 'down': 4, 'up': 4}[kind]
 flops = 2.0 * B * (h * w if kind == 'up' else ho * wo) * cin * cout * taps
 
 
+BF = os.environ.get('RV_BENCH_BF16') == '1'        # the opt-in bf16-operand variants (3x3 kernels)
+
+
 def run():
     if what == 'fwd':
-        ops.conv_forward_into(kind, x, wt, bias, y)
+        ops.conv_forward_into(kind, x, wt, bias, y, bf16=BF)
     else:
-        ops.conv_wgrad(kind, x, dy, wt, True)
+        ops.conv_wgrad(kind, x, dy, wt, True, bf16=BF)
 
 
 if os.environ.get('BURST'):
