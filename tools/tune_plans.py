@@ -32,6 +32,8 @@ def workloads(dev):
     yield 'UNet_Onset', ra.UNet_Onset((2, 2), (2, 2), log=True, reconstruction=True, mode='imagewise', spec='Mel', XI=1e-6, eps=2).to(dev), batch(), batch()
     yield 'UNet', ra.UNet((2, 2), (2, 2), log=True, reconstruction=True, mode='imagewise', spec='Mel', XI=1e-6, eps=2).to(dev), batch(), batch()
     yield 'OnsetsAndFrames', OnsetsAndFrames_VAT_full(229, 88, XI=1e-6, eps=1e-1).to(dev), batch(), batch()
+    # BASELINE config 2 at the script's own batch sizes (train_UNet_VAT.py:54,56): one labelled + eight unlabelled segments
+    yield 'UNet B_l=1', ra.UNet((2, 2), (2, 2), log=True, reconstruction=True, mode='imagewise', spec='Mel', XI=1e-6, eps=2).to(dev), batch(1), batch()
 
 
 def main():
@@ -86,7 +88,7 @@ def main():
     except OSError:
         git = ''
     meta = {'made_by': 'tools/tune_plans.py', 'rounds': args.rounds, 'device': torch.cuda.get_device_name(0), 'git': git,
-            'workloads': 'UNet_Onset, UNet (VAT + reconstruction), OnsetsAndFrames_VAT_full; B_l = B_ul = 8 x 327680 samples',
+            'workloads': 'UNet_Onset, UNet (VAT + reconstruction), OnsetsAndFrames_VAT_full at B_l = B_ul = 8 x 327680 samples; UNet at B_l = 1, B_ul = 8',
             'conv_key': 'mode,B,H,W,cin,cout,in_ld,out_ld,bn_stats,bn_bwd -> algo (rv_conv_fwd)',
             'wgrad_key': 'taps,B,Hv,Wv,Ca,Cb -> [waves per workgroup, workgroups] (rv_conv_wgrad_set_plan)',
             'gemm_key': 'M,N,K,batch,A k-fast,B k-fast,act,accumulate -> split-K factor (rv_gemm; slices folded in order)',
