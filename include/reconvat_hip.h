@@ -10,7 +10,9 @@
  *     every buffer; scratch is passed in as `workspace`, sized by the *_workspace_bytes queries);
  *   - returns 0 on success, <0 on error (-1 bad argument, -2 launch failure, -3 unsupported shape);
  *     `rv_last_error()` returns the text of the last error on the calling thread;
- *   - re-entrant per stream; no global mutable state.
+ *   - re-entrant per stream; the ONE piece of process-global mutable state is the weight-gradient plan table written by
+ *     rv_conv_wgrad_set_plan (configure it once per shape before the first launch of that shape: the shipped plan table does
+ *     exactly that; it is not synchronised against concurrent launches of the same shape).
  *
  * Activations are NHWC with an explicit pixel stride `*_ld` (floats between consecutive pixels), so a
  * tensor may be a channel slice of a wider buffer (the decoder's concat buffers).
