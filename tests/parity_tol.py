@@ -3,7 +3,7 @@
 tests/golden/lds_spread.npz (make_golden.py g_lds_spread) holds, for every VAT-carrying fixture, the reference's loss values at
 8 threads fp32 (the golden), 1 thread fp32 and fp64.  At XI = 1e-6 the power-iteration direction is rounding-noise driven, so
 these terms move by 3e-4 .. 5e-3 between those runs of the SAME reference code (non-VAT terms: < 1e-6).  A HIP loss term is
-accepted when |hip - reference| <= max(1e-3, 3 x spread) x |reference| (north_star's 1e-3, widened only where the reference
+accepted when |hip - reference| <= max(1e-3, 2 x spread) x |reference| (north_star's 1e-3, widened only where the reference
 itself is measurably noisier), and every measured error is appended to gpurun_out/parity_errors.jsonl for DESIGN.md section 4.
 """
 import json
@@ -40,7 +40,8 @@ def spread(case, key=None):
 def tol(case, key):
     if not is_vat_key(key):
         return 1e-3
-    return max(1e-3, 3.0 * spread(case, key))
+    # round 3: 2 x (was 3 x) -- every one of the 68 measured (case, key) errors of the final build is <= 1.75 x the case's spread
+    return max(1e-3, 2.0 * spread(case, key))
 
 
 def check(case, key, got, ref, where):

@@ -165,7 +165,7 @@ def test_bilstm_time_reversal_and_batch_permutation_full_size(dev, i):
 def test_fullsize_step_anchor_vs_reference(dev, kind):
     """The bench workload's schedule (two-stream hipGraph TrainStep, VAT + reconstruction) at full segment length (B = 2 segments
     of 327 680 samples -> 640 frames), against the REFERENCE's own losses and posteriorgrams on the same inputs, weights and
-    injected VAT noise (tests/golden/lds_spread.npz, cases <kind>_T640).  VAT terms: 3 x the reference's own spread on this
+    injected VAT noise (tests/golden/lds_spread.npz, cases <kind>_T640).  VAT terms: 2 x the reference's own spread on this
     case (1e-3 .. 3e-3); everything else 1e-3."""
     import os
     import numpy as np
@@ -213,7 +213,7 @@ def test_bench_batch_anchor_vs_reference(dev):
     """The BENCH workload itself -- B_l = B_ul = 8 segments of 327 680 samples, UNet_Onset VAT + reconstruction, two-stream hipGraph
     TrainStep, the shipped tile table at exactly the shapes it was tuned for -- against the REFERENCE's own eleven loss values and
     posteriorgram digests on the same closed-form inputs / weights / injected noise (tests/golden/anchor_b8.npz).  Non-VAT terms:
-    1e-3 (measured ~1e-7).  VAT terms: max(1e-3, 3 x the reference's own noise) with the noise estimate = the larger of this case's
+    1e-3 (measured ~1e-7).  VAT terms: max(1e-3, 2 x the reference's own noise) with the noise estimate = the larger of this case's
     8-thread vs 1-thread movement and the B = 2 anchor's 8-thread / 1-thread / fp64 movement (an fp64 run at B = 8 does not fit the
     build container)."""
     import os
@@ -255,7 +255,7 @@ def test_bench_batch_anchor_vs_reference(dev):
     report = {}
     for k, ref in zip(keys, g[case + '_f32_8t']):
         err = abs(float(step.losses[k]) - float(ref)) / max(abs(float(ref)), 1e-6)
-        tol = max(1e-3, 3.0 * noise_est) if parity_tol.is_vat_key(k) else 1e-3
+        tol = max(1e-3, 2.0 * noise_est) if parity_tol.is_vat_key(k) else 1e-3
         report[k.split('/')[-1]] = (err, tol)
         assert err <= tol, (k, float(step.losses[k]), float(ref), err, tol)
     print('B = 8 anchor, relative errors vs the reference:', {k: f'{e:.1e}' for k, (e, _) in report.items()})
@@ -305,7 +305,7 @@ def test_config2_batch_anchor_vs_reference(dev):
     report = {}
     for k, ref in zip(keys, g[case + '_f32_8t']):
         err = abs(float(step.losses[k]) - float(ref)) / max(abs(float(ref)), 1e-6)
-        tol = max(1e-3, 3.0 * noise_est) if parity_tol.is_vat_key(k) else 1e-3
+        tol = max(1e-3, 2.0 * noise_est) if parity_tol.is_vat_key(k) else 1e-3
         report[k.split('/')[-1]] = err
         assert err <= tol, (k, float(step.losses[k]), float(ref), err, tol)
     print('config 2 anchor (B_l = 1, B_ul = 8), relative errors vs the reference:', {k: f'{e:.1e}' for k, e in report.items()})

@@ -129,8 +129,8 @@ def test_vat_injected_noise(dev, kind):
     sp = np.load(os.path.join(G, 'lds_spread.npz'))
     assert np.allclose(sp[f'vat_{kind}_f32_8t'], g[f'{kind}_real_lds'], rtol=1e-6)      # same reference run
     for v, ref, s in zip(vals, g[f'{kind}_real_lds'], sp[f'vat_{kind}_spread']):
-        # |hip - reference| within 3 x the reference's own 1-thread / fp64 spread on this input (tests/parity_tol.py)
-        assert abs(v - ref) <= max(1e-3, 3 * float(s)) * ref, (v, ref, float(s))
+        # |hip - reference| within 2 x the reference's own 1-thread / fp64 spread on this input (tests/parity_tol.py)
+        assert abs(v - ref) <= max(1e-3, 2 * float(s)) * ref, (v, ref, float(s))
     rn = r_adv.norm(dim=-1)
     assert torch.allclose(rn, torch.full_like(rn, 2.0), rtol=1e-5)
     # the power-iteration pass must not leave gradients on the weights (reference: model.zero_grad())
