@@ -264,6 +264,9 @@ class TrainStep:
         # opt-in experiment (BASELINE config 3): bf16 operands on the matrix pipe for the BACKWARD 3x3 convs of the final graphs; every
         # forward pass and the whole power iteration stay fp32, so all loss terms / posteriorgrams are unchanged (ops.BF16)
         self.bf16_backward = bool(bf16_backward)
+        if self.bf16_backward and os.environ.get('RV_BF16_LOG'):
+            import sys
+            print('[bf16] backward convs of the final graphs use bf16 operands', file=sys.stderr)
         self.dual_stream = dual_stream        # the two VAT chains on two HIP streams (model._vat_two_streams)
         self._dual_ready = False              # ... from the second step on: the first one packs weights and autotunes
         if getattr(model, 'has_recurrence', False):

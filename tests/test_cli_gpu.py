@@ -158,10 +158,16 @@ def test_bf16_backward_and_tuning_modes_from_the_command_line(dev, tmp_path):
     """`dtype=bf16` (opt-in experiment: bf16-operand backward convs, forward fp32) trains through the script; RV_AUTOTUNE=0 (library
     default tiles) and RV_AUTOTUNE=1 (on-line tuner) run the same command line as the default plan-table mode."""
     logdir = str(tmp_path / 'bf16')
-    p = run('train_UNet_Onset_VAT.py', *SMALL, 'reconstruction=True', 'epoches=1', 'saving_freq=1', 'dtype=bf16', f'logdir={logdir}')
-    assert 'Training finished.' in p.stdout
+    env = dict(os.environ, PYTHONPATH=ROOT, RV_BF16_LOG='1')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'train_UNet_Onset_VAT.py'), 'with', *SMALL, 'reconstruction=True', 'epoches=3',
+                        'saving_freq=1', 'logging_freq=2', 'dtype=bf16', f'logdir={logdir}'], capture_output=True, text=True, cwd=ROOT,
+                       env=env, timeout=900)
+    assert p.returncode == 0 and 'Training finished.' in p.stdout, p.stderr[-2000:]
+    assert '[bf16] backward convs of the final graphs use bf16 operands' in p.stderr          # the option reached TrainStep
     rows = scalar_tags(logdir)
     assert any(r['tag'] == 'loss/train_frame' for r in rows)
+    # logging_freq=2 reached the loop: validation scalars after epochs 1 and 2, not after 3
+    assert {r['step'] for r in rows if r['tag'] == 'metric/frame/f1'} == {1, 2}
     for mode in ('0', '1'):
         env = dict(os.environ, PYTHONPATH=ROOT, RV_AUTOTUNE=mode)
         q = subprocess.run([sys.executable, os.path.join(ROOT, 'train_UNet_VAT.py'), 'with', *SMALL, 'VAT=True', 'reconstruction=False',

@@ -17,5 +17,5 @@ def config(overrides):
 def train(spec, resume_iteration, train_on, batch_size, sequence_length, small, supersmall, train_batch_size, learning_rate,
           learning_rate_decay_steps, learning_rate_decay_rate, alpha, clip_gradient_norm, validation_length, refresh, device,
           epoches, logdir, log, iteration, VAT_start, VAT, XI, eps, reconstruction, graph, fused_optimizer, saving_freq,
-          device_feed):
+          device_feed, logging_freq, dtype):
     return run_training(True, **locals())
