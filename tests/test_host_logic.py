@@ -244,3 +244,20 @@ def test_flat_adam_two_ranks_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_every_run_training_option_is_injected_by_the_scripts():
+    """sacred injects config entries into the main function BY PARAMETER NAME: an option of cli.run_training that a script's `train(...)`
+    does not list silently falls back to its default (round 3: `dtype` and `logging_freq` did)."""
+    import importlib.util
+    import inspect
+    from reconvat_amd import cli
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    options = set(inspect.signature(cli.run_training).parameters) - {'onset_script', '_unused'}
+    for script in ('train_UNet_Onset_VAT.py', 'train_UNet_VAT.py', 'train_baseline_onset_frame_VAT.py'):
+        spec = importlib.util.spec_from_file_location('script_' + script[:-3], os.path.join(root, script))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)                    # (automain only runs under __main__)
+        injected, cfg = set(inspect.signature(mod.train).parameters), set(mod.config({}))
+        assert not (options & cfg) - injected, (script, sorted((options & cfg) - injected))
+        assert not injected - cfg, (script, sorted(injected - cfg))
