@@ -176,6 +176,21 @@ def test_bf16_backward_and_tuning_modes_from_the_command_line(dev, tmp_path):
         assert q.returncode == 0 and 'Training finished.' in q.stdout, q.stderr[-2000:]
 
 
+def test_baseline_script_end_to_end(dev, tmp_path):
+    """`train_baseline_onset_frame_VAT.py with ... VAT=True` (Onsets&Frames BiLSTM baseline, train_baseline_onset_frame_VAT.py:25-170 of
+    the reference): two epochs through the three-chain captured step, checkpoint with the reference's state_dict keys, the
+    evaluation contract at the end."""
+    logdir = str(tmp_path / 'onf')
+    p = run('train_baseline_onset_frame_VAT.py', *SMALL, 'VAT=True', 'epoches=2', 'saving_freq=1', f'logdir={logdir}')
+    assert 'Training finished.' in p.stdout and 'Train Epoch: 2' in p.stdout
+    sd = torch.load(os.path.join(logdir, 'model-2.pt'), map_location='cpu')
+    assert 'combined_stack.1.weight' in sd or any(k.startswith('combined_stack') for k in sd), list(sd)[:8]
+    assert any(k.startswith('onset_stack') for k in sd) and any(k.startswith('frame_stack') for k in sd)
+    rows = scalar_tags(logdir)
+    assert any(r['tag'].startswith('loss/train_') for r in rows)
+    _check_evaluation_contract(logdir, rows, n_songs=4, first_epoch_logged=False)
+
+
 def test_eager_torch_optimizer_path(dev, tmp_path):
     """graph=False fused_optimizer=False: the reference loop verbatim (train_VAT_model + torch.optim.Adam + StepLR)."""
     logdir = str(tmp_path / 'eager')
