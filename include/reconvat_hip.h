@@ -40,13 +40,16 @@ int rv_melspec_lognorm_fwd(const float* audio, long audio_stride, int B, int nsa
 /* ---- convolutions (nn.Conv2d / nn.ConvTranspose2d call sites, model/UNet_onset.py:173-224) ------
  * rv_pack_weights: PyTorch-layout weight -> MFMA fragment order for a logical Wm[tap][k][n]
  *   value(tap,k,n) = w[k*s_k + n*s_n + (flip ? taps-1-tap : tap)];  scatter_cmid>0: 2x2/s2 scatter GEMM.
+ *   3x3 weights with kdim % 16 == 0 also carry their Winograd F(2x2,3x3) transform U = G g G^T (16 fragments per chunk and
+ *   n-tile) behind the nine tap fragments; rv_packed_weight_floats counts both.
  * rv_conv_fwd mode: 0 = 3x3 s1 p1, 1 = 1x1, 2 = 2x2/s2 gather (down fwd, up dgrad), 3 = 2x2/s2 scatter
  *   (ConvTranspose2d(k=2,s=2)(x, output_size=...) fwd, down dgrad).  Forward AND input-gradient of
  *   every layer are instances of it (the packing decides which).  algo: 0 default, 1 LDS-free direct kernel,
  *   2 LDS/DMA-pipelined kernel (3x3 only); forced tiles for the host autotuner (ops._conv_call), RV_EUNSUPPORTED when the tile
  *   does not fit the shape: 0x100|NT<<4|MT direct kernel, 0x200 / 0x300 / 0x400 / 0x700 |NT<<4|MTW LDS kernel with 4 / 8 / 16 /
  *   12 waves per workgroup (MTW in {3,5,6} for 12 waves: 9/15/18 tiles per SIMD and band), optionally TH<<12 = rows per band
- *   (<= what the tile slots hold).  bn_sums (nullable,
+ *   (<= what the tile slots hold); 0x600 / 0x900 |NT<<4|MTW: Winograd F(2x2,3x3) form of the persistent 3x3 kernel with 8 / 4
+ *   waves per workgroup (Cin % 16 == 0; TH<<12 = even rows per band), same epilogue fusions.  bn_sums (nullable,
  *   rv_bn_workspace_bytes(Cout) bytes of fp64 = 8 replicas of [2*Cout] that the consumer adds up, += ): per-channel sum / sum of squares of the written output, i.e. the batch statistics of the
  *   BatchNorm2d that consumes it (conv -> bn call sites, model/UNet_onset.py:196-198,221-223), produced in the conv
  *   epilogue; pass the same buffer to rv_bn_lrelu_fwd as `workspace` with sums_ready = 1.  bn_z (nullable; with

@@ -38,9 +38,38 @@ struct PackArgs {
     int flip;                 // spatial flip of the tap index
     int scatter_cmid;         // >0: n = tap4*cmid + c, taps==1, source = k*s_k + c*s_n + tap4
     long total;
+    long wino0;               // >0: elements [wino0, total) are the Winograd F(2x2,3x3) section U = G g G^T (16 "taps", same fragment order)
 };
 
+// U[xi = 4a + b][k][n] = sum_{ky,kx} G[a][ky] G[b][kx] g[ky][kx][k][n],  G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]
+__device__ __forceinline__ void pack_wino_elem(const PackArgs& a, long idx) {
+    const int R = a.R;
+    int r = (int)(idx % R);
+    long t = idx / R;
+    int lane = (int)(t % 64); t /= 64;
+    int nt = (int)(t % a.ntile_n); t /= a.ntile_n;
+    int c = (int)(t % a.nchunk);
+    int xi = (int)(t / a.nchunk);
+    int k = c * 4 * R + (lane >> 4) * R + r;
+    int n = nt * 16 + (lane & 15);
+    float v = 0.f;
+    if (k < a.kdim && n < a.ndim) {
+        const float* w = a.w + (long)k * a.s_k + (long)n * a.s_n;
+        const int ra = xi >> 2, cb = xi & 3;
+        float col[3];                                    // (g G^T)[ky][cb]
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            float g0 = w[a.flip ? 8 - (ky * 3 + 0) : ky * 3 + 0], g1 = w[a.flip ? 8 - (ky * 3 + 1) : ky * 3 + 1],
+                  g2 = w[a.flip ? 8 - (ky * 3 + 2) : ky * 3 + 2];
+            col[ky] = cb == 0 ? g0 : (cb == 1 ? 0.5f * (g0 + g1 + g2) : (cb == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+        }
+        v = ra == 0 ? col[0] : (ra == 1 ? 0.5f * (col[0] + col[1] + col[2]) : (ra == 2 ? 0.5f * (col[0] - col[1] + col[2]) : col[2]));
+    }
+    a.out[a.wino0 + idx] = v;
+}
+
 __device__ __forceinline__ void pack_frag_elem(const PackArgs& a, long idx) {
+    if (a.wino0 > 0 && idx >= a.wino0) { pack_wino_elem(a, idx - a.wino0); return; }
     const int R = a.R;
     int r = (int)(idx % R);
     long t = idx / R;
@@ -573,6 +602,15 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
         if (!(ABL(aa) & 4))
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
+#ifdef RV_ABLATION
+            if ((ABL(aa) & 256) && tap >= 4) break;          // Winograd F(2x2,3x3) cost probe: 4 MFMA groups per pixel tile ...
+            if (ABL(aa) & 512) {                             // ... plus its input-transform adds (8 per fragment and group)
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) asm volatile("v_add_f32 %0, %0, %1" : "+v"(xf[tap & 1][m][q % R]) : "v"(xf[tap & 1][m][(q + 1) % R]));
+            }
+#endif
             if (tap + 1 < 9) {
                 if (!(ABL(aa) & 16)) ldtap((tap + 1) & 1, tap + 1);
                 asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NT + MTW) : "memory");   // tap's own fragments have landed
@@ -685,6 +723,346 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
                 st1[n][r] = u; st2[n][r] = q;
             }
         __syncthreads();                                   // every wave is done with the unit buffers
+        float* red = smem;                                 // [NW][NT*16][2]
+        if (j == 0) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    red[((wave * NT + n) * 16 + 4 * g + r) * 2] = st1[n][r];
+                    red[((wave * NT + n) * 16 + 4 * g + r) * 2 + 1] = st2[n][r];
+                }
+        }
+        __syncthreads();
+        for (int t = tid; t < NT * 16 * 2; t += NTHR) {
+            const int cl = t >> 1, which = t & 1, ch = nt0 * 16 + cl;
+            double dsum = 0.0;
+            for (int w = 0; w < NW; ++w) dsum += (double)red[((w * NT) * 16 + cl) * 2 + which];
+            if (ch < a.Cout) atomicAdd(&a.bn_sums[(blockIdx.x % RV_BN_NREP) * 2 * a.Cout + which * a.Cout + ch], dsum);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) form of the persistent 3x3 kernel (algo family 0x6NM / 0x9NM; 16-channel chunks only).
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A    per 4x4 input patch d (stride 2) and 2x2 output tile Y
+//
+// 16 element-wise products per tile and (cin, cout) pair instead of 36: the matrix pipe does 2.25x fewer MFMAs.  The "pixel"
+// dimension of the MFMA is a run of 16 TILES of the band (flattened (tile row, tile column) index, as the direct kernel flattens
+// pixels); lane (j, g) reads the 4x4 patch of tile j for channels 4g..4g+3 of the chunk straight from the staged band (16
+// ds_read_b128), transforms it in registers (32 adds per channel) and feeds V[xi] to the 16 x NT x 4 MFMAs of the chunk; the
+// transformed weights U[xi] = G g G^T come pre-packed (rv_pack_weights appends them behind the nine tap fragments).  The
+// accumulators hold M[xi] for xi = 0..15; the band epilogue applies A^T . A in registers and shares bias / statistics / fused
+// BatchNorm-backward / store logic with the direct form.  Unit staging (LDS-DMA, two buffers) is the direct kernel's, with the
+// band padded to an even width.
+// ------------------------------------------------------------------------------------------
+template <int NT, int MTW, int NW>
+__global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
+    constexpr int NTHR = NW * 64;
+    constexpr int KC = 16;                       // channels per chunk
+    constexpr int WFLOATS = 16 * NT * 256;       // 16 xi x NT fragments x 64 lanes x 4 floats
+    const ConvArgs& a = aa.c;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int W = a.W, H = a.H, WT = (W + 1) >> 1, W2 = 2 * WT + 2, TH = aa.TH;
+    const int nrow = TH + 2;
+    const int xfloats = nrow * W2 * KC;
+    const int vid = aa.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int grp = vid / aa.nsplit, split = vid - grp * aa.nsplit;
+    const int nt0 = split * NT;
+    float* xs0 = smem;                                   // [2][nrow][W2][KC]
+    float* ws0 = smem + 2 * xfloats;                     // [2 (1 if one chunk)][16][NT][64][4]
+    const int band_lo = grp * aa.bands_per_wg;
+    const int band_hi = min(band_lo + aa.bands_per_wg, aa.total_bands);
+    if (band_lo >= band_hi) return;
+    const int nchunk = a.nchunk;
+    const int nunits = (band_hi - band_lo) * nchunk;
+    const int ipr = (W + 15) >> 4;                       // DMA instructions per input row (16 pixels x 64 bytes each)
+
+    // ---- staging plan (see conv3x3_lds_k) ----
+    constexpr int TXF = 4;
+    constexpr int NWF = 16 * NT;                         // weight DMA instructions per unit: one fragment each
+    constexpr int TW = (NWF + NW - 1) / NW;
+    const int nx = nrow * ipr;
+    int xs_row[TXF], xs_ldst[TXF];
+    unsigned xs_goff[TXF];
+    bool xs_lane[TXF];
+#pragma unroll
+    for (int t = 0; t < TXF; ++t) {
+        const int i = wave + NW * t;
+        const int row = i / ipr, k = i - row * ipr;
+        const int px = k * 16 + (lane >> 2), q = lane & 3;
+        xs_row[t] = row;
+        xs_ldst[t] = (row * W2 + 1 + k * 16) * KC;
+        xs_goff[t] = (unsigned)((row * W + px) * a.in_ld + q * 4) * 4u;
+        xs_lane[t] = i < nx && px < W;
+    }
+    unsigned w_off[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        const int f = wave + NW * t;                     // fragment = xi * NT + n
+        const int xi = f / NT, n = f - xi * NT;
+        w_off[t] = (unsigned)(((xi * nchunk * a.ntile_n) + nt0 + n) * 256 + lane * 4) * 4u;
+    }
+    const float* wino = a.wpack + (long)9 * nchunk * a.ntile_n * 256;      // the Winograd section of the packed weights
+    const int b_first = band_lo / aa.nbands, y_first = (band_lo - b_first * aa.nbands) * TH;
+    int sg_u = 0, sg_buf = 0, sg_b = b_first, sg_y0 = y_first, sg_c = 0;
+
+    auto stage = [&]() -> int {
+        int issued = 0;
+        float* xb = xs0 + sg_buf * xfloats;
+        const char* src = reinterpret_cast<const char*>(a.in + ((long)(sg_b * H + sg_y0 - 1) * W) * a.in_ld + sg_c * KC);
+#pragma unroll
+        for (int t = 0; t < TXF; ++t) {
+            if (wave + NW * t >= nx) break;
+            const int gy = sg_y0 - 1 + xs_row[t];
+            float* ldst = xb + xs_ldst[t];
+            if (gy >= 0 && gy < H) {
+                if (xs_lane[t]) glds16(reinterpret_cast<const float*>(src + xs_goff[t]), ldst);
+                ++issued;
+            } else if (xs_lane[t]) {
+                *reinterpret_cast<f32x4*>(ldst + lane * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        for (int i = wave + NW * TXF; i < nx; i += NW) {
+            const int row = i / ipr, k = i - row * ipr;
+            const int gy = sg_y0 - 1 + row;
+            const int px = k * 16 + (lane >> 2), q = lane & 3;
+            float* ldst = xb + (row * W2 + 1 + k * 16) * KC;
+            if (gy >= 0 && gy < H) {
+                if (px < W) glds16(reinterpret_cast<const float*>(src) + ((long)row * W + px) * a.in_ld + q * 4, ldst);
+                ++issued;
+            } else if (px < W) {
+                *reinterpret_cast<f32x4*>(ldst + lane * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (nchunk > 1 || sg_u == 0) {
+            float* wb = ws0 + ((nchunk > 1) ? sg_buf : 0) * WFLOATS;
+            const char* wsrc = reinterpret_cast<const char*>(wino + (long)sg_c * a.ntile_n * 256);
+#pragma unroll
+            for (int t = 0; t < TW; ++t) {
+                if (wave + NW * t >= NWF) break;
+                glds16(reinterpret_cast<const float*>(wsrc + w_off[t]), wb + (wave + NW * t) * 256);
+                ++issued;
+            }
+        }
+        ++sg_u;
+        sg_buf ^= 1;
+        if (++sg_c == nchunk) {
+            sg_c = 0;
+            sg_y0 += TH;
+            if (sg_y0 >= H) { sg_y0 = 0; ++sg_b; }
+        }
+        return issued;
+    };
+
+    // halo columns (left: 1, right: W2 - 1 - W) of both buffers are zero for the whole kernel (the DMA never touches them)
+    {
+        const int nz = W2 - W;                           // column 0 and columns W+1 .. W2-1
+        for (int k = tid; k < 2 * nrow * nz * KC; k += NTHR) {
+            const int ch = k % KC; int t = k / KC;
+            const int zc = t % nz; t /= nz;
+            const int row = t % nrow, buf = t / nrow;
+            const int col = zc == 0 ? 0 : W + zc;
+            xs0[buf * xfloats + (row * W2 + col) * KC + ch] = 0.f;
+        }
+    }
+
+    f32x4 acc[MTW][NT][16];
+    int lbase[MTW], tyx[MTW];
+    bool tv[MTW];
+    f32x4 bv[NT];
+    __shared__ __attribute__((aligned(16))) float cf[4 * 64];
+    if (a.bn_z) {
+        for (int idx = tid; idx < 4 * NT * 16; idx += NTHR) {
+            const int k = idx / (NT * 16), cl = idx - k * (NT * 16), ch = nt0 * 16 + cl;
+            cf[k * 64 + cl] = ch < a.Cout ? a.bn_coef[k * a.Cout + ch] : 0.f;
+        }
+    }
+    f32x4 st1[NT], st2[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) st1[n] = st2[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int cb = (nt0 + n) * 16 + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[n][r] = (a.bias && cb + r < a.Cout) ? a.bias[cb + r] : 0.f;
+    }
+    stage();
+    int ahead = 0;
+    int cu_buf = 0, cu_b = b_first, cu_y0 = y_first, cu_c = 0;
+    for (int u = 0; u < nunits; ++u) {
+        const int b = cu_b, y0 = cu_y0, c = cu_c, buf = cu_buf;
+        cu_buf ^= 1;
+        if (++cu_c == nchunk) {
+            cu_c = 0;
+            cu_y0 += TH;
+            if (cu_y0 >= H) { cu_y0 = 0; ++cu_b; }
+        }
+        const int th = min(TH, H - y0);
+        const int ntiles = ((th + 1) >> 1) * WT;
+        if (c == 0) {
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int t = (wave + NW * m) * 16 + j;
+                tv[m] = t < ntiles;
+                const unsigned tt = tv[m] ? (unsigned)t : 0u;
+                const int ty = (int)fastdiv(tt, a.fd_pw), tx = (int)tt - ty * WT;       // fd_pw divides by WT here
+                tyx[m] = (ty << 16) | tx;
+                lbase[m] = ((2 * ty) * W2 + 2 * tx) * KC + g * 4;
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int xi = 0; xi < 16; ++xi) acc[m][n][xi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        wait_vmcnt_le(ahead);
+        if (!(ABL(aa) & 1)) __syncthreads();
+        if (!(ABL(aa) & 2)) ahead = (sg_u < nunits) ? stage() : 0;
+        const float* xs = xs0 + buf * xfloats;
+        const float* ws = ws0 + ((nchunk > 1) ? buf : 0) * WFLOATS;
+        const unsigned ws_a = lds_addr(ws) + lane * 16;
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            if ((wave + NW * m) * 16 >= ntiles) continue;                   // wave-uniform: this tile group is beyond the band
+            f32x4 d[16];
+            f32x4 wf[2][NT];
+            const unsigned xa = lds_addr(xs) + lbase[m] * 4;
+            if (ABL(aa) & 16) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) d[e] = (f32x4){1.f + e, 2.f, 3.f, 4.f};
+            } else
+#pragma unroll
+            for (int e = 0; e < 16; ++e) lds_read(d[e], xa + ((e >> 2) * W2 + (e & 3)) * (KC * 4));
+#pragma unroll
+            for (int n = 0; n < NT; ++n) lds_read(wf[0][n], ws_a + n * 1024);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            // V = B^T d B, in place: rows then columns
+            if (!(ABL(aa) & 16))
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const f32x4 d0 = d[cc], d1 = d[4 + cc], d2 = d[8 + cc], d3 = d[12 + cc];
+                d[cc] = d0 - d2; d[4 + cc] = d1 + d2; d[8 + cc] = d2 - d1; d[12 + cc] = d1 - d3;
+            }
+            if (!(ABL(aa) & 16))
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const f32x4 d0 = d[4 * rr], d1 = d[4 * rr + 1], d2 = d[4 * rr + 2], d3 = d[4 * rr + 3];
+                d[4 * rr] = d0 - d2; d[4 * rr + 1] = d1 + d2; d[4 * rr + 2] = d2 - d1; d[4 * rr + 3] = d1 - d3;
+            }
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) {
+                if (xi + 1 < 16) {
+                    if (!(ABL(aa) & 32))
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) lds_read(wf[(xi + 1) & 1][n], ws_a + ((xi + 1) * NT + n) * 1024);
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NT) : "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(ABL(aa) & 4))
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[xi & 1][n][r], d[xi][r], acc[m][n][xi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (c != nchunk - 1 || (ABL(aa) & 8)) continue;
+        // ---- epilogue of this band: Y = A^T M A, then bias / statistics / store per output pixel ----
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            if (!tv[m]) continue;
+            const int ty = tyx[m] >> 16, tx = tyx[m] & 0xffff;
+            const int oy = 2 * ty, ox = 2 * tx;
+            const long pix00 = ((long)b * H + y0 + oy) * W + ox;
+            const bool vy1 = oy + 1 < th, vx1 = ox + 1 < W;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int co0 = (nt0 + n) * 16 + 4 * g;
+                if (co0 >= a.Cout) continue;
+                f32x4 y[4];
+                {
+                    f32x4 s0[4], s1[4];
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb) {
+                        s0[bb] = acc[m][n][bb] + acc[m][n][4 + bb] + acc[m][n][8 + bb];
+                        s1[bb] = acc[m][n][4 + bb] - acc[m][n][8 + bb] - acc[m][n][12 + bb];
+                    }
+                    y[0] = s0[0] + s0[1] + s0[2] + bv[n]; y[1] = s0[1] - s0[2] - s0[3] + bv[n];
+                    y[2] = s1[0] + s1[1] + s1[2] + bv[n]; y[3] = s1[1] - s1[2] - s1[3] + bv[n];
+                }
+                f32x4 z4[4];
+                if (a.bn_z) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        z4[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (((p >> 1) && !vy1) || ((p & 1) && !vx1)) continue;
+                        const float* zp = a.bn_z + (pix00 + (p >> 1) * W + (p & 1)) * a.bn_z_ld + co0;
+                        if ((a.bn_z_ld & 3) == 0 && co0 + 3 < a.Cout) z4[p] = *reinterpret_cast<const f32x4*>(zp);
+                        else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (co0 + r < a.Cout) z4[p][r] = zp[r];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    if (((p >> 1) && !vy1) || ((p & 1) && !vx1)) continue;
+                    float* o = a.out + (pix00 + (p >> 1) * W + (p & 1)) * a.out_ld + co0;
+                    f32x4 v = y[p];
+                    if (a.vec_store && co0 + 3 < a.Cout) {
+                        if (a.accumulate) { f32x4 old = *reinterpret_cast<f32x4*>(o); v += old; }
+                        *reinterpret_cast<f32x4*>(o) = v;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (co0 + r < a.Cout) {
+                                if (a.accumulate) v[r] += o[r];
+                                o[r] = v[r];
+                            }
+                    }
+                    if (a.bn_z) {
+                        const f32x4 mean4 = *reinterpret_cast<const f32x4*>(&cf[0 * 64 + n * 16 + 4 * g]);
+                        const f32x4 inv4 = *reinterpret_cast<const f32x4*>(&cf[1 * 64 + n * 16 + 4 * g]);
+                        const f32x4 sc4 = *reinterpret_cast<const f32x4*>(&cf[2 * 64 + n * 16 + 4 * g]);
+                        const f32x4 sh4 = *reinterpret_cast<const f32x4*>(&cf[3 * 64 + n * 16 + 4 * g]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float zh = fmaf(z4[p][r], sc4[r], sh4[r]);
+                            const float dd = zh > 0.f ? v[r] : v[r] * a.bn_slope;
+                            st1[n][r] += dd;
+                            st2[n][r] = fmaf(dd, (z4[p][r] - mean4[r]) * inv4[r], st2[n][r]);
+                        }
+                    } else {
+                        st1[n] += v;
+                        st2[n] += v * v;
+                    }
+                }
+            }
+        }
+    }
+    if (a.bn_sums) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float u = st1[n][r], q = st2[n][r];
+#pragma unroll
+                for (int dd = 1; dd < 16; dd <<= 1) {
+                    u += __shfl_xor(u, dd, 64);
+                    q += __shfl_xor(q, dd, 64);
+                }
+                st1[n][r] = u; st2[n][r] = q;
+            }
+        __syncthreads();
         float* red = smem;                                 // [NW][NT*16][2]
         if (j == 0) {
 #pragma unroll
@@ -1987,7 +2365,67 @@ static int launch_conv3x3_lds(const ConvArgs& a, int R, hipStream_t st, int forc
                   : launch_conv3x3_lds_r<2, 4>(a, best_nt, best_mt, best_th, best_wpc, st);
 }
 
+// Winograd launch (families 0x6NM: 8 waves, 0x9NM: 4 waves): a band of TH (even) rows holds (TH/2) x ceil(W/2) tiles of 2x2 outputs,
+// NW x MTW groups of 16 tiles per unit.  force_th = 0: as many rows as the tile slots hold.
+static size_t conv3x3_wino_bytes(int NT, int TH, int W, int nchunk) {
+    const int W2 = 2 * ((W + 1) / 2) + 2;
+    return ((size_t)2 * (TH + 2) * W2 * 16 + (size_t)(nchunk > 1 ? 2 : 1) * 16 * NT * 256) * sizeof(float);
+}
+
+template <int NW>
+static int launch_conv3x3_wino(const ConvArgs& a0, int NT, int MTW, int force_th, hipStream_t st) {
+    if (NT < 1 || a0.ntile_n % NT) return RV_EUNSUPPORTED;
+    ConvLdsArgs aa;
+    aa.c = a0;
+    const int WT = (a0.W + 1) / 2;
+    aa.c.fd_pw = fastdiv_make((unsigned)WT);
+    int trows = (NW * MTW * 16) / WT;
+    if (trows < 1) return RV_EUNSUPPORTED;
+    int TH = 2 * trows;
+    if (TH > a0.H) TH = (a0.H + 1) & ~1;
+    if (force_th) {
+        if (force_th > TH || (force_th & 1)) return RV_EUNSUPPORTED;
+        TH = force_th;
+    }
+    const size_t lds = conv3x3_wino_bytes(NT, TH, a0.W, a0.nchunk);
+    if (lds > 154 * 1024) return RV_EUNSUPPORTED;
+    aa.TH = TH; aa.nbands = cdiv(a0.H, TH);
+    aa.total_bands = a0.B * aa.nbands;
+    const int nsplit = a0.ntile_n / NT;
+    int wgs = 256 / nsplit;
+    if (wgs < 1) wgs = 1;
+    if (wgs > aa.total_bands) wgs = aa.total_bands;
+    aa.bands_per_wg = cdiv(aa.total_bands, wgs);
+    wgs = cdiv(aa.total_bands, aa.bands_per_wg);
+    aa.nbuf = 2; aa.skew = 0;
+    aa.ablate = getenv("RV_ABLATE") ? atoi(getenv("RV_ABLATE")) : 0;
+    static const int xcd_env = getenv("RV_CONV_XCD") ? atoi(getenv("RV_CONV_XCD")) : 1;
+    aa.nsplit = nsplit; aa.xcd = xcd_env;
+    dim3 grid(wgs * nsplit), blk(NW * 64);
+#define RV_WN(nt, mt)                                                                              \
+    if (NT == nt && MTW == mt) {                                                                  \
+        auto kern = conv3x3_wino_k<nt, mt, NW>;                                                   \
+        static bool attr_done = false;                                                            \
+        if (!attr_done) {                                                                         \
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) \
+                (void)hipGetLastError();                                                          \
+            attr_done = true;                                                                     \
+        }                                                                                         \
+        hipLaunchKernelGGL(kern, grid, blk, lds, st, aa);                                         \
+        return RV_OK;                                                                             \
+    }
+    if constexpr (NW == 8) {
+        RV_WN(1, 1) RV_WN(2, 1) RV_WN(1, 2)
+    } else {
+        RV_WN(1, 1) RV_WN(2, 1) RV_WN(1, 2)
+    }
+#undef RV_WN
+    return RV_EUNSUPPORTED;
+}
+
 static int frag_R(int kdim) { return (kdim % 16 == 0) ? 4 : ((kdim % 8 == 0) ? 2 : 0); }
+// 3x3 weights with 16-channel chunks carry their Winograd transform behind the nine tap fragments (conv3x3_wino_k)
+static bool wino_packed(int taps, int kdim) { return taps == 9 && kdim % 16 == 0; }
 
 // ---- profiling aid: raw f32 MFMA issue rate (NACC independent accumulators per wave) -------------------------
 template <int NACC>
@@ -2026,7 +2464,7 @@ long rv_packed_weight_floats(int taps, int kdim, int ndim) {
     int R = frag_R(kdim);
     if (R == 0) return (long)taps * kdim * ndim;   // plain layout (small-channel kernels)
     int nchunk = kdim / (4 * R), ntile_n = (ndim + 15) / 16;
-    return (long)taps * nchunk * ntile_n * 64 * R;
+    return (long)(taps + (wino_packed(taps, kdim) ? 16 : 0)) * nchunk * ntile_n * 64 * R;
 }
 
 // Pack a PyTorch-layout weight into MFMA fragment order (or plain [tap][k][n] when the layer runs on
@@ -2036,7 +2474,7 @@ long rv_packed_weight_floats(int taps, int kdim, int ndim) {
 static int pack_args_make(PackArgs& a, const float* w, float* out, int taps, int kdim, int ndim, long s_k, long s_n,
                           int flip, int scatter_cmid, int force_plain) {
     a.w = w; a.out = out; a.taps = taps; a.kdim = kdim; a.ndim = ndim;
-    a.s_k = s_k; a.s_n = s_n; a.flip = flip; a.scatter_cmid = scatter_cmid;
+    a.s_k = s_k; a.s_n = s_n; a.flip = flip; a.scatter_cmid = scatter_cmid; a.wino0 = 0;
     const int R = force_plain ? 0 : frag_R(kdim);
     if (R == 0) {
         RV_CHECK_ARG(scatter_cmid == 0, "rv_pack_weights: plain layout has no scatter form");
@@ -2045,6 +2483,10 @@ static int pack_args_make(PackArgs& a, const float* w, float* out, int taps, int
     } else {
         a.R = R; a.nchunk = kdim / (4 * R); a.ntile_n = (ndim + 15) / 16;
         a.total = (long)taps * a.nchunk * a.ntile_n * 64 * R;
+        if (wino_packed(taps, kdim) && scatter_cmid == 0) {
+            a.wino0 = a.total;
+            a.total += (long)16 * a.nchunk * a.ntile_n * 64 * R;
+        }
     }
     return RV_OK;
 }
@@ -2213,6 +2655,14 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
     const bool bf = ((algo >> 20) & 1) && mode == 0 && R == 4;
     algo &= ~(1 << 20);
     const int fam = (algo >> 8) & 15, f_nt = (algo >> 4) & 15, f_mt = algo & 15, f_th = (algo >> 12) & 255;
+    if (fam == 6 || fam == 9) {                // Winograd F(2x2,3x3): 0x6NM = 8 waves, 0x9NM = 4 waves per workgroup
+        if (mode != 0 || R != 4) { rv_set_error("rv_conv_fwd: the Winograd kernel needs a 3x3 conv with Cin %% 16 == 0"); return RV_EUNSUPPORTED; }
+        const int rcw = fam == 6 ? launch_conv3x3_wino<8>(a, f_nt, f_mt, f_th, st) : launch_conv3x3_wino<4>(a, f_nt, f_mt, f_th, st);
+        if (rcw != RV_OK) { rv_set_error("rv_conv_fwd: forced Winograd tile NT=%d MTW=%d TH=%d does not fit", f_nt, f_mt, f_th); return rcw; }
+        RV_LAUNCH_CHECK("rv_conv_fwd(winograd)");
+        *sums_done = true;
+        return RV_OK;
+    }
     if (mode == 0 && algo != 1 && fam != 1) {
         const bool forced = (fam >= 2 && fam <= 4) || fam == 7;
         int rc3 = forced ? launch_conv3x3_lds(a, R, st, f_nt, f_mt, fam == 7 ? 12 : (fam == 4 ? 16 : (fam == 3 ? 8 : 4)), f_th, bf)

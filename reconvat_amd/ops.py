@@ -426,6 +426,16 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
                             if 0 < th < th_max and th < 256:
                                 extra.append(th << 12 | cand)
                     cands += sorted(set(extra))
+                    if cin % 16 == 0 and os.environ.get('RV_TUNE_WINOGRAD', '1') != '0':
+                        # Winograd F(2x2,3x3) form (0x6NM: 8 waves, 0x9NM: 4 waves per workgroup; bands of an even number of rows)
+                        wt_ = (wd + 1) // 2
+                        for fam, nwv in ((6, 8), (9, 4)):
+                            for nt, mt in ((1, 1), (2, 1), (1, 2)):
+                                if ntile_n % nt:
+                                    continue
+                                th_max = min(h, 2 * ((nwv * mt * 16) // wt_))
+                                ths = [0] + [t for t in range(2, th_max, 2) if -(-h // t) != -(-h // (t + 2))]
+                                cands += [t << 12 | fam << 8 | nt << 4 | mt for t in ths]
                     fams = os.environ.get('RV_TUNE_FAMILIES')          # experiment: restrict the LDS tile families the tuner may pick
                     if fams:
                         keep = {int(f, 0) for f in fams.split(',')}
@@ -455,6 +465,8 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
             if invoke('rv_conv_fwd', *args, algo | (ALGO_BF16 if bf16 else 0), ptr(stats), *tail, stream()) == 0:
                 return
             algo = _algo_cache[key] = 0         # the borrowed tile does not fit this batch size: library default
+    if bf16 and (algo >> 8) & 15 in (6, 9):
+        algo = 0                                # the fp32 Winograd tile of this shape has no bf16 form: library-default direct tile
     if bf16 and algo not in (1,) and (algo >> 8) & 15 != 1:
         algo |= ALGO_BF16                       # (the library ignores the bit outside the persistent 3x3 kernel / 16-channel chunks)
     call('rv_conv_fwd', *args, algo, ptr(stats), *tail, stream())

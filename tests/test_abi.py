@@ -43,7 +43,8 @@ def test_ctypes_signatures_match_header(built):
         assert len(_lib.SIGNATURES[name][1]) == n, name
     lib = _lib.load()
     assert lib.rv_abi_version() == 1
-    assert lib.rv_packed_weight_floats(9, 16, 16) == 9 * 1 * 1 * 64 * 4
+    assert lib.rv_packed_weight_floats(9, 16, 16) == (9 + 16) * 1 * 1 * 64 * 4      # nine tap fragments + the 16 Winograd fragments
+    assert lib.rv_packed_weight_floats(9, 8, 16) == 9 * 1 * 1 * 64 * 2
     assert lib.rv_packed_weight_floats(9, 1, 16) == 9 * 16
     assert lib.rv_reduce_workspace_bytes(4096) == 8
 

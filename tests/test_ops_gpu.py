@@ -220,8 +220,43 @@ def test_conv3x3_forced_tile_vs_torch(dev, cin, cout, H, W, algo, monkeypatch):
             assert torch.equal(ops.ConvFn.apply(g[0], g[1], g[2], 'c3', None), yg)
 
 
+WINO_CASES = [(16, 16, 12, 229, 0x611), (32, 32, 22, 114, 0x621), (64, 64, 31, 57, 0x621), (16, 32, 9, 114, 0x611), (128, 128, 40, 28, 0x621),
+              (96, 48, 21, 57, 0x611), (48, 24, 10, 114, 0x611), (32, 16, 3, 17, 0x911), (64, 32, 20, 57, 0x921), (16, 16, 6, 57, 0x912),
+              (32, 32, 24, 114, 0x4621), (64, 64, 16, 28, 0x2611), (16, 8, 8, 229, 0x611)]
+
+
+@pytest.mark.parametrize('cin,cout,H,W,algo', WINO_CASES)
+def test_conv3x3_winograd_vs_torch(dev, cin, cout, H, W, algo, monkeypatch):
+    """Winograd F(2x2,3x3) form of the persistent 3x3 kernel (families 0x6NM / 0x9NM, forced): forward and both gradients (the input
+    gradient runs the same kernel on the flipped / transposed weights) against torch's fp32 convolution, odd and even widths and
+    heights, ragged last bands, fused statistics; repeated launches bit-identical."""
+    from reconvat_amd import ops
+    monkeypatch.setenv('RV_FORCE_ALGO', hex(algo))
+    B = 3
+    x, w, b = rnd(B, cin, H, W, seed=1), rnd(cout, cin, 3, 3, seed=2, scale=0.2), rnd(cout, seed=3)
+    leaves = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    yr = F.conv2d(*leaves, padding=1)
+    cot = rnd(*yr.shape, seed=4)
+    (yr * cot).sum().backward()
+    g = [nhwc(x).to(dev).requires_grad_(True), w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)]
+    stats = torch.zeros(ops.bn_ws_doubles(cout), dtype=torch.float64, device=dev)
+    yg = ops.ConvFn.apply(g[0], g[1], g[2], 'c3', None, stats)
+    if cout % 16:
+        monkeypatch.delenv('RV_FORCE_ALGO')              # (the input gradient of a narrower output has 8-channel chunks: direct form)
+    (yg * nhwc(cot).to(dev)).sum().backward()
+    assert rel_err(nchw(yg), yr) < 2 * TOL
+    zd = yg.detach().double().reshape(-1, cout)
+    assert rel_err(stats.view(-1, 2 * cout).sum(0), torch.cat([zd.sum(0), (zd * zd).sum(0)])) < 1e-6
+    assert rel_err(nchw(g[0].grad), leaves[0].grad) < 2 * TOL_G
+    assert rel_err(g[1].grad, leaves[1].grad) < TOL_G and rel_err(g[2].grad, leaves[2].grad) < TOL_G
+    if cout % 16 == 0:
+        with torch.no_grad():
+            for _ in range(5):
+                assert torch.equal(ops.ConvFn.apply(g[0], g[1], g[2], 'c3', None), yg)
+
+
 @pytest.mark.parametrize('c1,c2,H,W,algo', [(16, 16, 12, 37, 0), (24, 16, 9, 57, 0x211), (64, 32, 8, 28, 0x321), (8, 2, 6, 19, 0), (8, 2, 37, 300, 0), (32, 32, 8, 30, 1),
-                                            (24, 16, 11, 114, 0x713), (64, 24, 9, 57, 0x726)])
+                                            (24, 16, 11, 114, 0x713), (64, 24, 9, 57, 0x726), (32, 32, 11, 114, 0x621), (16, 16, 9, 57, 0x611), (48, 32, 8, 28, 0x911)])
 def test_conv_dgrad_fused_bn_backward_reduction(dev, c1, c2, H, W, algo, monkeypatch):
     """conv2(lrelu(bn(z))): with a BnLink the input-gradient kernel of conv2 also produces the BatchNorm's backward
     reduction (epilogue of the persistent kernel, reduction pass behind the others); gradients must not change."""
