@@ -757,7 +757,10 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
 // BatchNorm-backward / store logic with the direct form.  Unit staging (LDS-DMA, two buffers) is the direct kernel's, with the
 // band padded to an even width.
 // ------------------------------------------------------------------------------------------
-template <int NT, int MTW, int NW>
+// HALF (family 0xANM): the patch is read and transformed one HALF chunk (8 channels, two k-steps) at a time -- 32 instead of 64 patch
+// registers, the transform in packed math -- which is what lets the NT = 2 tile (two n-tiles share one patch: half the patch
+// reads / transforms / x staging / barriers per MFMA) fit the 256 registers of two waves per SIMD.
+template <int NT, int MTW, int NW, bool HALF = false>
 __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
     constexpr int NTHR = NW * 64;
     constexpr int KC = 16;                       // channels per chunk
@@ -928,50 +931,57 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
             if ((wave + NW * m) * 16 >= ntiles) continue;                   // wave-uniform: this tile group is beyond the band
-            f32x4 d[16];
-            f32x4 wf[2][NT];
+            typedef typename VecR<HALF ? 2 : 4>::T pvec;
+            constexpr int NR = HALF ? 2 : 4;             // k-steps per pass
             const unsigned xa = lds_addr(xs) + lbase[m] * 4;
-            if (ABL(aa) & 16) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) d[e] = (f32x4){1.f + e, 2.f, 3.f, 4.f};
-            } else
+            for (int h = 0; h < (HALF ? 2 : 1); ++h) {
+                pvec d[16];
+                pvec wf[2][NT];
+                if (ABL(aa) & 16) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) lds_read(d[e], xa + ((e >> 2) * W2 + (e & 3)) * (KC * 4));
+                    for (int e = 0; e < 16; ++e)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) lds_read(wf[0][n], ws_a + n * 1024);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            // V = B^T d B, in place: rows then columns
-            if (!(ABL(aa) & 16))
+                        for (int r = 0; r < NR; ++r) d[e][r] = 1.f + e + r;
+                } else
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const f32x4 d0 = d[cc], d1 = d[4 + cc], d2 = d[8 + cc], d3 = d[12 + cc];
-                d[cc] = d0 - d2; d[4 + cc] = d1 + d2; d[8 + cc] = d2 - d1; d[12 + cc] = d1 - d3;
-            }
-            if (!(ABL(aa) & 16))
+                for (int e = 0; e < 16; ++e) lds_read(d[e], xa + ((e >> 2) * W2 + (e & 3)) * (KC * 4) + h * 8);
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const f32x4 d0 = d[4 * rr], d1 = d[4 * rr + 1], d2 = d[4 * rr + 2], d3 = d[4 * rr + 3];
-                d[4 * rr] = d0 - d2; d[4 * rr + 1] = d1 + d2; d[4 * rr + 2] = d2 - d1; d[4 * rr + 3] = d1 - d3;
-            }
+                for (int n = 0; n < NT; ++n) lds_read(wf[0][n], ws_a + n * 1024 + h * 8);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                // V = B^T d B, in place: rows then columns
+                if (!(ABL(aa) & 16))
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi) {
-                if (xi + 1 < 16) {
-                    if (!(ABL(aa) & 32))
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) lds_read(wf[(xi + 1) & 1][n], ws_a + ((xi + 1) * NT + n) * 1024);
-                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NT) : "memory");
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int cc = 0; cc < 4; ++cc) {
+                    const pvec d0 = d[cc], d1 = d[4 + cc], d2 = d[8 + cc], d3 = d[12 + cc];
+                    d[cc] = d0 - d2; d[4 + cc] = d1 + d2; d[8 + cc] = d2 - d1; d[12 + cc] = d1 - d3;
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                if (!(ABL(aa) & 4))
+                if (!(ABL(aa) & 16))
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int rr = 0; rr < 4; ++rr) {
+                    const pvec d0 = d[4 * rr], d1 = d[4 * rr + 1], d2 = d[4 * rr + 2], d3 = d[4 * rr + 3];
+                    d[4 * rr] = d0 - d2; d[4 * rr + 1] = d1 + d2; d[4 * rr + 2] = d2 - d1; d[4 * rr + 3] = d1 - d3;
+                }
 #pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        acc[m][n][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[xi & 1][n][r], d[xi][r], acc[m][n][xi], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int xi = 0; xi < 16; ++xi) {
+                    if (xi + 1 < 16) {
+                        if (!(ABL(aa) & 32))
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) lds_read(wf[(xi + 1) & 1][n], ws_a + ((xi + 1) * NT + n) * 1024 + h * 8);
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NT) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(ABL(aa) & 4))
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[m][n][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[xi & 1][n][r], d[xi][r], acc[m][n][xi], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         if (c != nchunk - 1 || (ABL(aa) & 8)) continue;
@@ -2372,7 +2382,7 @@ static size_t conv3x3_wino_bytes(int NT, int TH, int W, int nchunk) {
     return ((size_t)2 * (TH + 2) * W2 * 16 + (size_t)(nchunk > 1 ? 2 : 1) * 16 * NT * 256) * sizeof(float);
 }
 
-template <int NW>
+template <int NW, bool HALF = false>
 static int launch_conv3x3_wino(const ConvArgs& a0, int NT, int MTW, int force_th, hipStream_t st) {
     if (NT < 1 || a0.ntile_n % NT) return RV_EUNSUPPORTED;
     ConvLdsArgs aa;
@@ -2404,7 +2414,7 @@ static int launch_conv3x3_wino(const ConvArgs& a0, int NT, int MTW, int force_th
     dim3 grid(wgs * nsplit), blk(NW * 64);
 #define RV_WN(nt, mt)                                                                              \
     if (NT == nt && MTW == mt) {                                                                  \
-        auto kern = conv3x3_wino_k<nt, mt, NW>;                                                   \
+        auto kern = conv3x3_wino_k<nt, mt, NW, HALF>;                                             \
         static bool attr_done = false;                                                            \
         if (!attr_done) {                                                                         \
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) \
@@ -2414,7 +2424,11 @@ static int launch_conv3x3_wino(const ConvArgs& a0, int NT, int MTW, int force_th
         hipLaunchKernelGGL(kern, grid, blk, lds, st, aa);                                         \
         return RV_OK;                                                                             \
     }
-    if constexpr (NW == 8) {
+    if constexpr (HALF && NW == 12) {
+        RV_WN(1, 1)
+    } else if constexpr (HALF) {
+        RV_WN(2, 1) RV_WN(1, 2) RV_WN(1, 1)
+    } else if constexpr (NW == 8) {
         RV_WN(1, 1) RV_WN(2, 1) RV_WN(1, 2)
     } else {
         RV_WN(1, 1) RV_WN(2, 1) RV_WN(1, 2)
@@ -2655,9 +2669,11 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
     const bool bf = ((algo >> 20) & 1) && mode == 0 && R == 4;
     algo &= ~(1 << 20);
     const int fam = (algo >> 8) & 15, f_nt = (algo >> 4) & 15, f_mt = algo & 15, f_th = (algo >> 12) & 255;
-    if (fam == 6 || fam == 9) {                // Winograd F(2x2,3x3): 0x6NM = 8 waves, 0x9NM = 4 waves per workgroup
+    if (fam == 6 || fam == 9 || fam == 10 || fam == 12) {   // Winograd F(2x2,3x3): 0x6NM = 8 waves, 0x9NM = 4 waves per workgroup, 0xANM = 8 waves + half-chunk patch, 0xCNM = 12 waves + half-chunk patch
         if (mode != 0 || R != 4) { rv_set_error("rv_conv_fwd: the Winograd kernel needs a 3x3 conv with Cin %% 16 == 0"); return RV_EUNSUPPORTED; }
-        const int rcw = fam == 6 ? launch_conv3x3_wino<8>(a, f_nt, f_mt, f_th, st) : launch_conv3x3_wino<4>(a, f_nt, f_mt, f_th, st);
+        const int rcw = fam == 6 ? launch_conv3x3_wino<8>(a, f_nt, f_mt, f_th, st)
+                      : (fam == 9 ? launch_conv3x3_wino<4>(a, f_nt, f_mt, f_th, st)
+                      : (fam == 10 ? launch_conv3x3_wino<8, true>(a, f_nt, f_mt, f_th, st) : launch_conv3x3_wino<12, true>(a, f_nt, f_mt, f_th, st)));
         if (rcw != RV_OK) { rv_set_error("rv_conv_fwd: forced Winograd tile NT=%d MTW=%d TH=%d does not fit", f_nt, f_mt, f_th); return rcw; }
         RV_LAUNCH_CHECK("rv_conv_fwd(winograd)");
         *sums_done = true;
