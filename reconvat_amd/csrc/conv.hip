@@ -744,7 +744,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Winograd F(2x2, 3x3) form of the persistent 3x3 kernel (algo family 0x6NM / 0x9NM; 16-channel chunks only).
+// Winograd F(2x2, 3x3) form of the persistent 3x3 kernel (algo families 0x6NM / 0x9NM, with HALF 0xANM / 0xCNM; 16-channel chunks only).
 //
 //   Y = A^T [ (G g G^T) .* (B^T d B) ] A    per 4x4 input patch d (stride 2) and 2x2 output tile Y
 //
@@ -757,9 +757,10 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
 // BatchNorm-backward / store logic with the direct form.  Unit staging (LDS-DMA, two buffers) is the direct kernel's, with the
 // band padded to an even width.
 // ------------------------------------------------------------------------------------------
-// HALF (family 0xANM): the patch is read and transformed one HALF chunk (8 channels, two k-steps) at a time -- 32 instead of 64 patch
+// HALF (families 0xANM: 8 waves, 0xCNM: 12 waves): the patch is read and transformed one HALF chunk (8 channels, two k-steps) at a time -- 32 instead of 64 patch
 // registers, the transform in packed math -- which is what lets the NT = 2 tile (two n-tiles share one patch: half the patch
-// reads / transforms / x staging / barriers per MFMA) fit the 256 registers of two waves per SIMD.
+// reads / transforms / x staging / barriers per MFMA) fit the 256 registers of two waves per SIMD.  With NT = 1 the kernel needs 165
+// registers: three waves per SIMD (12-wave workgroups).
 template <int NT, int MTW, int NW, bool HALF = false>
 __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
     constexpr int NTHR = NW * 64;
