@@ -257,6 +257,31 @@ def test_conv3x3_winograd_vs_torch(dev, cin, cout, H, W, algo, monkeypatch):
                 assert torch.equal(ops.ConvFn.apply(g[0], g[1], g[2], 'c3', None), yg)
 
 
+@pytest.mark.parametrize('cin,cout,H,W,algo', [(32, 32, 22, 114, 0x611), (64, 32, 13, 57, 0xa21), (16, 16, 10, 229, 0xc11), (48, 16, 9, 57, 0x911)])
+def test_conv3x3_winograd_accumulate_and_colsum(dev, cin, cout, H, W, algo, monkeypatch):
+    """The Winograd form behind the other two epilogue options of the persistent kernel: ``accumulate`` (a GradShare consumer adds its
+    input gradient into the shared buffer) and the plain per-channel sums of what it stores (ColsumLink) -- against the direct form."""
+    from reconvat_amd import ops
+    B = 3
+    dy = nhwc(rnd(B, cout, H, W, seed=1)).to(dev)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=0.2).to(dev)
+    base = nhwc(rnd(B, cin, H, W, seed=3)).to(dev)
+    outs = []
+    for forced in (algo, 0x111):
+        monkeypatch.setenv('RV_FORCE_ALGO', hex(forced))
+        ops.invalidate_weight_cache()
+        dx = base.clone()
+        ops.conv_dgrad_into('c3', dy, w, dx, accumulate=True)
+        sums = torch.zeros(ops.bn_ws_doubles(cin), dtype=torch.float64, device=dev)
+        dx2 = torch.empty_like(base)
+        ops.conv_dgrad_into('c3', dy, w, dx2, sum_ws=sums)
+        outs.append((dx, dx2, sums.view(-1, 2 * cin).sum(0)[:cin]))
+    assert rel_err(outs[0][0], outs[1][0]) < 4e-5 and rel_err(outs[0][1], outs[1][1]) < 4e-5
+    assert rel_err(outs[0][0] - base, outs[0][1]) < 4e-5
+    assert rel_err(outs[0][2], outs[0][1].double().reshape(-1, cin).sum(0)) < 1e-6
+    assert rel_err(outs[0][2], outs[1][2]) < 1e-5
+
+
 @pytest.mark.parametrize('c1,c2,H,W,algo', [(16, 16, 12, 37, 0), (24, 16, 9, 57, 0x211), (64, 32, 8, 28, 0x321), (8, 2, 6, 19, 0), (8, 2, 37, 300, 0), (32, 32, 8, 30, 1),
                                             (24, 16, 11, 114, 0x713), (64, 24, 9, 57, 0x726), (32, 32, 11, 114, 0x621), (16, 16, 9, 57, 0x611), (48, 32, 8, 28, 0x911), (64, 64, 12, 57, 0xa21), (32, 32, 10, 57, 0xc11)])
 def test_conv_dgrad_fused_bn_backward_reduction(dev, c1, c2, H, W, algo, monkeypatch):
