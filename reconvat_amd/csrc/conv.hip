@@ -744,7 +744,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Winograd F(2x2, 3x3) form of the persistent 3x3 kernel (algo families 0x6NM / 0x9NM, with HALF 0xANM / 0xCNM; 16-channel chunks only).
+// Winograd F(2x2, 3x3) form of the persistent 3x3 kernel (algo families 0x6NM, with HALF 0xANM / 0xCNM; 16-channel chunks only).
 //
 //   Y = A^T [ (G g G^T) .* (B^T d B) ] A    per 4x4 input patch d (stride 2) and 2x2 output tile Y
 //
@@ -2376,7 +2376,7 @@ static int launch_conv3x3_lds(const ConvArgs& a, int R, hipStream_t st, int forc
                   : launch_conv3x3_lds_r<2, 4>(a, best_nt, best_mt, best_th, best_wpc, st);
 }
 
-// Winograd launch (families 0x6NM: 8 waves, 0x9NM: 4 waves): a band of TH (even) rows holds (TH/2) x ceil(W/2) tiles of 2x2 outputs,
+// Winograd launch (families 0x6NM: 8 waves, 0xANM / 0xCNM: 8 / 12 waves with the half-chunk patch): a band of TH (even) rows holds (TH/2) x ceil(W/2) tiles of 2x2 outputs,
 // NW x MTW groups of 16 tiles per unit.  force_th = 0: as many rows as the tile slots hold.
 static size_t conv3x3_wino_bytes(int NT, int TH, int W, int nchunk) {
     const int W2 = 2 * ((W + 1) / 2) + 2;
@@ -2425,14 +2425,11 @@ static int launch_conv3x3_wino(const ConvArgs& a0, int NT, int MTW, int force_th
         hipLaunchKernelGGL(kern, grid, blk, lds, st, aa);                                         \
         return RV_OK;                                                                             \
     }
-    if constexpr (HALF && NW == 12) {
-        RV_WN(1, 1)
-    } else if constexpr (HALF) {
-        RV_WN(2, 1) RV_WN(1, 2) RV_WN(1, 1)
-    } else if constexpr (NW == 8) {
-        RV_WN(1, 1) RV_WN(2, 1) RV_WN(1, 2)
+    // (instantiated: the tiles that fit the register file without scratch -- 64 accumulator registers per (tile group, n-tile) pair)
+    if constexpr (HALF && NW == 8) {
+        RV_WN(2, 1) RV_WN(1, 1)
     } else {
-        RV_WN(1, 1) RV_WN(2, 1) RV_WN(1, 2)
+        RV_WN(1, 1)
     }
 #undef RV_WN
     return RV_EUNSUPPORTED;
@@ -2670,11 +2667,10 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
     const bool bf = ((algo >> 20) & 1) && mode == 0 && R == 4;
     algo &= ~(1 << 20);
     const int fam = (algo >> 8) & 15, f_nt = (algo >> 4) & 15, f_mt = algo & 15, f_th = (algo >> 12) & 255;
-    if (fam == 6 || fam == 9 || fam == 10 || fam == 12) {   // Winograd F(2x2,3x3): 0x6NM = 8 waves, 0x9NM = 4 waves per workgroup, 0xANM = 8 waves + half-chunk patch, 0xCNM = 12 waves + half-chunk patch
+    if (fam == 6 || fam == 10 || fam == 12) {   // Winograd F(2x2,3x3): 0x6NM = 8 waves, 0xANM = 8 waves + half-chunk patch, 0xCNM = 12 waves + half-chunk patch
         if (mode != 0 || R != 4) { rv_set_error("rv_conv_fwd: the Winograd kernel needs a 3x3 conv with Cin %% 16 == 0"); return RV_EUNSUPPORTED; }
         const int rcw = fam == 6 ? launch_conv3x3_wino<8>(a, f_nt, f_mt, f_th, st)
-                      : (fam == 9 ? launch_conv3x3_wino<4>(a, f_nt, f_mt, f_th, st)
-                      : (fam == 10 ? launch_conv3x3_wino<8, true>(a, f_nt, f_mt, f_th, st) : launch_conv3x3_wino<12, true>(a, f_nt, f_mt, f_th, st)));
+                      : (fam == 10 ? launch_conv3x3_wino<8, true>(a, f_nt, f_mt, f_th, st) : launch_conv3x3_wino<12, true>(a, f_nt, f_mt, f_th, st));
         if (rcw != RV_OK) { rv_set_error("rv_conv_fwd: forced Winograd tile NT=%d MTW=%d TH=%d does not fit", f_nt, f_mt, f_th); return rcw; }
         RV_LAUNCH_CHECK("rv_conv_fwd(winograd)");
         *sums_done = true;

@@ -427,12 +427,12 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
                                 extra.append(th << 12 | cand)
                     cands += sorted(set(extra))
                     if cin % 16 == 0 and os.environ.get('RV_TUNE_WINOGRAD', '1') != '0':
-                        # Winograd F(2x2,3x3) form (0x6NM: 8 waves, 0x9NM: 4 waves per workgroup, 0xANM / 0xCNM: 8 / 12 waves with the
-                        # patch read half a chunk at a time; bands of an even number of rows)
+                        # Winograd F(2x2,3x3) form (0x6NM: 8 waves; 0xANM / 0xCNM: 8 / 12 waves with the patch read half a chunk at a
+                        # time; bands of an even number of rows).  NT = 2 exists in the half-chunk 8-wave form only.
                         wt_ = (wd + 1) // 2
-                        for fam, nwv in ((6, 8), (9, 4), (10, 8), (12, 12)):
-                            for nt, mt in ((1, 1), (2, 1), (1, 2)):
-                                if ntile_n % nt or (fam == 12 and (nt, mt) != (1, 1)):
+                        for fam, nwv in ((6, 8), (10, 8), (12, 12)):
+                            for nt, mt in ((1, 1), (2, 1)):
+                                if ntile_n % nt or (nt == 2 and fam != 10):
                                     continue
                                 th_max = min(h, 2 * ((nwv * mt * 16) // wt_))
                                 ths = [0] + [t for t in range(2, th_max, 2) if -(-h // t) != -(-h // (t + 2))]
@@ -466,7 +466,7 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
             if invoke('rv_conv_fwd', *args, algo | (ALGO_BF16 if bf16 else 0), ptr(stats), *tail, stream()) == 0:
                 return
             algo = _algo_cache[key] = 0         # the borrowed tile does not fit this batch size: library default
-    if bf16 and (algo >> 8) & 15 in (6, 9, 10, 12):
+    if bf16 and (algo >> 8) & 15 in (6, 10, 12):
         algo = 0                                # the fp32 Winograd tile of this shape has no bf16 form: library-default direct tile
     if bf16 and algo not in (1,) and (algo >> 8) & 15 != 1:
         algo |= ALGO_BF16                       # (the library ignores the bit outside the persistent 3x3 kernel / 16-channel chunks)

@@ -220,16 +220,16 @@ def test_conv3x3_forced_tile_vs_torch(dev, cin, cout, H, W, algo, monkeypatch):
             assert torch.equal(ops.ConvFn.apply(g[0], g[1], g[2], 'c3', None), yg)
 
 
-WINO_CASES = [(16, 16, 12, 229, 0x611), (32, 32, 22, 114, 0x621), (64, 64, 31, 57, 0x621), (16, 32, 9, 114, 0x611), (128, 128, 40, 28, 0x621),
-              (96, 48, 21, 57, 0x611), (48, 24, 10, 114, 0x611), (32, 16, 3, 17, 0x911), (64, 32, 20, 57, 0x921), (16, 16, 6, 57, 0x912),
-              (32, 32, 24, 114, 0x4621), (64, 64, 16, 28, 0x2611), (16, 8, 8, 229, 0x611),
-              (32, 32, 22, 114, 0xa21), (64, 64, 31, 57, 0xa21), (128, 128, 40, 28, 0x8a21), (96, 64, 21, 57, 0xa21), (16, 16, 12, 229, 0xa11), (48, 48, 9, 57, 0xa12),
+WINO_CASES = [(16, 16, 12, 229, 0x611), (32, 32, 22, 114, 0x611), (64, 64, 31, 57, 0x611), (16, 32, 9, 114, 0x611), (128, 128, 40, 28, 0x611),
+              (96, 48, 21, 57, 0x611), (48, 24, 10, 114, 0x611), (32, 16, 3, 17, 0x611), (64, 32, 20, 57, 0xa11), (16, 16, 6, 57, 0xa11),
+              (32, 32, 24, 114, 0x4611), (64, 64, 16, 28, 0x2611), (16, 8, 8, 229, 0x611),
+              (32, 32, 22, 114, 0xa21), (64, 64, 31, 57, 0xa21), (128, 128, 40, 28, 0x8a21), (96, 64, 21, 57, 0xa21), (16, 16, 12, 229, 0xa11), (48, 48, 9, 57, 0xa11),
               (64, 64, 31, 57, 0xac11), (16, 16, 12, 229, 0xc11), (128, 128, 40, 28, 0xc11), (32, 16, 9, 114, 0x4c11)]
 
 
 @pytest.mark.parametrize('cin,cout,H,W,algo', WINO_CASES)
 def test_conv3x3_winograd_vs_torch(dev, cin, cout, H, W, algo, monkeypatch):
-    """Winograd F(2x2,3x3) form of the persistent 3x3 kernel (families 0x6NM / 0x9NM / 0xANM / 0xCNM, forced): forward and both gradients (the input
+    """Winograd F(2x2,3x3) form of the persistent 3x3 kernel (families 0x6NM / 0xANM / 0xCNM, forced): forward and both gradients (the input
     gradient runs the same kernel on the flipped / transposed weights) against torch's fp32 convolution, odd and even widths and
     heights, ragged last bands, fused statistics; repeated launches bit-identical."""
     from reconvat_amd import ops
@@ -257,7 +257,7 @@ def test_conv3x3_winograd_vs_torch(dev, cin, cout, H, W, algo, monkeypatch):
                 assert torch.equal(ops.ConvFn.apply(g[0], g[1], g[2], 'c3', None), yg)
 
 
-@pytest.mark.parametrize('cin,cout,H,W,algo', [(32, 32, 22, 114, 0x611), (64, 32, 13, 57, 0xa21), (16, 16, 10, 229, 0xc11), (48, 16, 9, 57, 0x911)])
+@pytest.mark.parametrize('cin,cout,H,W,algo', [(32, 32, 22, 114, 0x611), (64, 32, 13, 57, 0xa21), (16, 16, 10, 229, 0xc11), (48, 16, 9, 57, 0xa11)])
 def test_conv3x3_winograd_accumulate_and_colsum(dev, cin, cout, H, W, algo, monkeypatch):
     """The Winograd form behind the other two epilogue options of the persistent kernel: ``accumulate`` (a GradShare consumer adds its
     input gradient into the shared buffer) and the plain per-channel sums of what it stores (ColsumLink) -- against the direct form."""
@@ -283,7 +283,7 @@ def test_conv3x3_winograd_accumulate_and_colsum(dev, cin, cout, H, W, algo, monk
 
 
 @pytest.mark.parametrize('c1,c2,H,W,algo', [(16, 16, 12, 37, 0), (24, 16, 9, 57, 0x211), (64, 32, 8, 28, 0x321), (8, 2, 6, 19, 0), (8, 2, 37, 300, 0), (32, 32, 8, 30, 1),
-                                            (24, 16, 11, 114, 0x713), (64, 24, 9, 57, 0x726), (32, 32, 11, 114, 0x621), (16, 16, 9, 57, 0x611), (48, 32, 8, 28, 0x911), (64, 64, 12, 57, 0xa21), (32, 32, 10, 57, 0xc11)])
+                                            (24, 16, 11, 114, 0x713), (64, 24, 9, 57, 0x726), (32, 32, 11, 114, 0x611), (16, 16, 9, 57, 0x611), (48, 32, 8, 28, 0xa11), (64, 64, 12, 57, 0xa21), (32, 32, 10, 57, 0xc11)])
 def test_conv_dgrad_fused_bn_backward_reduction(dev, c1, c2, H, W, algo, monkeypatch):
     """conv2(lrelu(bn(z))): with a BnLink the input-gradient kernel of conv2 also produces the BatchNorm's backward
     reduction (epilogue of the persistent kernel, reduction pass behind the others); gradients must not change."""

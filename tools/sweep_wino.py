@@ -1,4 +1,4 @@
-"""Time the Winograd F(2x2,3x3) tiles (families 0x6NM / 0x9NM / 0xANM, every legal rows-per-band) against the plan-table tile of the direct
+"""Time the Winograd F(2x2,3x3) tiles (families 0x6NM / 0xANM / 0xCNM, every legal rows-per-band) against the plan-table tile of the direct
 persistent kernel on the 3x3 launch shapes of the BASELINE step (B = 8, fused statistics).
 
     python tools/sweep_wino.py            (one line per shape)
@@ -49,9 +49,9 @@ for cin, cout, h, w in SHAPES:
     t0 = timed(args, base_algo, stats)
     res = []
     ntile_n = (cout + 15) // 16
-    for fam, nw in ((6, 8), (9, 4), (10, 8), (12, 12)):
-        for nt, mt in ((1, 1), (2, 1), (1, 2)):
-            if ntile_n % nt or (fam == 12 and (nt, mt) != (1, 1)):
+    for fam, nw in ((6, 8), (10, 8), (12, 12)):
+        for nt, mt in ((1, 1), (2, 1)):
+            if ntile_n % nt or (nt == 2 and fam != 10):
                 continue
             wt_ = (w + 1) // 2
             th_max = min(h, 2 * ((nw * mt * 16) // wt_))
