@@ -461,7 +461,7 @@ def parity_leg(device):
             'rel_err_non_vat_max': float(f'{max(non.values()):.3e}'), 'rel_err_vat_max': float(f'{max(vat.values()):.3e}'),
             'rel_err': {k: float(f'{v:.3e}') for k, v in errs.items()},
             'reference_own_spread_vat_max': float(f'{max(v for k, v in spread.items() if "LDS" in k or "r_norm" in k):.3e}'),
-            'tolerance': '1e-3 relative (north_star) on every term; (the -m gpu tests widen the VAT terms to max(1e-3, 3 x the reference\'s own '
+            'tolerance': '1e-3 relative (north_star) on every term; (the -m gpu tests widen the VAT terms to max(1e-3, 2 x the reference\'s own '
                          '8-thread / 1-thread / fp64 movement) on the small fixtures, where the reference itself is noisier than 1e-3)',
             'kernel_plan_table': plans.digest()}
 
@@ -475,7 +475,12 @@ def self_launch(args):
     import tempfile
     n = args.gpus
     have = torch.cuda.device_count()              # (the ranks are fresh child processes: this process never execs and never runs GPU work)
-    if have < n:
+    if os.environ.get('RV_DP_SAME_GPU') == '1':   # every rank on cuda:0 over gloo (rank logic with the real kernels on a one-GPU box)
+        if os.environ.get('RV_DP_BACKEND', 'nccl').lower() != 'gloo':
+            raise SystemExit('RV_DP_SAME_GPU=1 needs RV_DP_BACKEND=gloo (RCCL refuses two ranks on one device)')
+        if have < 1:
+            raise SystemExit('bench.py: no GPU')
+    elif have < n:
         raise SystemExit(f'bench.py --gpus {n}: this node exposes {have} GPU(s)')
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
@@ -515,6 +520,23 @@ def self_launch(args):
         raise SystemExit(f'bench.py: rank(s) failed: {bad}')
 
 
+def make_rank_step(model_name, batch_l, batch_ul_n, rank, device, graph=True, dual_stream=True, bf16_backward=False):
+    """Model, optimiser, resident synthetic shard and TrainStep of data-parallel rank `rank`: identical seeded initial weights on
+    every rank, a distinct data shard and a distinct VAT noise stream per rank.  tests/test_dp_gpu.py rebuilds a
+    rank's step in a single process with this function."""
+    import reconvat_amd as ra
+    torch.manual_seed(1234)                       # identical initial weights on every rank
+    cls = ra.UNet_Onset if model_name == 'onset' else ra.UNet
+    model = cls((2, 2), (2, 2), log=True, reconstruction=True, mode='imagewise', spec='Mel', device=str(device), XI=1e-6, eps=2).to(device)
+    opt = ra.FlatAdam(model.parameters(), lr=1e-3, step_size=1000, gamma=0.98)
+    gen = torch.Generator().manual_seed(1000 + rank)      # distinct data shard per rank
+    batch, batch_ul = synthetic_batch(batch_l, gen, device), synthetic_batch(batch_ul_n, gen, device)
+    torch.manual_seed(77 + rank)                  # VAT noise stream of this rank
+    step = ra.TrainStep(model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=graph, dual_stream=dual_stream,
+                        bf16_backward=bf16_backward)
+    return model, opt, batch, batch_ul, step
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -533,6 +555,9 @@ def main():
                          'graphs; every forward pass and the power iteration stay fp32 (loss terms / posteriorgrams unchanged)')
     ap.add_argument('--no-parity', action='store_true', help='skip the post-run parity leg (frozen-weight step vs the reference fixture)')
     ap.add_argument('--verbose', action='store_true', help='dump the per-launch conv table to stderr')
+    ap.add_argument('--dp-dump', default=None, metavar='DIR',
+                    help='test instrumentation (tests/test_dp_gpu.py): every rank writes DIR/rank<r>.pt -- its data / VAT-noise checksums, its '
+                         'gradient bucket before and after the FIRST all-reduce and its parameters after the first optimiser step')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -544,29 +569,20 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
-    torch.cuda.set_device(local)
-    device = torch.device('cuda', local)
+    from reconvat_amd import dp
+    device = dp.local_device() if world > 1 else torch.device('cuda', local)
+    torch.cuda.set_device(device)
     if world > 1 or os.environ.get('RV_DP_FORCE_ALLREDUCE') == '1':
         # (RV_DP_FORCE_ALLREDUCE=1 under a launcher with one rank: a single-rank RCCL group, so that a one-GPU box executes the
-        # gradient all-reduce call for real)
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29541')
-        os.environ.setdefault('RANK', '0')
-        os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=device)
+        # gradient all-reduce call for real; RV_DP_BACKEND=gloo RV_DP_SAME_GPU=1: N ranks on cuda:0 -- reconvat_amd/dp.py)
+        dp.init(device)
 
     import reconvat_amd as ra
     from reconvat_amd import plans, ops as ops_mod
-    torch.manual_seed(1234)                       # identical initial weights on every rank
     cls = ra.UNet_Onset if args.model == 'onset' else ra.UNet
-    model = cls((2, 2), (2, 2), log=True, reconstruction=True, mode='imagewise', spec='Mel', device=str(device), XI=1e-6, eps=2).to(device)
     batch_l = args.batch if args.batch_l is None else args.batch_l
-    opt = ra.FlatAdam(model.parameters(), lr=1e-3, step_size=1000, gamma=0.98)
-    gen = torch.Generator().manual_seed(1000 + rank)      # distinct data shard per rank
-    batch, batch_ul = synthetic_batch(batch_l, gen, device), synthetic_batch(args.batch, gen, device)
-    torch.manual_seed(77 + rank)                  # VAT noise stream
-    step = ra.TrainStep(model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=not args.no_graph,
-                        dual_stream=not args.single_stream, bf16_backward=args.bf16_backward)
+    model, opt, batch, batch_ul, step = make_rank_step(args.model, batch_l, args.batch, rank, device, graph=not args.no_graph,
+                                                       dual_stream=not args.single_stream, bf16_backward=args.bf16_backward)
     used_graph = not args.no_graph
     if used_graph:
         try:
@@ -578,35 +594,65 @@ def main():
             step.use_graph, step.graph, used_graph = False, None, False
 
     def barrier():
-        if dist.is_initialized():
-            dist.barrier()
+        dp.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    dump = None
+    if args.dp_dump:
+        # the first optimiser step of this rank, seen from inside FlatAdam.step(): bucket before / after the collective, then the
+        # parameters that step produced (written below, after the warm-up steps have been issued and synchronised)
+        dump = {'rank': rank, 'world': world, 'audio_checksum_l': float(batch['audio'].double().sum()),
+                'audio_checksum_ul': float(batch_ul['audio'].double().sum()), 'cuda_seed': int(torch.cuda.initial_seed())}
+
+        def dp_hook(when, o):
+            if when + '_bucket' not in dump:
+                dump[when + '_bucket'] = o.flat_grad.detach().cpu().clone()
+        opt.dp_hook = dp_hook
+
+        def grab_params():
+            if 'params_after_step1' not in dump:
+                dump['params_after_step1'] = opt.flat_param.detach().cpu().clone()
+                dump['losses_step1'] = {k: float(v) for k, v in step.losses.items()}
+
+    for i in range(args.warmup):
         step()
+        if dump is not None and i == 0:
+            grab_params()
     barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         step()
+        if dump is not None and i == 0:
+            grab_params()
+    ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist.is_initialized():
+    device_ms = ev0.elapsed_time(ev1)             # the same K steps on the device's own clock (HIP events on the launch stream)
+    if dp.active():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dp.all_reduce(t, dist.ReduceOp.MAX)
         elapsed = t.item()
     loss = float(step.loss.item())
     nan_flag = int(model.vat_loss.nan_flag.item())
     loss_terms = {k: round(float(v), 6) for k, v in step.losses.items()}      # the 11 loss values of the last timed step
     # replica check: identical seeded weights + one summed gradient bucket + identical Adam => bit-identical parameters on
     # every rank.  Checksum = wrapping int64 sum of the parameter bit patterns; MAX - MIN over ranks must be 0.
-    rccl_ranks, replicas_equal = 1, True
+    dp_ranks, replicas_equal = 1, True
     checksum = opt.flat_param.view(torch.int32).sum(dtype=torch.int64).reshape(1)
-    if dist.is_initialized():
-        rccl_ranks = dist.get_world_size()
+    if dp.active():
+        dp_ranks = dist.get_world_size()
         hi, lo = checksum.clone(), checksum.clone()
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dp.all_reduce(hi, dist.ReduceOp.MAX)
+        dp.all_reduce(lo, dist.ReduceOp.MIN)
         replicas_equal = bool((hi - lo).item() == 0)
+    if dump is not None:
+        dump.update(allreduce_calls=int(getattr(opt, 'allreduce_calls', 0)), optimizer_steps=int(opt.step_count.item()),
+                    params_final=opt.flat_param.detach().cpu().clone(), offsets=list(opt.offsets),
+                    names=[n for n, p_ in model.named_parameters() if p_.requires_grad])
+        os.makedirs(args.dp_dump, exist_ok=True)
+        torch.save(dump, os.path.join(args.dp_dump, f'rank{rank}.pt'))
     ms = elapsed / args.steps * 1e3
     audio_s = world * (batch_l + args.batch) * SEG_SECONDS * args.steps / elapsed
 
@@ -621,8 +667,12 @@ def main():
                    'parallelism': f'dp{world}', 'hipgraph': used_graph, 'two_stream_schedule': not args.single_stream, 'labelled_only_audio_s_per_s': round(audio_s * batch_l / (batch_l + args.batch), 2),
                    'kernel_plan_table': plans.digest(), 'kernel_plan_mode': str(ops_mod.AUTOTUNE),
                    'final_loss': round(loss, 5), 'vat_nan_flag': nan_flag, 'losses_last_step': loss_terms},
-        'rccl_ranks': rccl_ranks, 'replicas_equal': replicas_equal, 'param_checksum': int(checksum.item()),
-        'rccl_allreduce_calls': int(getattr(opt, 'allreduce_calls', 0)),      # gradient all-reduces issued through RCCL by FlatAdam.step
+        # the same K steps timed by two HIP events on the launch stream (the record carries its own evidence that the device worked)
+        'device_ms_per_step': round(device_ms / args.steps, 3),
+        'dp_ranks': dp_ranks, 'dp_backend': (dist.get_backend() if dp.active() else None), 'replicas_equal': replicas_equal,
+        'param_checksum': int(checksum.item()),
+        # gradient all-reduces issued by FlatAdam.step (RCCL, or gloo through pinned host memory): one per optimiser step
+        'dp_allreduce_calls': int(getattr(opt, 'allreduce_calls', 0)), 'optimizer_steps': int(opt.step_count.item()),
     }
     if rank == 0 and world == 1 and args.model == 'onset' and batch_l == args.batch == 8:       # (the roofline / parity legs are written for the headline workload)
         if not args.no_roofline:
@@ -686,8 +736,7 @@ def main():
             line['parity'] = parity_leg(device)
         if not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
-    if dist.is_initialized():
-        dist.destroy_process_group()
+    dp.shutdown()
     if rank == 0:
         # RCCL writes its version banner to the C-level stdout (block-buffered when piped, flushed at exit): push it out NOW so that
         # the JSON line is the LAST line of stdout

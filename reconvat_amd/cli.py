@@ -16,10 +16,9 @@ from datetime import datetime
 
 import numpy as np
 import torch
-import torch.distributed as dist
 from torch.utils.data import DataLoader
 
-from . import UNet_Onset, UNet
+from . import UNet_Onset, UNet, dp
 from .dataset import prepare_VAT_dataset
 from .train import FlatAdam, TrainStep, train_VAT_model, cycle
 
@@ -123,7 +122,7 @@ def log_validation(model, val_set, l_loader, ep, writer, reconstruction, onset_s
                 writer.add_scalar(key, float(np.mean(values)), ep)
     test_losses = eval_model(model, ep, l_loader, VAT_start, VAT)
     for key, values in test_losses.items():
-        if key.startswith('loss/'):
+        if key.startswith('loss/') and values:
             writer.add_scalar(key, float(np.mean(values)), ep)
     model.train(was_training)
 
@@ -139,14 +138,13 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
         raise SystemExit(f"device={device!r}: this build runs the training path on an MI355X only (hand-written HIP kernels, no CPU "
                          "fallback); use device=cuda:0.  The reference's CPU plumbing run maps to the same command with device=cuda:0.")
     if world > 1:
-        local = int(os.environ.get('LOCAL_RANK', '0'))
-        device = f'cuda:{local}'
-        torch.cuda.set_device(local)
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        # rank 0 alone runs the validation passes (whole songs can take minutes) while its peers wait at a barrier: a generous
-        # collective timeout keeps the watchdog from firing on that wait
-        from datetime import timedelta
-        dist.init_process_group('nccl', device_id=torch.device(device), timeout=timedelta(hours=4))
+        # one process per GPU (RV_DP_BACKEND=nccl: RCCL; gloo + RV_DP_SAME_GPU=1: every rank on cuda:0, for one-GPU boxes).  The
+        # training group keeps the default collective timeout; rank 0 alone runs the validation passes (whole songs can take
+        # minutes) while its peers wait in dp.wait_for_rank0() on a separate long-timeout gloo group
+        dev_ = dp.local_device()
+        device = f'cuda:{dev_.index}'
+        torch.cuda.set_device(dev_)
+        dp.init(dev_, long_wait_group=True)
     elif str(device).startswith('cuda'):
         torch.cuda.set_device(torch.device(device))
 
@@ -188,7 +186,8 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
     scheduler = None
     if fused_optimizer:
         optimizer = FlatAdam(model.parameters(), lr=learning_rate, step_size=learning_rate_decay_steps,
-                             gamma=learning_rate_decay_rate, data_parallel=world > 1)
+                             gamma=learning_rate_decay_rate, data_parallel=world > 1,
+                             sync_error_word=bool(getattr(model, 'has_recurrence', False)))
     else:
         optimizer = torch.optim.Adam(model.parameters(), learning_rate)
         scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=learning_rate_decay_steps, gamma=learning_rate_decay_rate)
@@ -250,7 +249,7 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
                 torch.save(model.state_dict(), os.path.join(logdir, f'model-{ep}.pt'))
                 torch.save(optimizer.state_dict(), os.path.join(logdir, 'last-optimizer-state.pt'))
         if world > 1 and (ep % logging_freq == 0 or ep == 1):
-            dist.barrier()                                 # the other ranks wait for rank 0's validation pass
+            dp.wait_for_rank0()                            # the other ranks wait for rank 0's validation pass
     if rank == 0:
         torch.save(model.state_dict(), os.path.join(logdir, 'model-final.pt'))
         # final evaluation exactly as the reference scripts end (train_UNet_Onset_VAT.py:156-170): WHOLE songs of the test split
@@ -273,7 +272,6 @@ def run_training(onset_script, spec, resume_iteration, train_on, batch_size, seq
         print(f'Training finished.  validation frame F1 {f1:.4f}, note F1 '
               f"{float(np.mean(metrics['metric/note/f1'])) if metrics['metric/note/f1'] else float('nan'):.4f}")
     if world > 1:
-        dist.barrier()                                     # nobody tears the process group down while rank 0 still evaluates
-    if world > 1:
-        dist.destroy_process_group()
+        dp.wait_for_rank0()                                # nobody tears the process group down while rank 0 still evaluates
+        dp.shutdown()
     return model

@@ -12,7 +12,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import dp, ops
 from ._lib import call, ptr, stream
 
 
@@ -110,7 +110,8 @@ class FlatAdam:
     Parameters that never receive a gradient keep a zero gradient and zero moments -> they do not move,
     which is what torch.optim.Adam does by skipping them (6 such tensors in UNet_Onset)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, step_size=1000, gamma=0.98, data_parallel=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, step_size=1000, gamma=0.98, data_parallel=None,
+                 sync_error_word=False):
         self.params = [p for p in params if p.requires_grad]
         assert self.params, 'no trainable parameters'
         dev = self.params[0].device
@@ -141,7 +142,10 @@ class FlatAdam:
         ops.step_error_word(dev)                # create the per-device error word outside any graph capture
         # the ONE all-reduce call site of a step is step(); None = whenever a process group with world > 1 is up
         self.data_parallel = data_parallel
-        self.sync_error_word = False            # TrainStep sets it for models with a recurrence (see allreduce_gradients)
+        # models with a recurrence (BiLSTM time-out flag, `model.has_recurrence`): data-parallel ranks MAX the per-device error word
+        # along with the gradients so that all of them skip the same steps (see allreduce_gradients).  Pass it here for every
+        # data-parallel loop (eager train_VAT_model included); TrainStep also switches it on from the model.
+        self.sync_error_word = bool(sync_error_word)
         ops.invalidate_weight_cache()
 
     @staticmethod
@@ -175,7 +179,9 @@ class FlatAdam:
         call('rv_adam_step', ptr(self.flat_param), ptr(self.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n,
              ptr(self.step_count), self.lr, self.step_size, self.gamma, self.betas[0], self.betas[1], self.eps,
              self.grad_scale, ptr(ops.step_error_word(self.flat_grad.device)), stream())
-        # (same skip word: a step whose update was skipped advances neither StepLR nor the bias correction)
+        # (same skip word: a step whose update was skipped advances neither StepLR nor the bias correction -- `step_count`, and with
+        # it the `step` of state_dict(), counts APPLIED updates, not calls; the word stays set until check() reports it, so every
+        # step between a fault and the next check() is skipped on all ranks alike)
         call('rv_counter_add', ptr(self.step_count), 1, ptr(ops.step_error_word(self.flat_grad.device)), stream())
         ops.invalidate_weight_cache()
 
@@ -232,18 +238,24 @@ class FlatAdam:
 
 
 def allreduce_gradients(opt):
-    """ONE RCCL all-reduce (sum) of the flat gradient bucket per optimiser step, after the final backward
-    and never inside the VAT power iteration; the 1/world_size mean is folded into the Adam kernel."""
+    """ONE all-reduce (sum) of the flat gradient bucket per optimiser step -- RCCL over xGMI, or gloo through a pinned host
+    buffer (reconvat_amd/dp.py) -- after the final backward and never inside the VAT power iteration; the 1/world_size mean is
+    folded into the Adam kernel."""
     # (RV_DP_FORCE_ALLREDUCE=1: also with a single-rank group -- lets a one-GPU box execute the RCCL call in place, tests/test_cli_gpu.py)
     min_world = 1 if os.environ.get('RV_DP_FORCE_ALLREDUCE') == '1' else 2
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() >= min_world:
-        dist.all_reduce(opt.flat_grad, op=dist.ReduceOp.SUM)
+    if dp.active() and dist.get_world_size() >= min_world:
+        hook = getattr(opt, 'dp_hook', None)           # test instrumentation: sees the bucket before and after the collective
+        if hook is not None:
+            hook('pre', opt)
+        dp.all_reduce(opt.flat_grad, dist.ReduceOp.SUM)
         opt.grad_scale = 1.0 / dist.get_world_size()
         opt.allreduce_calls = getattr(opt, 'allreduce_calls', 0) + 1
         if getattr(opt, 'sync_error_word', False):
             # models with a recurrence (BiLSTM time-out flag): every rank must skip the same steps, or the replicas diverge and the
             # rank that raises in check() leaves its peers blocked in the next collective -- MAX the flag along with the gradients
-            dist.all_reduce(ops.step_error_word(opt.flat_grad.device), op=dist.ReduceOp.MAX)
+            dp.all_reduce(ops.step_error_word(opt.flat_grad.device), dist.ReduceOp.MAX)
+        if hook is not None:
+            hook('post', opt)
 
 
 class TrainStep:

@@ -399,6 +399,71 @@ def g_anchor_b8():
     save('anchor_b8', **out)
 
 
+def g_anchor_grads():
+    """Full-size PARAMETER GRADIENTS against the reference: B = 2 segments of 327 680 samples (640 frames),
+    reconstruction on, both models, the reference's own loop rule (model/helper_functions.py:589-600: every LDS key x alpha/2,
+    everything else x 1, `loss.backward()`), in two deterministic modes:
+      * `novat`: run_on_batch(batch, None, False) -- no VAT term at all (model/UNet_onset.py:380-405,460-483);
+      * `radv` : VAT on with n_power = 0 -- the reference's power-iteration loop never runs and the patched `randn_like` goes straight
+        into r_adv = eps * d / ||d|| (:129-151), so the WHOLE eleven-term step (both VAT branches, reconstruction branch) is
+        deterministic and its gradient is comparable between implementations.
+    Each at 8 threads fp32 (the reference as shipped) and in fp64 (the yardstick of the `e_gpu <= 2 x e_cpu32 + 2e-3` bar).
+    Stored per parameter: (norm, strided sample of <= 512 values) of both runs, and the loss values."""
+    out = {}
+    real_randn_like = torch.randn_like
+    T, B, N = 640, 2, 512
+    for kind in ('onset', 'frame'):
+        for mode in ('novat', 'radv'):
+            bl, bul = _batch(B, T, 'L'), _batch(B, T, 'UL')
+            noises = [fx.fixture_noise((B, 1, T, 229), 'radv_ul'), fx.fixture_noise((B, 1, T, 229), 'radv_l')]
+            tag = f'{kind}_{mode}'
+            for name, dtype in (('f32', torch.float32), ('f64', torch.float64)):
+                torch.set_num_threads(8)
+                net, _ = build_ref(kind, True)
+                if dtype == torch.float64:
+                    net = net.double()
+                cast = lambda d: {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()}
+                seq = [n.to(dtype) for n in noises]
+
+                def fake(t, **kw):
+                    d = seq.pop(0).clone()
+                    return d.requires_grad_(True) if kw.get('requires_grad') else d
+                torch.randn_like = fake
+                try:
+                    if mode == 'radv':
+                        net.vat_loss.n_power = 0
+                        pr, lr, _ = net.run_on_batch(cast(bl), cast(bul), True)
+                    else:
+                        pr, lr, _ = net.run_on_batch(cast(bl), None, False)
+                finally:
+                    torch.randn_like = real_randn_like
+                loss = 0                                   # model/helper_functions.py:589-595 with alpha = 1
+                for key in lr:
+                    loss = loss + (0.5 * lr[key] if key.startswith('loss/train_LDS') else lr[key])
+                loss.backward()
+                named = dict(net.named_parameters())
+                out[f'{tag}_{name}_losses'] = np.array([float(v) for v in lr.values()], dtype=np.float64)
+                if name == 'f32':
+                    out[f'{tag}_keys'] = np.array(list(lr.keys()))
+                    out[f'{tag}_nograd'] = np.array([k for k, p in named.items() if p.grad is None])
+                    out[f'{tag}_gmax'] = max(p.grad.abs().max().item() for p in named.values() if p.grad is not None)
+                    for k in ('frame', 'frame2', 'reconstruction'):
+                        out[f'{tag}_{k}'] = digest(pr[k], 512)
+                for k, p in named.items():
+                    if p.grad is not None:
+                        d = digest(p.grad, N)
+                        out[f'{tag}_{name}_g:' + k] = d.astype(np.float32) if name == 'f32' else d
+                del net, pr, lr, loss, named
+            # what the bar will be made of: the reference's own fp32 error against its fp64 run, on the stored samples
+            errs = []
+            for k in [k[len(f'{tag}_f64_g:'):] for k in out if k.startswith(f'{tag}_f64_g:')]:
+                a, b = out[f'{tag}_f32_g:' + k].astype(np.float64)[1:], out[f'{tag}_f64_g:' + k][1:]
+                errs.append(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+            print(tag, 'losses', dict(zip(out[f'{tag}_keys'], np.round(out[f'{tag}_f32_losses'], 5))),
+                  f'| reference fp32 vs fp64 gradient error per tensor: median {np.median(errs):.2e}, max {np.max(errs):.2e}')
+    save('anchor_grads', **out)
+
+
 def g_application():
     """UNet.run_on_batch_application (model/self_attention_VAT.py:1205-1291) and UNet.transcribe (:1293-1314), reference run."""
     out = {}
@@ -823,7 +888,7 @@ def g_onset_frames():
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['frontend', 'unet', 'attention', 'networks', 'vat', 'run_on_batch', 'train_step', 'dataset',
-                             'decoding', 'onset_frames', 'ingest', 'lds_spread', 'application', 'lds_backward', 'anchor_b8']
+                             'decoding', 'onset_frames', 'ingest', 'lds_spread', 'application', 'lds_backward', 'anchor_b8', 'anchor_grads']
     for w in which:
         print('==', w)
         globals()['g_' + w]()

@@ -209,7 +209,7 @@ def test_bench_self_launch_two_ranks(dev):
                         '--batch', '2'], capture_output=True, text=True, cwd=ROOT, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     line = json.loads(p.stdout.strip().splitlines()[-1])
-    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['replicas_equal'] is True
+    assert line['n_gpus'] == 2 and line['dp_ranks'] == 2 and line['dp_backend'] == 'nccl' and line['replicas_equal'] is True
 
 
 def test_rccl_allreduce_executes_on_one_gpu(dev):
@@ -229,7 +229,7 @@ def test_rccl_allreduce_executes_on_one_gpu(dev):
         assert p.stdout.strip().splitlines()[-1] == lines[0], 'the JSON line must be the LAST line of stdout: ' + p.stdout[-1500:]
         outs.append(json.loads(lines[0]))
     plain, rccl = outs
-    assert plain['rccl_allreduce_calls'] == 0 and rccl['rccl_allreduce_calls'] == 4 and rccl['rccl_ranks'] == 1
+    assert plain['dp_allreduce_calls'] == 0 and rccl['dp_allreduce_calls'] == 4 and rccl['dp_ranks'] == 1 and rccl['dp_backend'] == 'nccl'
     assert rccl['replicas_equal'] is True
     assert abs(rccl['config']['final_loss'] - plain['config']['final_loss']) <= 2e-3 * abs(plain['config']['final_loss'])
 

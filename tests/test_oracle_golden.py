@@ -139,3 +139,36 @@ def test_lds_spread_fixture_is_consistent_with_the_other_goldens():
             for k, s in zip(sp[case + '_keys'], sp[case + '_spread']):
                 vat = 'LDS' in str(k) or 'r_norm' in str(k)
                 assert (1e-5 < s < 1e-2) if vat else (s < 1e-5), (case, k, s)
+
+
+def test_oracle_fullsize_gradients_match_the_reference_golden():
+    """The oracle's full-size backward (B = 2 x 640 frames, reconstruction on, no VAT) against the REFERENCE's own loss.backward()
+    stored in tests/golden/anchor_grads.npz: the oracle is the same sequence of torch ops, so losses agree to round-off and the
+    gradients far inside the reference's own fp32-vs-fp64 error (what the GPU test's bar is made of)."""
+    g = load('anchor_grads')
+    tag = 'onset_novat'
+    params = fx.fixture_params('onset', True)
+    for k in om.trainable_keys(params):
+        params[k].requires_grad_(True)
+    onset, frame = fx.fixture_labels(2, 640, 'L')
+    bl = {'audio': fx.fixture_audio(2, 640 * 512, 'L'), 'onset': onset, 'frame': frame}
+    _, lo, _ = om.run_on_batch_onset(params, True, bl, None, False, True)
+    assert list(lo.keys()) == [str(k) for k in g[tag + '_keys']]
+    for (k, v), ref in zip(lo.items(), g[tag + '_f32_losses']):
+        assert abs(float(v.detach()) - float(ref)) <= 2e-5 * max(abs(float(ref)), 1e-6), (k, float(v.detach()), float(ref))
+    sum(lo.values()).backward()
+    gmax = float(g[tag + '_gmax'])
+    nograd = set(str(k) for k in g[tag + '_nograd'])
+    checked = 0
+    for k in om.trainable_keys(params):
+        if k in nograd:
+            assert params[k].grad is None, k
+            continue
+        d32, d64 = g[f'{tag}_f32_g:' + k].astype(np.float64), g[f'{tag}_f64_g:' + k]
+        d = digest(params[k].grad, 512)
+        den = max(np.linalg.norm(d64[1:]), 1e-4 * gmax * (len(d64) - 1) ** 0.5)
+        e_oracle = np.linalg.norm(d[1:] - d32[1:]) / den          # oracle vs the reference's fp32 run (same arithmetic)
+        e_ref = np.linalg.norm(d32[1:] - d64[1:]) / den           # the reference's fp32 run vs its own fp64 run
+        assert e_oracle <= 0.5 * e_ref + 1e-4, (k, e_oracle, e_ref)
+        checked += 1
+    assert checked > 90
