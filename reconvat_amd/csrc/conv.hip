@@ -25,6 +25,7 @@
 // workspace and folded by a deterministic second pass (no atomics).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------
 // weight packing
@@ -344,6 +345,7 @@ struct ConvLdsArgs {
     int skew;          // nbuf == 3: half of the waves stage after their multiplies
     int ablate;        // ABLATION (timing experiments only)
     int nsplit, xcd;   // n-splits per band group; XCD-aware placement on/off
+    int wres;          // conv3x3_wino_k: the weights of ALL chunks stay in LDS for the whole kernel (staged once, with unit 0)
 };
 
 
@@ -375,11 +377,31 @@ __device__ __forceinline__ void lds_read(f32x2& v, unsigned addr) {
 __device__ __forceinline__ void lds_read(float& v, unsigned addr) {
     asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
 }
+// compile-time loop (the body sees its index as a constant expression: instruction immediates, register-array indices)
+template <int I, int N, class F> __device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sfor<I + 1, N>(static_cast<F&&>(f));
+    }
+}
+
+template <int OFF> __device__ __forceinline__ void lds_read_o(f32x4& v, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF> __device__ __forceinline__ void lds_read_o(f32x2& v, unsigned addr) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+}
+
 // wait until at most N of this wave's LDS operations are outstanding (the counter is 4 bits wide: N is clamped to 15, which
 // only makes the wait stricter)
 template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N > 15 ? 15 : N) : "memory");
 }
+
+// 1 KiB of zeros in global memory: the DMA source of everything that must read as zero (rows above / below the image, the halo
+// columns) -- every piece of every staged row is then written by exactly one unmasked DMA instruction per unit, and the staging code
+// has no exec-mask or row branches left
+__device__ __attribute__((aligned(16))) const float rv_zero_piece[256] = {0.f};
 
 // BF (R == 4 only; opt-in experiment, BASELINE config 3): the operands are rounded to bf16 (round-to-nearest-even,
 // v_cvt_pk_bf16_f32) on their way from LDS to the matrix pipe and ONE v_mfma_f32_16x16x16_bf16 replaces the four f32 MFMAs of a
@@ -463,6 +485,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
         w_lane[t] = i < NWF && f < 9 * NT;
         w_off[t] = (unsigned)((tap * nchunk * a.ntile_n + nt0 + n) * 64 * R + o * 4) * 4u;
     }
+    const char* zsrc = reinterpret_cast<const char*>(rv_zero_piece) + lane * 16;
     const int b_first = band_lo / aa.nbands, y_first = (band_lo - b_first * aa.nbands) * TH;
     int sg_u = 0, sg_buf = 0, sg_b = b_first, sg_y0 = y_first, sg_c = 0;      // staging cursor (units in order)
 
@@ -476,24 +499,20 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
             if (wave + NW * t >= nx) break;
             const int gy = sg_y0 - 1 + xs_row[t];
             float* ldst = xb + xs_ldst[t];                               // wave-uniform
-            if (gy >= 0 && gy < H) {
-                if (xs_lane[t]) glds16(reinterpret_cast<const float*>(src + xs_goff[t]), ldst);
-                ++issued;
-            } else if (xs_lane[t]) {
-                *reinterpret_cast<f32x4*>(ldst + lane * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
+            // rows above / below the image fetch zeros (rv_zero_piece) instead of branching into a store: one select, one DMA
+            const bool rowok = gy >= 0 && gy < H;
+            if (xs_lane[t]) glds16(reinterpret_cast<const float*>(rowok ? src + xs_goff[t] : zsrc), ldst);
+            ++issued;
         }
         for (int i = wave + NW * TXF; i < nx; i += NW) {                 // narrow workgroups on wide rows
             const int row = i / ipr, k = i - row * ipr;
             const int gy = sg_y0 - 1 + row;
             const int px = k * PPI + lane / Q, q = lane - (lane / Q) * Q;
             float* ldst = xb + (row * W2 + 1 + k * PPI) * KC;
-            if (gy >= 0 && gy < H) {
-                if (px < W) glds16(reinterpret_cast<const float*>(src) + ((long)row * W + px) * a.in_ld + q * 4, ldst);
-                ++issued;
-            } else if (px < W) {
-                *reinterpret_cast<f32x4*>(ldst + lane * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
+            const bool rowok = gy >= 0 && gy < H;
+            if (px < W)
+                glds16(rowok ? reinterpret_cast<const float*>(src) + ((long)row * W + px) * a.in_ld + q * 4 : reinterpret_cast<const float*>(zsrc), ldst);
+            ++issued;
         }
         if (nchunk > 1 || sg_u == 0) {
             float* wb = ws0 + ((nchunk > 1) ? sg_buf : 0) * WFLOATS;
@@ -591,19 +610,24 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
         unsigned xs_a[MTW];
 #pragma unroll
         for (int m = 0; m < MTW; ++m) xs_a[m] = lds_addr(xs) + lbase[m] * 4;
-        auto ldtap = [&](const int buf, const int tap) {
+        const unsigned rowb = (unsigned)W2 * KC * 4;
+        // fragment reads of one tap: the weight offsets and the column part of the tap shift are instruction immediates, the row
+        // part is one add per (tile, kernel row)
+        auto ldtap = [&](auto bufc, auto tapc) {
+            constexpr int bsel = decltype(bufc)::value, tap = decltype(tapc)::value;
+            sfor<0, NT>([&](auto nc) {
+                constexpr int n = decltype(nc)::value;
+                lds_read_o<(tap * NT + n) * 64 * R * 4>(wf[bsel][n], ws_a);
+            });
 #pragma unroll
-            for (int n = 0; n < NT; ++n) lds_read(wf[buf][n], ws_a + (tap * NT + n) * 64 * R * 4);
-            const int toff = ((tap / 3) * W2 + (tap % 3)) * KC * 4;
-#pragma unroll
-            for (int m = 0; m < MTW; ++m) lds_read(xf[buf][m], xs_a[m] + toff);
+            for (int m = 0; m < MTW; ++m) lds_read_o<(tap % 3) * KC * 4>(xf[bsel][m], xs_a[m] + (tap / 3) * rowb);
         };
-        ldtap(0, 0);
+        ldtap(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         if (!(ABL(aa) & 4))
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        sfor<0, 9>([&](auto tapc) {
+            constexpr int tap = decltype(tapc)::value;
 #ifdef RV_ABLATION
-            if ((ABL(aa) & 256) && tap >= 4) break;          // Winograd F(2x2,3x3) cost probe: 4 MFMA groups per pixel tile ...
+            if ((ABL(aa) & 256) && tap >= 4) return;         // Winograd F(2x2,3x3) cost probe: 4 MFMA groups per pixel tile ...
             if (ABL(aa) & 512) {                             // ... plus its input-transform adds (8 per fragment and group)
 #pragma unroll
                 for (int m = 0; m < MTW; ++m)
@@ -611,8 +635,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
                     for (int q = 0; q < 8; ++q) asm volatile("v_add_f32 %0, %0, %1" : "+v"(xf[tap & 1][m][q % R]) : "v"(xf[tap & 1][m][(q + 1) % R]));
             }
 #endif
-            if (tap + 1 < 9) {
-                if (!(ABL(aa) & 16)) ldtap((tap + 1) & 1, tap + 1);
+            if constexpr (tap + 1 < 9) {
+                if (!(ABL(aa) & 16)) ldtap(std::integral_constant<int, (tap + 1) & 1>{}, std::integral_constant<int, tap + 1>{});
                 asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NT + MTW) : "memory");   // tap's own fragments have landed
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -639,7 +663,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tap & 1][n][r], xf[tap & 1][m][r], acc[m][n], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
         if (late && !(ABL(aa) & 2)) ahead = (sg_u < nunits) ? stage() : 0;
         if (c != nchunk - 1) continue;
         // epilogue of this band
@@ -761,7 +785,45 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
 // registers, the transform in packed math -- which is what lets the NT = 2 tile (two n-tiles share one patch: half the patch
 // reads / transforms / x staging / barriers per MFMA) fit the 256 registers of two waves per SIMD.  With NT = 1 the kernel needs 165
 // registers: three waves per SIMD (12-wave workgroups).
-template <int NT, int MTW, int NW, bool HALF = false>
+// LDS image of a staged band (round 4).  A row is a sequence of 1 KiB PIECES of 16 pixels x 16 channels; piece k holds the padded
+// columns X = 16k .. 16k+15 (X = x + 1: X = 0 is the left halo column).  One LDS-DMA instruction fills one piece (lane i -> bytes
+// [16 i, 16 i + 16) of the piece -- fixed by the hardware), but WHICH (pixel, channel quad) a lane fetches is free, so the position of a
+// quad inside its piece is a permutation chosen for the READ side: lane (j, g) of the multiplying wave reads, for each of the 16 patch
+// elements, pixel X = 2 (tx_j + const) + const' -- neighbouring lanes are TWO pixels (128 bytes in a pixel-major image) apart, which
+// put the 16 lanes of a ds_read_b128 lane group on 4 of the 16 slots of a bank row (4-way conflict, 61 % of all LDS cycles in the
+// round-3 kernel).  Layout 1: slot = parity * 32 + (quad >> 1) * 16 + (pixel >> 1) * 2 + (quad & 1): the eight tiles x two quads
+// (g, g ^ 1) of a lane group land on sixteen different slots -- conflict-free.  Layout 0: even / odd pixel planes, pixel-major inside
+// a plane (slot = parity * 32 + (pixel >> 1) * 4 + quad): 2-way, every DMA lane quad still fetches 64 contiguous bytes.
+template <int LAY> __device__ __forceinline__ int wino_slot(int p, int q) {
+    return LAY == 1 ? (p & 1) * 32 + (q >> 1) * 16 + (p >> 1) * 2 + (q & 1) : (p & 1) * 32 + (p >> 1) * 4 + q;
+}
+// ... and its inverse for the DMA side: (pixel of the piece, quad) that lane i fetches
+template <int LAY> __device__ __forceinline__ void wino_lane(int i, int& p, int& q) {
+    if (LAY == 1) { p = ((i >> 1) & 7) * 2 + (i >> 5); q = ((i >> 4) & 1) * 2 + (i & 1); }
+    else { p = ((i >> 2) & 7) * 2 + (i >> 5); q = i & 3; }
+}
+// byte offset, inside a row, of quad g of the pixel pair index u = X >> 1 (even pixel; the odd one is 512 bytes further)
+template <int LAY> __device__ __forceinline__ int wino_pair_off(int u, int g) {
+    return (u >> 3) * 1024 + (LAY == 1 ? (g >> 1) * 256 + (u & 7) * 32 + (g & 1) * 16 : (u & 7) * 64 + g * 16);
+}
+
+// packed f32 add / subtract on channel pairs (v_pk_add_f32, the subtraction as a neg modifier)
+__device__ __forceinline__ f32x2 pk_add(const f32x2 a, const f32x2 b) { return a + b; }
+__device__ __forceinline__ f32x2 pk_sub(const f32x2 a, const f32x2 b) { return a - b; }
+__device__ __forceinline__ f32x4 pk_add(const f32x4 a, const f32x4 b) {
+    const f32x2 lo = (f32x2){a[0], a[1]} + (f32x2){b[0], b[1]}, hi = (f32x2){a[2], a[3]} + (f32x2){b[2], b[3]};
+    return (f32x4){lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ f32x4 pk_sub(const f32x4 a, const f32x4 b) {      // (left to the compiler, a <4 x float> fsub is scalarised)
+    f32x2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"((f32x2){a[0], a[1]}), "v"((f32x2){b[0], b[1]}));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"((f32x2){a[2], a[3]}), "v"((f32x2){b[2], b[3]}));
+    return (f32x4){lo[0], lo[1], hi[0], hi[1]};
+}
+
+// BNZ: the launch carries the fused BatchNorm-backward reduction (a.bn_z != NULL); its epilogue needs ~30 more registers, so the plain
+// launches get their own instance
+template <int NT, int MTW, int NW, bool HALF = false, int LAY = 1, bool BNZ = false>
 __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
     constexpr int NTHR = NW * 64;
     constexpr int KC = 16;                       // channels per chunk
@@ -771,38 +833,45 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
-    const int W = a.W, H = a.H, WT = (W + 1) >> 1, W2 = 2 * WT + 2, TH = aa.TH;
+    const int W = a.W, H = a.H, WT = (W + 1) >> 1, TH = aa.TH;
+    const int NP = (2 * WT + 2 + 15) >> 4;               // pieces per row
+    const int RP = NP * 256;                             // floats per row
     const int nrow = TH + 2;
-    const int xfloats = nrow * W2 * KC;
+    const int xfloats = nrow * RP;
     const int vid = aa.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int grp = vid / aa.nsplit, split = vid - grp * aa.nsplit;
     const int nt0 = split * NT;
-    float* xs0 = smem;                                   // [2][nrow][W2][KC]
-    float* ws0 = smem + 2 * xfloats;                     // [2 (1 if one chunk)][16][NT][64][4]
+    float* xs0 = smem;                                   // [2][nrow][NP][256]
+    float* ws0 = smem + 2 * xfloats;                     // [nchunk if resident, else 2 (1 if one chunk)][16][NT][64][4]
     const int band_lo = grp * aa.bands_per_wg;
     const int band_hi = min(band_lo + aa.bands_per_wg, aa.total_bands);
     if (band_lo >= band_hi) return;
     const int nchunk = a.nchunk;
+    const bool wres = aa.wres != 0;                      // all chunks' weights stay in LDS for the whole kernel (loaded with unit 0)
     const int nunits = (band_hi - band_lo) * nchunk;
-    const int ipr = (W + 15) >> 4;                       // DMA instructions per input row (16 pixels x 64 bytes each)
 
-    // ---- staging plan (see conv3x3_lds_k) ----
-    constexpr int TXF = 4;
-    constexpr int NWF = 16 * NT;                         // weight DMA instructions per unit: one fragment each
+    // ---- staging plan: slot i = (row, piece) of the unit's input rows, dealt round-robin over the waves; per slot the lane's byte
+    // offset from the unit's first input row and whether it fetches a real pixel (else: zeros).  Per unit that leaves one scalar row
+    // test, one select and one DMA instruction per slot. ----
+    constexpr int TXF = NW == 12 ? 3 : 4;                // slots planned in registers (any further: generic loop)
+    constexpr int NWF = 16 * NT;                         // weight fragments per chunk
     constexpr int TW = (NWF + NW - 1) / NW;
-    const int nx = nrow * ipr;
+    const int nx = nrow * NP;
+    int lp, lq;
+    wino_lane<LAY>(lane, lp, lq);
+    const char* zsrc = reinterpret_cast<const char*>(rv_zero_piece) + lane * 16;
     int xs_row[TXF], xs_ldst[TXF];
     unsigned xs_goff[TXF];
-    bool xs_lane[TXF];
+    bool xs_real[TXF];
 #pragma unroll
     for (int t = 0; t < TXF; ++t) {
         const int i = wave + NW * t;
-        const int row = i / ipr, k = i - row * ipr;
-        const int px = k * 16 + (lane >> 2), q = lane & 3;
+        const int row = i / NP, k = i - row * NP;
+        const int px = k * 16 + lp - 1;
         xs_row[t] = row;
-        xs_ldst[t] = (row * W2 + 1 + k * 16) * KC;
-        xs_goff[t] = (unsigned)((row * W + px) * a.in_ld + q * 4) * 4u;
-        xs_lane[t] = i < nx && px < W;
+        xs_ldst[t] = row * RP + k * 256;
+        xs_real[t] = px >= 0 && px < W;
+        xs_goff[t] = xs_real[t] ? (unsigned)((row * W + px) * a.in_ld + lq * 4) * 4u : 0u;
     }
     unsigned w_off[TW];
 #pragma unroll
@@ -823,27 +892,32 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
         for (int t = 0; t < TXF; ++t) {
             if (wave + NW * t >= nx) break;
             const int gy = sg_y0 - 1 + xs_row[t];
-            float* ldst = xb + xs_ldst[t];
-            if (gy >= 0 && gy < H) {
-                if (xs_lane[t]) glds16(reinterpret_cast<const float*>(src + xs_goff[t]), ldst);
-                ++issued;
-            } else if (xs_lane[t]) {
-                *reinterpret_cast<f32x4*>(ldst + lane * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
+            const bool rowok = gy >= 0 && gy < H;
+            glds16(reinterpret_cast<const float*>((rowok && xs_real[t]) ? src + xs_goff[t] : zsrc), xb + xs_ldst[t]);
+            ++issued;
         }
-        for (int i = wave + NW * TXF; i < nx; i += NW) {
-            const int row = i / ipr, k = i - row * ipr;
+        for (int i = wave + NW * TXF; i < nx; i += NW) {                    // narrow workgroups on wide rows
+            const int row = i / NP, k = i - row * NP;
             const int gy = sg_y0 - 1 + row;
-            const int px = k * 16 + (lane >> 2), q = lane & 3;
-            float* ldst = xb + (row * W2 + 1 + k * 16) * KC;
-            if (gy >= 0 && gy < H) {
-                if (px < W) glds16(reinterpret_cast<const float*>(src) + ((long)row * W + px) * a.in_ld + q * 4, ldst);
-                ++issued;
-            } else if (px < W) {
-                *reinterpret_cast<f32x4*>(ldst + lane * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
+            const int px = k * 16 + lp - 1;
+            const bool real = gy >= 0 && gy < H && px >= 0 && px < W;
+            const char* s = real ? src + ((long)(row * W + px) * a.in_ld + lq * 4) * 4 : zsrc;
+            glds16(reinterpret_cast<const float*>(s), xb + row * RP + k * 256);
+            ++issued;
         }
-        if (nchunk > 1 || sg_u == 0) {
+        if (wres) {
+            if (sg_u == 0) {
+                for (int c = 0; c < nchunk; ++c) {
+                    const char* wsrc = reinterpret_cast<const char*>(wino + (long)c * a.ntile_n * 256);
+#pragma unroll
+                    for (int t = 0; t < TW; ++t) {
+                        if (wave + NW * t >= NWF) break;
+                        glds16(reinterpret_cast<const float*>(wsrc + w_off[t]), ws0 + c * WFLOATS + (wave + NW * t) * 256);
+                        ++issued;
+                    }
+                }
+            }
+        } else if (nchunk > 1 || sg_u == 0) {
             float* wb = ws0 + ((nchunk > 1) ? sg_buf : 0) * WFLOATS;
             const char* wsrc = reinterpret_cast<const char*>(wino + (long)sg_c * a.ntile_n * 256);
 #pragma unroll
@@ -863,24 +937,14 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
         return issued;
     };
 
-    // halo columns (left: 1, right: W2 - 1 - W) of both buffers are zero for the whole kernel (the DMA never touches them)
-    {
-        const int nz = W2 - W;                           // column 0 and columns W+1 .. W2-1
-        for (int k = tid; k < 2 * nrow * nz * KC; k += NTHR) {
-            const int ch = k % KC; int t = k / KC;
-            const int zc = t % nz; t /= nz;
-            const int row = t % nrow, buf = t / nrow;
-            const int col = zc == 0 ? 0 : W + zc;
-            xs0[buf * xfloats + (row * W2 + col) * KC + ch] = 0.f;
-        }
-    }
-
+    typedef typename VecR<HALF ? 2 : 4>::T pvec;         // what one patch / weight read delivers
+    constexpr int NH = HALF ? 2 : 1;                     // passes over the chunk
+    constexpr int WD = (NT == 1 && NW <= 8) ? 3 : 2;     // weight-fragment ring: prefetch distance WD - 1 (register budget)
     f32x4 acc[MTW][NT][16];
-    int lbase[MTW], tyx[MTW];
+    int lb0[MTW], lb1[MTW], tyx[MTW];
     bool tv[MTW];
-    f32x4 bv[NT];
     __shared__ __attribute__((aligned(16))) float cf[4 * 64];
-    if (a.bn_z) {
+    if (BNZ) {
         for (int idx = tid; idx < 4 * NT * 16; idx += NTHR) {
             const int k = idx / (NT * 16), cl = idx - k * (NT * 16), ch = nt0 * 16 + cl;
             cf[k * 64 + cl] = ch < a.Cout ? a.bn_coef[k * a.Cout + ch] : 0.f;
@@ -889,12 +953,6 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
     f32x4 st1[NT], st2[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) st1[n] = st2[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int cb = (nt0 + n) * 16 + 4 * g;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bv[n][r] = (a.bias && cb + r < a.Cout) ? a.bias[cb + r] : 0.f;
-    }
     stage();
     int ahead = 0;
     int cu_buf = 0, cu_b = b_first, cu_y0 = y_first, cu_c = 0;
@@ -916,7 +974,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
                 const unsigned tt = tv[m] ? (unsigned)t : 0u;
                 const int ty = (int)fastdiv(tt, a.fd_pw), tx = (int)tt - ty * WT;       // fd_pw divides by WT here
                 tyx[m] = (ty << 16) | tx;
-                lbase[m] = ((2 * ty) * W2 + 2 * tx) * KC + g * 4;
+                lb0[m] = (2 * ty) * RP * 4 + wino_pair_off<LAY>(tx, g);
+                lb1[m] = (2 * ty) * RP * 4 + wino_pair_off<LAY>(tx + 1, g);
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -926,67 +985,76 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
         wait_vmcnt_le(ahead);
         if (!(ABL(aa) & 1)) __syncthreads();
         if (!(ABL(aa) & 2)) ahead = (sg_u < nunits) ? stage() : 0;
-        const float* xs = xs0 + buf * xfloats;
-        const float* ws = ws0 + ((nchunk > 1) ? buf : 0) * WFLOATS;
-        const unsigned ws_a = lds_addr(ws) + lane * 16;
+        const unsigned xs_a = lds_addr(xs0 + buf * xfloats);
+        const unsigned ws_a = lds_addr(ws0 + (wres ? c : ((nchunk > 1) ? buf : 0)) * WFLOATS) + lane * 16;
+        const unsigned rp4 = (unsigned)RP * 4u;
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
             if ((wave + NW * m) * 16 >= ntiles) continue;                   // wave-uniform: this tile group is beyond the band
-            typedef typename VecR<HALF ? 2 : 4>::T pvec;
-            constexpr int NR = HALF ? 2 : 4;             // k-steps per pass
-            const unsigned xa = lds_addr(xs) + lbase[m] * 4;
-#pragma unroll
-            for (int h = 0; h < (HALF ? 2 : 1); ++h) {
+            sfor<0, NH>([&](auto hc) {
+                constexpr int h = decltype(hc)::value;
                 pvec d[16];
-                pvec wf[2][NT];
-                if (ABL(aa) & 16) {
+                pvec wf[WD][NT];
+                unsigned ra[4][2];                                            // per patch row: address of the (even) pixel pairs tx, tx + 1
 #pragma unroll
-                    for (int e = 0; e < 16; ++e)
+                for (int er = 0; er < 4; ++er) {
+                    ra[er][0] = xs_a + lb0[m] + er * rp4;
+                    ra[er][1] = xs_a + lb1[m] + er * rp4;
+                }
+                // patch element (er, ec): pixel X = 2 tx + ec -> pair tx + (ec >> 1); the odd pixel of a pair sits 512 bytes behind the
+                // even one; HALF: second half-chunk 8 bytes into the quad.  All offsets are instruction immediates.
 #pragma unroll
-                        for (int r = 0; r < NR; ++r) d[e][r] = 1.f + e + r;
-                } else
-#pragma unroll
-                for (int e = 0; e < 16; ++e) lds_read(d[e], xa + ((e >> 2) * W2 + (e & 3)) * (KC * 4) + h * 8);
-#pragma unroll
-                for (int n = 0; n < NT; ++n) lds_read(wf[0][n], ws_a + n * 1024 + h * 8);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int er = 0; er < 4; ++er) {
+                    lds_read_o<h * 8>(d[er * 4 + 0], ra[er][0]);
+                    lds_read_o<512 + h * 8>(d[er * 4 + 1], ra[er][0]);
+                    lds_read_o<h * 8>(d[er * 4 + 2], ra[er][1]);
+                    lds_read_o<512 + h * 8>(d[er * 4 + 3], ra[er][1]);
+                }
+                // weight fragments: WD - 1 xi ahead of the multiplies
+                auto ldw = [&](auto xic) {
+                    constexpr int xi = decltype(xic)::value;
+                    sfor<0, NT>([&](auto nc) {
+                        constexpr int n = decltype(nc)::value;
+                        lds_read_o<(xi * NT + n) * 1024 + h * 8>(wf[xi % WD][n], ws_a);
+                    });
+                };
+                sfor<0, WD - 1>([&](auto xic) { ldw(xic); });
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((WD - 1) * NT) : "memory");      // the patch has landed
                 __builtin_amdgcn_sched_barrier(0);
-                // V = B^T d B, in place: rows then columns
-                if (!(ABL(aa) & 16))
+                // V = B^T d B, in place (rows, then columns); pk_add / pk_sub work on channel PAIRS: one v_pk_add_f32 each
+                if (!(ABL(aa) & 16)) {
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    const pvec d0 = d[cc], d1 = d[4 + cc], d2 = d[8 + cc], d3 = d[12 + cc];
-                    d[cc] = d0 - d2; d[4 + cc] = d1 + d2; d[8 + cc] = d2 - d1; d[12 + cc] = d1 - d3;
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const pvec e0 = d[cc], e1 = d[4 + cc], e2 = d[8 + cc], e3 = d[12 + cc];
+                        d[cc] = pk_sub(e0, e2); d[4 + cc] = pk_add(e1, e2); d[8 + cc] = pk_sub(e2, e1); d[12 + cc] = pk_sub(e1, e3);
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const pvec e0 = d[4 * rr], e1 = d[4 * rr + 1], e2 = d[4 * rr + 2], e3 = d[4 * rr + 3];
+                        d[4 * rr] = pk_sub(e0, e2); d[4 * rr + 1] = pk_add(e1, e2); d[4 * rr + 2] = pk_sub(e2, e1); d[4 * rr + 3] = pk_sub(e1, e3);
+                    }
                 }
-                if (!(ABL(aa) & 16))
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const pvec d0 = d[4 * rr], d1 = d[4 * rr + 1], d2 = d[4 * rr + 2], d3 = d[4 * rr + 3];
-                    d[4 * rr] = d0 - d2; d[4 * rr + 1] = d1 + d2; d[4 * rr + 2] = d2 - d1; d[4 * rr + 3] = d1 - d3;
-                }
-#pragma unroll
-                for (int xi = 0; xi < 16; ++xi) {
-                    if (xi + 1 < 16) {
-                        if (!(ABL(aa) & 32))
-#pragma unroll
-                        for (int n = 0; n < NT; ++n) lds_read(wf[(xi + 1) & 1][n], ws_a + ((xi + 1) * NT + n) * 1024 + h * 8);
-                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NT) : "memory");
+                sfor<0, 16>([&](auto xic) {
+                    constexpr int xi = decltype(xic)::value;
+                    if constexpr (xi + WD - 1 < 16) {
+                        if (!(ABL(aa) & 32)) ldw(std::integral_constant<int, xi + WD - 1>{});
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((WD - 1) * NT) : "memory");
                     } else {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((15 - xi) * NT) : "memory");
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (!(ABL(aa) & 4))
 #pragma unroll
-                    for (int r = 0; r < NR; ++r)
+                    for (int r = 0; r < (HALF ? 2 : 4); ++r)
 #pragma unroll
                         for (int n = 0; n < NT; ++n)
-                            acc[m][n][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[xi & 1][n][r], d[xi][r], acc[m][n][xi], 0, 0, 0);
+                            acc[m][n][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[xi % WD][n][r], d[xi][r], acc[m][n][xi], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                }
-            }
+                });
+            });
         }
         if (c != nchunk - 1 || (ABL(aa) & 8)) continue;
-        // ---- epilogue of this band: Y = A^T M A, then bias / statistics / store per output pixel ----
+        // ---- epilogue of this band: Y = A^T M A (packed math on channel pairs), then bias / statistics / store per output pixel ----
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
             if (!tv[m]) continue;
@@ -999,18 +1067,29 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
                 const int co0 = (nt0 + n) * 16 + 4 * g;
                 if (co0 >= a.Cout) continue;
                 f32x4 y[4];
-                {
-                    f32x4 s0[4], s1[4];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    f32x2 s0[4], s1[4];
+                    f32x2 bq;                       // bias of this lane's channel pair (once per band: not worth registers across the units)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) bq[r] = (a.bias && co0 + 2 * q + r < a.Cout) ? a.bias[co0 + 2 * q + r] : 0.f;
 #pragma unroll
                     for (int bb = 0; bb < 4; ++bb) {
-                        s0[bb] = acc[m][n][bb] + acc[m][n][4 + bb] + acc[m][n][8 + bb];
-                        s1[bb] = acc[m][n][4 + bb] - acc[m][n][8 + bb] - acc[m][n][12 + bb];
+                        const f32x2 m0 = (f32x2){acc[m][n][bb][2 * q], acc[m][n][bb][2 * q + 1]};
+                        const f32x2 m1 = (f32x2){acc[m][n][4 + bb][2 * q], acc[m][n][4 + bb][2 * q + 1]};
+                        const f32x2 m2 = (f32x2){acc[m][n][8 + bb][2 * q], acc[m][n][8 + bb][2 * q + 1]};
+                        const f32x2 m3 = (f32x2){acc[m][n][12 + bb][2 * q], acc[m][n][12 + bb][2 * q + 1]};
+                        s0[bb] = m0 + m1 + m2;
+                        s1[bb] = m1 - m2 - m3;
                     }
-                    y[0] = s0[0] + s0[1] + s0[2] + bv[n]; y[1] = s0[1] - s0[2] - s0[3] + bv[n];
-                    y[2] = s1[0] + s1[1] + s1[2] + bv[n]; y[3] = s1[1] - s1[2] - s1[3] + bv[n];
+                    const f32x2 y0_ = s0[0] + s0[1] + s0[2] + bq, y1_ = s0[1] - s0[2] - s0[3] + bq;
+                    const f32x2 y2_ = s1[0] + s1[1] + s1[2] + bq, y3_ = s1[1] - s1[2] - s1[3] + bq;
+                    y[0][2 * q] = y0_[0]; y[0][2 * q + 1] = y0_[1]; y[1][2 * q] = y1_[0]; y[1][2 * q + 1] = y1_[1];
+                    y[2][2 * q] = y2_[0]; y[2][2 * q + 1] = y2_[1]; y[3][2 * q] = y3_[0]; y[3][2 * q + 1] = y3_[1];
                 }
                 f32x4 z4[4];
-                if (a.bn_z) {
+                if (BNZ) {
+                    __builtin_amdgcn_sched_barrier(0);       // the accumulators are dead from here: keep the z loads behind the transform
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
                         z4[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1040,7 +1119,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
                                 o[r] = v[r];
                             }
                     }
-                    if (a.bn_z) {
+                    if (BNZ) {
                         const f32x4 mean4 = *reinterpret_cast<const f32x4*>(&cf[0 * 64 + n * 16 + 4 * g]);
                         const f32x4 inv4 = *reinterpret_cast<const f32x4*>(&cf[1 * 64 + n * 16 + 4 * g]);
                         const f32x4 sc4 = *reinterpret_cast<const f32x4*>(&cf[2 * 64 + n * 16 + 4 * g]);
@@ -2378,14 +2457,15 @@ static int launch_conv3x3_lds(const ConvArgs& a, int R, hipStream_t st, int forc
 
 // Winograd launch (families 0x6NM: 8 waves, 0xANM / 0xCNM: 8 / 12 waves with the half-chunk patch): a band of TH (even) rows holds (TH/2) x ceil(W/2) tiles of 2x2 outputs,
 // NW x MTW groups of 16 tiles per unit.  force_th = 0: as many rows as the tile slots hold.
-static size_t conv3x3_wino_bytes(int NT, int TH, int W, int nchunk) {
-    const int W2 = 2 * ((W + 1) / 2) + 2;
-    return ((size_t)2 * (TH + 2) * W2 * 16 + (size_t)(nchunk > 1 ? 2 : 1) * 16 * NT * 256) * sizeof(float);
+static size_t conv3x3_wino_bytes(int NT, int TH, int W, int wbufs) {
+    const int NP = (2 * ((W + 1) / 2) + 2 + 15) / 16;            // 1 KiB pieces (16 pixels x 16 channels) per staged row
+    return (size_t)2 * (TH + 2) * NP * 1024 + (size_t)wbufs * 16 * NT * 1024;
 }
 
-template <int NW, bool HALF = false>
+template <int NW, bool HALF = false, int LAY = 1>
 static int launch_conv3x3_wino(const ConvArgs& a0, int NT, int MTW, int force_th, hipStream_t st) {
     if (NT < 1 || a0.ntile_n % NT) return RV_EUNSUPPORTED;
+    if (NW == 12 && a0.bn_z) return RV_EUNSUPPORTED;      // the fused BatchNorm-backward epilogue does not fit three waves per SIMD without scratch
     ConvLdsArgs aa;
     aa.c = a0;
     const int WT = (a0.W + 1) / 2;
@@ -2398,7 +2478,21 @@ static int launch_conv3x3_wino(const ConvArgs& a0, int NT, int MTW, int force_th
         if (force_th > TH || (force_th & 1)) return RV_EUNSUPPORTED;
         TH = force_th;
     }
-    const size_t lds = conv3x3_wino_bytes(NT, TH, a0.W, a0.nchunk);
+    // weights: resident for the whole kernel when all chunks fit next to the two band buffers (no weight DMA after unit 0, 16 NT KiB less
+    // L2 traffic per unit); else double-buffered per chunk like the band
+    static const int wres_env = getenv("RV_WINO_WRES") ? atoi(getenv("RV_WINO_WRES")) : 1;
+    aa.wres = 0;
+    size_t lds = conv3x3_wino_bytes(NT, TH, a0.W, a0.nchunk > 1 ? 2 : 1);
+    // "as many rows as the tile slots hold" (force_th == 0) also means: as many as the LDS holds (a staged row is a whole number of
+    // 1 KiB pieces, so e.g. a 114-pixel row takes 8 KiB)
+    while (!force_th && lds > 154 * 1024 && TH > 2) {
+        TH -= 2;
+        lds = conv3x3_wino_bytes(NT, TH, a0.W, a0.nchunk > 1 ? 2 : 1);
+    }
+    if (a0.nchunk > 1 && wres_env) {
+        const size_t lds_res = conv3x3_wino_bytes(NT, TH, a0.W, a0.nchunk);
+        if (lds_res <= 154 * 1024) { aa.wres = 1; lds = lds_res; }
+    }
     if (lds > 154 * 1024) return RV_EUNSUPPORTED;
     aa.TH = TH; aa.nbands = cdiv(a0.H, TH);
     aa.total_bands = a0.B * aa.nbands;
@@ -2415,14 +2509,16 @@ static int launch_conv3x3_wino(const ConvArgs& a0, int NT, int MTW, int force_th
     dim3 grid(wgs * nsplit), blk(NW * 64);
 #define RV_WN(nt, mt)                                                                              \
     if (NT == nt && MTW == mt) {                                                                  \
-        auto kern = conv3x3_wino_k<nt, mt, NW, HALF>;                                             \
         static bool attr_done = false;                                                            \
         if (!attr_done) {                                                                         \
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) \
+            if (hipFuncSetAttribute((const void*)conv3x3_wino_k<nt, mt, NW, HALF, LAY, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) \
+                (void)hipGetLastError();                                                          \
+            if (hipFuncSetAttribute((const void*)conv3x3_wino_k<nt, mt, NW, HALF, LAY, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) \
                 (void)hipGetLastError();                                                          \
             attr_done = true;                                                                     \
         }                                                                                         \
-        hipLaunchKernelGGL(kern, grid, blk, lds, st, aa);                                         \
+        if (a0.bn_z) hipLaunchKernelGGL((conv3x3_wino_k<nt, mt, NW, HALF, LAY, true>), grid, blk, lds, st, aa);  \
+        else hipLaunchKernelGGL((conv3x3_wino_k<nt, mt, NW, HALF, LAY, false>), grid, blk, lds, st, aa);         \
         return RV_OK;                                                                             \
     }
     // (instantiated: the tiles that fit the register file without scratch -- 64 accumulator registers per (tile group, n-tile) pair)
@@ -2669,8 +2765,15 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
     const int fam = (algo >> 8) & 15, f_nt = (algo >> 4) & 15, f_mt = algo & 15, f_th = (algo >> 12) & 255;
     if (fam == 6 || fam == 10 || fam == 12) {   // Winograd F(2x2,3x3): 0x6NM = 8 waves, 0xANM = 8 waves + half-chunk patch, 0xCNM = 12 waves + half-chunk patch
         if (mode != 0 || R != 4) { rv_set_error("rv_conv_fwd: the Winograd kernel needs a 3x3 conv with Cin %% 16 == 0"); return RV_EUNSUPPORTED; }
-        const int rcw = fam == 6 ? launch_conv3x3_wino<8>(a, f_nt, f_mt, f_th, st)
-                      : (fam == 10 ? launch_conv3x3_wino<8, true>(a, f_nt, f_mt, f_th, st) : launch_conv3x3_wino<12, true>(a, f_nt, f_mt, f_th, st));
+        // (RV_WINO_LAYOUT=0: the 2-way-conflict even / odd plane image instead of the conflict-free one -- A/B experiments only)
+        static const int lay_env = getenv("RV_WINO_LAYOUT") ? atoi(getenv("RV_WINO_LAYOUT")) : 1;
+        int rcw;
+        if (lay_env == 0)
+            rcw = fam == 6 ? launch_conv3x3_wino<8, false, 0>(a, f_nt, f_mt, f_th, st)
+                           : (fam == 10 ? launch_conv3x3_wino<8, true, 0>(a, f_nt, f_mt, f_th, st) : launch_conv3x3_wino<12, true, 0>(a, f_nt, f_mt, f_th, st));
+        else
+            rcw = fam == 6 ? launch_conv3x3_wino<8>(a, f_nt, f_mt, f_th, st)
+                           : (fam == 10 ? launch_conv3x3_wino<8, true>(a, f_nt, f_mt, f_th, st) : launch_conv3x3_wino<12, true>(a, f_nt, f_mt, f_th, st));
         if (rcw != RV_OK) { rv_set_error("rv_conv_fwd: forced Winograd tile NT=%d MTW=%d TH=%d does not fit", f_nt, f_mt, f_th); return rcw; }
         RV_LAUNCH_CHECK("rv_conv_fwd(winograd)");
         *sums_done = true;

@@ -224,7 +224,9 @@ WINO_CASES = [(16, 16, 12, 229, 0x611), (32, 32, 22, 114, 0x611), (64, 64, 31, 5
               (96, 48, 21, 57, 0x611), (48, 24, 10, 114, 0x611), (32, 16, 3, 17, 0x611), (64, 32, 20, 57, 0xa11), (16, 16, 6, 57, 0xa11),
               (32, 32, 24, 114, 0x4611), (64, 64, 16, 28, 0x2611), (16, 8, 8, 229, 0x611),
               (32, 32, 22, 114, 0xa21), (64, 64, 31, 57, 0xa21), (128, 128, 40, 28, 0x8a21), (96, 64, 21, 57, 0xa21), (16, 16, 12, 229, 0xa11), (48, 48, 9, 57, 0xa11),
-              (64, 64, 31, 57, 0xac11), (16, 16, 12, 229, 0xc11), (128, 128, 40, 28, 0xc11), (32, 16, 9, 114, 0x4c11)]
+              (64, 64, 31, 57, 0xac11), (16, 16, 12, 229, 0xc11), (128, 128, 40, 28, 0xc11), (32, 16, 9, 114, 0x4c11),
+              # round 4: rows of exactly one / two 1 KiB pieces, weights too large to stay resident (double-buffered per chunk), resident at 4 chunks
+              (128, 128, 10, 14, 0x611), (32, 32, 8, 30, 0x611), (192, 96, 20, 28, 0x611), (64, 48, 12, 57, 0xa11), (192, 64, 9, 28, 0xc11)]
 
 
 @pytest.mark.parametrize('cin,cout,H,W,algo', WINO_CASES)
@@ -283,7 +285,23 @@ def test_conv3x3_winograd_accumulate_and_colsum(dev, cin, cout, H, W, algo, monk
 
 
 @pytest.mark.parametrize('c1,c2,H,W,algo', [(16, 16, 12, 37, 0), (24, 16, 9, 57, 0x211), (64, 32, 8, 28, 0x321), (8, 2, 6, 19, 0), (8, 2, 37, 300, 0), (32, 32, 8, 30, 1),
-                                            (24, 16, 11, 114, 0x713), (64, 24, 9, 57, 0x726), (32, 32, 11, 114, 0x611), (16, 16, 9, 57, 0x611), (48, 32, 8, 28, 0xa11), (64, 64, 12, 57, 0xa21), (32, 32, 10, 57, 0xc11)])
+                                            (24, 16, 11, 114, 0x713), (64, 24, 9, 57, 0x726), (32, 32, 11, 114, 0x611), (16, 16, 9, 57, 0x611), (48, 32, 8, 28, 0xa11), (64, 64, 12, 57, 0xa21), (48, 48, 14, 229, 0x611), (96, 32, 9, 114, 0xa11)])
+def test_winograd_12_wave_tile_refuses_the_fused_bn_backward(dev, monkeypatch):
+    """Three waves per SIMD leave 168 registers: the fused BatchNorm-backward epilogue of the Winograd kernel does not fit them without
+    scratch, so that combination is refused (the tuner never offers it) instead of silently spilling."""
+    from reconvat_amd import ops, _lib
+    monkeypatch.setenv('RV_FORCE_ALGO', '0xc11')
+    x = torch.rand(2, 10, 57, 32, device=dev)
+    w = torch.rand(32, 32, 3, 3, device=dev)
+    link = ops.BnLink()
+    z = torch.rand(2, 10, 57, 32, device=dev)
+    link.z, link.coef, link.ws, link.slope = z, torch.rand(5 * 32, device=dev), torch.zeros(ops.bn_ws_doubles(32), dtype=torch.float64, device=dev), 0.01
+    with pytest.raises(RuntimeError, match='does not fit'):
+        ops.conv_dgrad_into('c3', x, w, torch.empty_like(x), bn_link=link)
+    ops.conv_dgrad_into('c3', x, w, torch.empty_like(x))           # ... the plain launch of the same tile is fine
+    torch.cuda.synchronize()
+
+
 def test_conv_dgrad_fused_bn_backward_reduction(dev, c1, c2, H, W, algo, monkeypatch):
     """conv2(lrelu(bn(z))): with a BnLink the input-gradient kernel of conv2 also produces the BatchNorm's backward
     reduction (epilogue of the persistent kernel, reduction pass behind the others); gradients must not change."""
