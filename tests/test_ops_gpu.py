@@ -284,8 +284,6 @@ def test_conv3x3_winograd_accumulate_and_colsum(dev, cin, cout, H, W, algo, monk
     assert rel_err(outs[0][2], outs[1][2]) < 1e-5
 
 
-@pytest.mark.parametrize('c1,c2,H,W,algo', [(16, 16, 12, 37, 0), (24, 16, 9, 57, 0x211), (64, 32, 8, 28, 0x321), (8, 2, 6, 19, 0), (8, 2, 37, 300, 0), (32, 32, 8, 30, 1),
-                                            (24, 16, 11, 114, 0x713), (64, 24, 9, 57, 0x726), (32, 32, 11, 114, 0x611), (16, 16, 9, 57, 0x611), (48, 32, 8, 28, 0xa11), (64, 64, 12, 57, 0xa21), (48, 48, 14, 229, 0x611), (96, 32, 9, 114, 0xa11)])
 def test_winograd_12_wave_tile_refuses_the_fused_bn_backward(dev, monkeypatch):
     """Three waves per SIMD leave 168 registers: the fused BatchNorm-backward epilogue of the Winograd kernel does not fit them without
     scratch, so that combination is refused (the tuner never offers it) instead of silently spilling."""
@@ -302,6 +300,8 @@ def test_winograd_12_wave_tile_refuses_the_fused_bn_backward(dev, monkeypatch):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize('c1,c2,H,W,algo', [(16, 16, 12, 37, 0), (24, 16, 9, 57, 0x211), (64, 32, 8, 28, 0x321), (8, 2, 6, 19, 0), (8, 2, 37, 300, 0), (32, 32, 8, 30, 1),
+                                            (24, 16, 11, 114, 0x713), (64, 24, 9, 57, 0x726), (32, 32, 11, 114, 0x611), (16, 16, 9, 57, 0x611), (48, 32, 8, 28, 0xa11), (64, 64, 12, 57, 0xa21), (48, 48, 14, 229, 0x611), (96, 32, 9, 114, 0xa11)])
 def test_conv_dgrad_fused_bn_backward_reduction(dev, c1, c2, H, W, algo, monkeypatch):
     """conv2(lrelu(bn(z))): with a BnLink the input-gradient kernel of conv2 also produces the BatchNorm's backward
     reduction (epilogue of the persistent kernel, reduction pass behind the others); gradients must not change."""
