@@ -387,8 +387,8 @@ def _cpu_steps(threads, budget_s, min_timed=3, max_timed=3, batch=1):
 def cpu_baseline():
     """The oracle (CPU restatement pinned to the reference by tests/golden) timed on this host's cores: one labelled + one
     unlabelled full-length segment per step (B = 1 + 1: a bounded sample of the B = 8 + 8 workload, same step definition:
-    front-end, 2 x VAT, forward, backward, Adam), 1 warm-up + 3 timed steps at 8 threads and at all physical cores
-    (BASELINE.md section 4).  `value` is the faster of the two."""
+    front-end, 2 x VAT, forward, backward, Adam) at 8 threads, and the workload's own B = 8 + 8 at 8 / 32 / 64 threads (capped at
+    the physical core count); `value` is the fastest of them, every run is listed."""
     try:
         import psutil
         physical = psutil.cpu_count(logical=False) or os.cpu_count()
@@ -396,15 +396,16 @@ def cpu_baseline():
         physical = os.cpu_count()
     prev = torch.get_num_threads()
     runs = []
-    for n in sorted({min(8, physical), physical}):
-        per_step, timed = _cpu_steps(n, budget_s=60.0)
-        runs.append({'threads': n, 'batch': '1+1', 's_per_step': round(per_step, 3), 'timed_steps': timed,
-                     'audio_s_per_s': round(2 * SEG_SECONDS / per_step, 3)})
-    # the workload's own batch (B_l = B_ul = 8, SURVEY 8(d): "same synthetic inputs, same step definition") at 8 threads: 1 warm-up +
-    # 2 timed steps of ~10-15 s
-    per_step, timed = _cpu_steps(min(8, physical), budget_s=20.0, min_timed=2, max_timed=2, batch=8)
-    runs.append({'threads': min(8, physical), 'batch': '8+8', 's_per_step': round(per_step, 3), 'timed_steps': timed,
-                 'audio_s_per_s': round(16 * SEG_SECONDS / per_step, 3)})
+    per_step, timed = _cpu_steps(min(8, physical), budget_s=30.0)
+    runs.append({'threads': min(8, physical), 'batch': '1+1', 's_per_step': round(per_step, 3), 'timed_steps': timed,
+                 'audio_s_per_s': round(2 * SEG_SECONDS / per_step, 3)})
+    # the workload's own batch (B_l = B_ul = 8, SURVEY 8(d): "same synthetic inputs, same step definition") at 8, 32 and 64 threads
+    # (never more than the physical cores; all 128+ logical CPUs at once is an oversubscription artefact, 7x slower than 8 threads
+    # in rounds 1-3): 1 warm-up + 2 timed steps each
+    for n in sorted({min(8, physical), min(32, physical), min(64, physical)}):
+        per_step, timed = _cpu_steps(n, budget_s=20.0, min_timed=2, max_timed=2, batch=8)
+        runs.append({'threads': n, 'batch': '8+8', 's_per_step': round(per_step, 3), 'timed_steps': timed,
+                     'audio_s_per_s': round(16 * SEG_SECONDS / per_step, 3)})
     torch.set_num_threads(prev)
     best = max(runs, key=lambda r: r['audio_s_per_s'])
     return {'value': best['audio_s_per_s'], 'unit': 'audio-s/s', 'cores': best['threads'], 'kind': 'port',
@@ -690,20 +691,35 @@ def main():
                     print(f'[conv] {t:8.3f} ms/step  x{c:3d}  {m_:8.4f} ms  {tf:7.1f} TF/s  {sg}', file=sys.stderr)
             # HBM bytes of the same launches from the committed PMC passes (rocprofv3 cannot run inside this process):
             # tools/pmc_traffic.py over separate FETCH_SIZE / WRITE_SIZE runs of `bench.py --no-graph`, gfx950-corrected
-            traffic, traffic_src = None, None
-            for cand in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
-                tpath = os.path.join(ROOT, 'profiles', cand)
+            traffic, traffic_src, traffic_digest, two_stream = None, None, None, None
+            for rnd in ('r04', 'r03', 'r02', 'r01'):
+                tpath = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_traffic.json')
                 if os.path.exists(tpath):
                     with open(tpath) as fh:
                         tj = json.load(fh)
-                    traffic, traffic_src = tj.get('traffic_bytes'), f"profiles/{cand} (committed PMC pass, {tj.get('git', 'commit not recorded')})"
+                    traffic, traffic_digest = tj.get('traffic_bytes'), tj.get('kernel_plan_table')
+                    traffic_src = f"profiles/{rnd}_pmc_traffic.json (committed PMC pass, {tj.get('git', 'commit not recorded')})"
                     break
+            # the conv fraction INSIDE the shipped two-stream schedule: rocprofv3 kernel-trace of the timed command, summed by
+            # tools/rocpd_stats.py (committed table; a profiler cannot run inside this process)
+            for rnd in ('r04',):
+                spath = os.path.join(ROOT, 'profiles', f'{rnd}_two_stream_conv.json')
+                if os.path.exists(spath):
+                    with open(spath) as fh:
+                        two_stream = json.load(fh)
+                    two_stream['source'] = f'profiles/{rnd}_two_stream_conv.json (tools/rocpd_stats.py --json over profiles/{rnd}_step_kernel_stats.txt\'s trace)'
             families = measure_families(eager, device)
             line['roofline'] = {
                 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,
                 'traffic_scope': 'HBM bytes (FETCH_SIZE x2 + WRITE_SIZE) of all conv launches of one step; NOT measured by this run: '
                                  + str(traffic_src),
+                # the PMC pass ran the tile table with this digest; a mismatch means the committed traffic figure describes other tiles
+                'traffic_plan_table': traffic_digest, 'traffic_plan_table_matches': (traffic_digest == plans.digest()) if traffic_digest else None,
+                # executed conv flops / summed conv kernel time of the SHIPPED two-stream schedule (kernels stretched by the concurrent chain)
+                'frac_two_stream': (round(conv_flops_total / (two_stream['conv_ms_per_step'] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
+                                    if two_stream else None),
+                'two_stream': two_stream,
                 'kernel': 'conv3x3_lds_k / conv_mfma_k / wgrad_mfma_k family (all conv launches of one step)',
                 'conv_ms_source': 'isolated re-launch of every distinct conv launch of one step, HIP events on the launch stream, after the '
                                   f'timed loop, operands ROTATED through >= {min_sets} scratch sets totalling > 256 MiB per launch shape (no launch finds '

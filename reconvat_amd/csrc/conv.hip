@@ -1750,7 +1750,12 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
 #pragma unroll
                 for (int kx = 0; kx < KW; ++kx)
 #pragma unroll
-                    for (int ta = 0; ta < TAW; ++ta) uf[ky * KW + kx][ta] = ur[kx * CA + (hp * TAW + ta) * 16];
+                    for (int ta = 0; ta < TAW; ++ta) {
+#ifdef RV_ABLATION
+                        if ((ABL(a) & 256) && ky * KW + kx >= 4) { uf[ky * KW + kx][ta] = 0.f; continue; }   // probe: 4 + TB reads per k-step
+#endif
+                        uf[ky * KW + kx][ta] = ur[kx * CA + (hp * TAW + ta) * 16];
+                    }
             }
         };
         auto mm = [&](const float (&vf)[TB], const float (&uf)[TAPS][TAW]) {
@@ -1761,6 +1766,25 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
                     for (int ta = 0; ta < TAW; ++ta) acc[t][ta][0][0] += uf[t][ta] * vf[0] + vf[TB - 1];
                 return;
             }
+#ifdef RV_ABLATION
+            if (ABL(a) & 256) {                               // Winograd F(3x3, 2x2) cost probe: 4 of 9 MFMA groups per k-step (16 per 4 tiles) ...
+                float vv[TB];
+#pragma unroll
+                for (int tb = 0; tb < TB; ++tb) vv[tb] = vf[tb];
+                if (ABL(a) & 512) {                           // ... plus the transform adds of both operands (56 per 4 tiles = 14 per k-step)
+#pragma unroll
+                    for (int q = 0; q < 14; ++q) asm volatile("v_add_f32 %0, %0, %1" : "+v"(vv[q % TB]) : "v"(uf[q % TAPS][0]));
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int ta = 0; ta < TAW; ++ta)
+#pragma unroll
+                        for (int tb = 0; tb < TB; ++tb)
+                            acc[t][ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[t][ta], vv[tb], acc[t][ta][tb], 0, 0, 0);
+                return;
+            }
+#endif
 #pragma unroll
             for (int t = 0; t < TAPS; ++t)
 #pragma unroll

@@ -95,8 +95,31 @@ class deferred_bn_updates:
             call('rv_bn_running_update', ptr(rm), ptr(rv), ptr(nbt), ptr(coef), c, BN_MOMENTUM, stream())
 
 
-_REPLAY_KEEP = []          # pinned host tables of captured replays must outlive their hipGraph
+_REPLAY_KEEP = []          # pinned host tables of captured replays must outlive their hipGraph (captures outside any keep_scope)
 _REPLAY_POOL = []          # pre-allocated pinned staging buffers for capture
+
+# Objects a hipGraph capture pins (host tables a captured copy node re-reads at every replay, their device copies) must live exactly
+# as long as the graph.  A capture runs inside `keep_scope(owner_list)`: everything pinned during it lands in the OWNER's list
+# (TrainStep._keep), which is dropped together with the graph -- so a process may capture and drop any number of steps without
+# growing.  Outside a scope the module-level lists above keep the objects for the life of the process (one-off captures in tests).
+_KEEP_SCOPE = [None]
+
+
+class keep_scope:
+    def __init__(self, owner_list):
+        self.owner = owner_list
+
+    def __enter__(self):
+        self.prev = _KEEP_SCOPE[0]
+        _KEEP_SCOPE[0] = self.owner
+        return self.owner
+
+    def __exit__(self, *exc):
+        _KEEP_SCOPE[0] = self.prev
+
+
+def _keep(obj, fallback):
+    (_KEEP_SCOPE[0] if _KEEP_SCOPE[0] is not None else fallback).append(obj)
 
 
 def prepare_replay_pool(n=4):
@@ -132,7 +155,7 @@ def replay_bn_updates(pendings, device):
         if not _REPLAY_POOL:
             raise RuntimeError('replay_bn_updates: no pinned staging buffer left for hipGraph capture')
         host = _REPLAY_POOL.pop()
-        _REPLAY_KEEP.append(host)
+        _keep(host, _REPLAY_KEEP)
         assert len(words) <= host.numel(), 'BatchNorm replay table larger than the staging buffer'
         host[:len(words)] = torch.tensor(words, dtype=torch.int64)
     else:
@@ -142,7 +165,7 @@ def replay_bn_updates(pendings, device):
     call('rv_bn_running_update_table', ptr(table), len(order), BN_MOMENTUM, stream())
     table.record_stream(torch.cuda.current_stream(device))
     if capturing:
-        _REPLAY_KEEP.append(table)             # keep the device copy's memory out of the graph pool's reuse
+        _keep(table, _REPLAY_KEEP)             # keep the device copy's memory out of the graph pool's reuse
 
 
 
@@ -298,6 +321,9 @@ class PackPlan:
     def __init__(self, device):
         import ctypes
         lib = _lib.load()
+        # packs of weights that were not refreshed for a while belong to models that are gone: drop them (they hold the weight alive)
+        for k in [k for k, v in _pack_cache.items() if v[0][0] < _EPOCH[0] - 64]:
+            del _pack_cache[k]
         self.entries = [(k, v) for k, v in _pack_cache.items() if v[2].device == device]
         self.count = len(self.entries)
         if not self.count:
@@ -373,15 +399,18 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
     if os.environ.get('RV_FORCE_ALGO') and (mode == 0 or os.environ.get('RV_FORCE_ALGO_ALL')):   # kernel experiments
         algo = int(os.environ['RV_FORCE_ALGO'], 0)
     elif AUTOTUNE and cin % 8 == 0 and (cout > 2 or mode == 3):     # (the small-channel VALU kernels have one form)
-        key = (mode, bb, h, wd, cin, cout, ild, old, stats is not None, bnbwd is not None)
-        if bf16 and AUTOTUNE is True:
-            key = key + ('bf16',)                                   # the on-line tuner times the bf16 kernel separately
+        base_key = (mode, bb, h, wd, cin, cout, ild, old, stats is not None, bnbwd is not None)
+        # the bf16-operand variant of a shape is its own cache entry in every mode: its tile may differ from the fp32 one (the fp32
+        # Winograd tiles have no bf16 form), and a bf16 launch must never overwrite what the fp32 launches of the same shape run
+        key = base_key + ('bf16',) if bf16 else base_key
         algo = _algo_cache.get(key, -1)
         if algo < 0 and AUTOTUNE == 'table':
-            hit = plans.lookup_conv(key)
+            hit = plans.lookup_conv(base_key)
             algo = hit[0] if hit is not None else 0
+            if bf16 and (algo >> 8) & 15 in (6, 10, 12):
+                algo = 0                        # fp32 Winograd tile: the bf16 launch of this shape runs the library-default direct tile
             _algo_cache[key] = algo
-            if hit is not None and not hit[1]:
+            if hit is not None and not hit[1] and algo != 0:
                 _algo_unchecked.add(key)
         if algo < 0:
             if torch.cuda.is_current_stream_capturing():
@@ -467,7 +496,7 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
                 return
             algo = _algo_cache[key] = 0         # the borrowed tile does not fit this batch size: library default
     if bf16 and (algo >> 8) & 15 in (6, 10, 12):
-        algo = 0                                # the fp32 Winograd tile of this shape has no bf16 form: library-default direct tile
+        algo = 0                                # (forced / on-line tuned Winograd tile: no bf16 form -> library-default direct tile)
     if bf16 and algo not in (1,) and (algo >> 8) & 15 != 1:
         algo |= ALGO_BF16                       # (the library ignores the bit outside the persistent 3x3 kernel / 16-channel chunks)
     call('rv_conv_fwd', *args, algo, ptr(stats), *tail, stream())
@@ -677,7 +706,7 @@ class _WgradTable:
             if not _WGRAD_POOL:
                 raise RuntimeError('deferred_wgrad_reductions: no pinned table left for hipGraph capture')
             self.host = _WGRAD_POOL.pop()
-            _WGRAD_KEEP.append(self.host)
+            _keep(self.host, _WGRAD_KEEP)
             self.pinned = True
         else:
             self.host = torch.empty(_WGRAD_MAX * self.eb, dtype=torch.uint8)
@@ -700,7 +729,7 @@ class _WgradTable:
             call('rv_wgrad_reduce_table', ptr(table), self.n, total, self.stream.cuda_stream)
             table.record_stream(self.stream)
             if self.pinned:
-                _WGRAD_KEEP.append(table)      # captured: keep the device copy's memory out of the graph pool's reuse
+                _keep(table, _WGRAD_KEEP)      # captured: keep the device copy's memory out of the graph pool's reuse
         self.n, self.keep = 0, []
 
 
@@ -956,7 +985,7 @@ def _tune_gemm(key, launch, m, n, k, cands=(1, 2, 3, 4, 6, 8, 12, 16, 24, 32)):
 
 
 def gemm(a, b_kn, c, bias=None, act=0, accumulate=False, splitk=None, c2=None, batch=1, bstrides=(0, 0, 0), a_rowsum=None,
-         deterministic=True):
+         deterministic=True, defer_ok=False):
     """c[m,n] (+)= act(sum_k a[m,k] * b_kn[k,n] + bias[n]) on arbitrary 2-D views.  batch > 1: `batch` problems of this
     shape, problem z offset by z * bstrides (elements) from a / b_kn / c.  splitk None: the shipped plan table's factor for this
     shape (ops.AUTOTUNE == 'table'), the on-line tuner's (True), else the library heuristic; the reduction over k slices is
@@ -982,7 +1011,7 @@ def gemm(a, b_kn, c, bias=None, act=0, accumulate=False, splitk=None, c2=None, b
         call('rv_gemm', pa, sam, sak, pb, sbk, sbn, pc_, scm, scn, pc2, s2m, s2n, ptr(bias), m, n, k, act,
              1 if accumulate else 0, s, batch, bstrides[0], bstrides[1], bstrides[2], rs, ptr(ws), ptr(tk), stream())
 
-    deferrable = accumulate and not deterministic and bias is None and act == 0 and c2 is None and _GEMM_DEFER[0] is not None
+    deferrable = defer_ok and accumulate and not deterministic and bias is None and act == 0 and c2 is None and _GEMM_DEFER[0] is not None
     if splitk is None:
         key = (m, n, k, batch, int(sak <= sam), int(sbk <= sbn), act, int(bool(accumulate)) + 2 * int(bool(deterministic)))
         splitk = _gemm_splitk.get(key)
@@ -1033,7 +1062,7 @@ class _GemmTable:
             if not _GEMM_POOL:
                 raise RuntimeError('deferred_param_gemms: no pinned table left for hipGraph capture')
             self.host = _GEMM_POOL.pop()
-            _GEMM_KEEP.append(self.host)
+            _keep(self.host, _GEMM_KEEP)
             self.pinned = True
         else:
             self.host = torch.empty(_GEMM_MAX * self.eb, dtype=torch.uint8)
@@ -1050,7 +1079,7 @@ class _GemmTable:
             call('rv_gemm_table_run', ptr(table), self.n, total, self.orientation, self.stream.cuda_stream)
             table.record_stream(self.stream)
             if self.pinned:
-                _GEMM_KEEP.append(table)       # captured: keep the device copy's memory out of the graph pool's reuse
+                _keep(table, _GEMM_KEEP)       # captured: keep the device copy's memory out of the graph pool's reuse
             if KEEP_TABLES[0]:
                 _GEMM_KEEP.append((table, self.keep))
                 GEMM_TABLE_WORK[table.data_ptr()] = (self.flops, self.bytes)
@@ -1121,11 +1150,11 @@ def _param_wgrad(a_t, b, param, splitk=None, bias_param=None):
     if bias_param is not None:
         gb = _grad_buf(bias_param)
         if g is not None and gb is not None:
-            gemm(a_t, b, g.view(a_t.shape[0], b.shape[1]), accumulate=True, splitk=splitk, a_rowsum=gb, deterministic=False)
+            gemm(a_t, b, g.view(a_t.shape[0], b.shape[1]), accumulate=True, splitk=splitk, a_rowsum=gb, deterministic=False, defer_ok=True)
             return None, True
         return _param_wgrad(a_t, b, param, splitk), False
     if g is not None:
-        gemm(a_t, b, g.view(a_t.shape[0], b.shape[1]), accumulate=True, splitk=splitk, deterministic=False)
+        gemm(a_t, b, g.view(a_t.shape[0], b.shape[1]), accumulate=True, splitk=splitk, deterministic=False, defer_ok=True)
         return None
     dw = torch.empty((a_t.shape[0], b.shape[1]), device=b.device, dtype=torch.float32)
     gemm(a_t, b, dw, splitk=splitk, deterministic=False)
@@ -1311,7 +1340,7 @@ class LocalAttnFn(Function):
         if ctx.needs_input_grad[1]:
             gk, gq, gv = _grad_buf(pwk), _grad_buf(pwq), _grad_buf(pwv)
             if fused and _adjacent(gk, gq, gv):
-                gemm(dqkv.t(), x2, torch.as_strided(gk, (3 * f, fin), (fin, 1)), accumulate=True, deterministic=False)
+                gemm(dqkv.t(), x2, torch.as_strided(gk, (3 * f, fin), (fin, 1)), accumulate=True, deterministic=False, defer_ok=True)
             elif fused:
                 dw3 = torch.empty((3 * f, fin), device=x2.device, dtype=torch.float32)
                 gemm(dqkv.t(), x2, dw3, deterministic=False)
@@ -1328,7 +1357,8 @@ class LocalAttnFn(Function):
             drel = grel.view(f, 31) if direct else torch.zeros((f, 31), device=q.device, dtype=torch.float32)
             de2 = de.view(m, g, 31)
             # one batched split-K launch over the heads: head h reads q[:, h*dh:], de[:, h, :], writes drel[h*dh:]
-            gemm(q[:, :dh].t(), de2[:, 0, :], drel[:dh], accumulate=True, deterministic=False, batch=g, bstrides=(dh, 31, dh * 31))
+            gemm(q[:, :dh].t(), de2[:, 0, :], drel[:dh], accumulate=True, deterministic=False, batch=g, bstrides=(dh, 31, dh * 31),
+                 defer_ok=direct)       # (a zero-filled temporary handed back to autograd is filled NOW, never by a deferred launch)
             drel = None if direct else drel.view_as(rel)
         return dx, dwq, dwk, dwv, drel, None
 

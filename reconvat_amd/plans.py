@@ -11,8 +11,11 @@ fp32 summation order), and results are reproducible run to run.
     ops.AUTOTUNE = True      RV_AUTOTUNE=1  time every legal tile on the first eager call of a shape (how the table is made)
     ops.AUTOTUNE = False     RV_AUTOTUNE=0  library default tiles everywhere
 
-A shape keyed at another batch size than the table's (B = 8) falls back to the entry of the same layer geometry: tile legality
-does not depend on B (checked at first use; an illegal tile falls back to the library default).
+A shape keyed at another batch size than the table's (B = 1 and 8) borrows the entry of the same layer geometry at the NEAREST
+batch size that is not smaller (B = 4 -> the B = 8 entry: band counts / occupancy are those of the larger launch), else the
+largest smaller one; tile legality does not depend on B (checked at first use; an illegal tile falls back to the library default).
+A shape whose geometry is not in the table at all (other sequence_length, whole-song evaluation) runs the library default tile;
+`RV_TUNE_LOG=1` reports every such miss once.
 """
 import hashlib
 import json
@@ -22,6 +25,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PLAN_FILE = os.environ.get('RV_PLAN_FILE', os.path.join(HERE, 'tuned_plans.json'))
 
 _state = {'loaded': False, 'conv': {}, 'conv_nob': {}, 'wgrad': {}, 'wgrad_nob': {}, 'gemm': {}, 'digest': None, 'meta': {}}
+_missed = set()
 HITS = {'conv': set(), 'wgrad': set(), 'gemm': set()}         # table keys actually used in this process (tests assert coverage with it)
 
 
@@ -46,11 +50,11 @@ def _load():
     for k, v in doc.get('conv', {}).items():
         key = tuple(int(x) for x in k.split(','))           # (mode, B, H, W, cin, cout, ild, old, stats, bnbwd)
         _state['conv'][key] = int(v)
-        _state['conv_nob'].setdefault((key[0],) + key[2:], (key, int(v)))
+        _state['conv_nob'].setdefault((key[0],) + key[2:], []).append((key[1], key, int(v)))
     for k, v in doc.get('wgrad', {}).items():
         key = tuple(int(x) for x in k.split(','))           # (taps, B, Hv, Wv, Ca, Cb)
         _state['wgrad'][key] = (int(v[0]), int(v[1]))
-        _state['wgrad_nob'].setdefault((key[0],) + key[2:], (key, (int(v[0]), int(v[1]))))
+        _state['wgrad_nob'].setdefault((key[0],) + key[2:], []).append((key[1], key, (int(v[0]), int(v[1]))))
     for k, v in doc.get('gemm', {}).items():
         _state['gemm'][tuple(int(x) for x in k.split(','))] = int(v)   # (M, N, K, batch, a k-fast, b k-fast, act, accumulate) -> splitk
 
@@ -76,6 +80,19 @@ def wgrad_entries():
     return dict(_state['wgrad'])
 
 
+def _nearest_batch(cands, b):
+    """Entry of the nearest batch size >= b, else of the largest one below (cands: [(B, key, value)])."""
+    above = [c for c in cands if c[0] >= b]
+    return min(above, key=lambda c: c[0]) if above else max(cands, key=lambda c: c[0])
+
+
+def _miss(kind, key):
+    if os.environ.get('RV_TUNE_LOG') and (kind, key) not in _missed:
+        import sys
+        _missed.add((kind, key))
+        print(f'[plans] {kind} shape {key} is not in the shipped table: library default tile', file=sys.stderr)
+
+
 def lookup_conv(key):
     """(algo, exact) for a conv launch key (mode, B, H, W, cin, cout, ild, old, stats, bnbwd) or None."""
     _load()
@@ -83,10 +100,12 @@ def lookup_conv(key):
     if key in _state['conv']:
         HITS['conv'].add(key)
         return _state['conv'][key], True
-    hit = _state['conv_nob'].get((key[0],) + key[2:])
-    if hit is not None:
-        HITS['conv'].add(hit[0])
-        return hit[1], False
+    cands = _state['conv_nob'].get((key[0],) + key[2:])
+    if cands:
+        _, src, algo = _nearest_batch(cands, key[1])
+        HITS['conv'].add(src)
+        return algo, False
+    _miss('conv', key)
     return None
 
 
@@ -97,10 +116,12 @@ def lookup_wgrad(key):
     if key in _state['wgrad']:
         HITS['wgrad'].add(key)
         return _state['wgrad'][key]
-    hit = _state['wgrad_nob'].get((key[0],) + key[2:])
-    if hit is not None:
-        HITS['wgrad'].add(hit[0])
-        return hit[1]
+    cands = _state['wgrad_nob'].get((key[0],) + key[2:])
+    if cands:
+        _, src, plan = _nearest_batch(cands, key[1])
+        HITS['wgrad'].add(src)
+        return plan
+    _miss('wgrad', key)
     return None
 
 

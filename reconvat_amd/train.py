@@ -269,6 +269,7 @@ class TrainStep:
         self.batch = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
         self.batch_ul = {k: v.clone() for k, v in batch_ul.items() if torch.is_tensor(v)} if batch_ul else None
         self.graph = None
+        self._keep = []                       # what the captured graph pins (ops.keep_scope): dropped with the graph in release()
         self.losses = None
         self.loss = None
         self.use_graph = graph
@@ -365,8 +366,21 @@ class TrainStep:
         self.pack_plan = ops.PackPlan(self.opt.flat_grad.device)
         self.pack_plan.run()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with ops.keep_scope(self._keep), torch.cuda.graph(self.graph):
             self._fwd_bwd()
+
+    def release(self):
+        """Drop the captured graph and everything it pinned (pinned host tables, their device copies, the static losses).  Called
+        by __del__; call it explicitly to re-capture (e.g. another batch shape) without waiting for the garbage collector."""
+        self.graph = None
+        self.losses = self.loss = None
+        self._keep.clear()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def __call__(self):
         if self.use_graph:

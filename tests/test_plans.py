@@ -25,9 +25,31 @@ def test_lookup_exact_and_borrowed():
     from reconvat_amd import plans
     key, algo = sorted(plans.conv_entries().items())[0]
     assert plans.lookup_conv(key) == (algo, True)
-    other_b = (key[0], 2) + key[2:]
-    assert plans.lookup_conv(other_b) == (algo, False)            # same layer geometry at another batch size
+    # same layer geometry at another batch size: the entry of the nearest batch size that is not smaller, else the largest below
+    conv = plans.conv_entries()
+    both = [(k, v) for k, v in sorted(conv.items()) if k[1] == 1 and (k[0], 8) + k[2:] in conv]
+    assert both, 'the table holds B = 1 and B = 8 entries of the same geometry (config 2 and the headline workload)'
+    k1, a1 = both[0]
+    a8 = conv[(k1[0], 8) + k1[2:]]
+    assert plans.lookup_conv((k1[0], 4) + k1[2:]) == (a8, False)      # B = 4 -> the B = 8 tile
+    assert plans.lookup_conv((k1[0], 16) + k1[2:]) == (a8, False)     # B = 16 -> the largest one below
+    assert plans.lookup_conv((k1[0], 1) + k1[2:]) == (a1, True)
     assert plans.lookup_conv((0, 8, 33, 17, 16, 16, 16, 16, 0, 0)) is None
     wkey, plan = sorted(plans.wgrad_entries().items())[0]
-    assert plans.lookup_wgrad(wkey) == plan and plans.lookup_wgrad((wkey[0], 2) + wkey[2:]) == plan
+    assert plans.lookup_wgrad(wkey) == plan
+    w8 = plans.wgrad_entries().get((wkey[0], 8) + wkey[2:])
+    if w8 is not None:
+        assert plans.lookup_wgrad((wkey[0], 2) + wkey[2:]) == w8
     assert plans.lookup_wgrad((9, 8, 33, 17, 16, 16)) is None
+
+
+def test_shipped_table_digest_is_pinned():
+    """The digest bench.py prints and profiles/*_pmc_traffic.json records: a changed table must be a deliberate, reviewed change
+    (regenerate with tools/tune_plans.py on an MI355X, re-run the -m gpu suite against it, then update this value)."""
+    from reconvat_amd import plans
+    assert plans.digest() == PINNED_DIGEST, (plans.digest(), 'tuned_plans.json changed: re-run the GPU suite and pin the new digest')
+    meta = plans.meta()
+    assert 'MI355X' in meta.get('device', '') and meta.get('git'), meta.get('device')
+
+
+PINNED_DIGEST = 'be098bbf6d3470dc'

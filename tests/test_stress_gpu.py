@@ -108,3 +108,82 @@ def test_two_stream_schedule_is_timing_independent(dev, seed):
         for i, ((lr, sr, _), (lg, sg, _)) in enumerate(zip(ref, got)):
             assert lr == lg, (graph, seed, i, {k: (lr[k], lg[k]) for k in lr if lr[k] != lg[k]})
             assert torch.equal(sr, sg), (graph, seed, i)
+
+
+def _small_step(dev, kind, seed, graph=True):
+    """A 64-frame two-stream TrainStep on closed-form weights / inputs / noise (lr > 0: the weights move)."""
+    import reconvat_amd as ra
+    from oracle import fixture as fx
+    from test_model_gpu import build
+    m = build(kind, True, dev)
+    opt = ra.FlatAdam(m.parameters(), lr=1e-3)
+    bl, bul = _mk(dev, 2, 64, 'L'), _mk(dev, 2, 64, 'UL')
+    noise = [fx.fixture_noise((2, 1, 64, 229), 'd0_ul').to(dev), fx.fixture_noise((2, 1, 64, 229), 'd0_l').to(dev)]
+    state = {'i': seed}
+
+    def draw(t):
+        state['i'] += 1
+        return noise[state['i'] % 2].clone()
+    m.vat_loss.noise = draw
+    return m, opt, ra.TrainStep(m, opt, bl, bul, alpha=1.0, VAT=True, clip=3.0, graph=graph, dual_stream=True)
+
+
+def test_capturing_and_dropping_steps_does_not_grow_process_state(dev):
+    """what a captured step pins (pinned host tables, their device copies) belongs to its TrainStep and goes with it.
+    Twelve capture / replay / drop cycles in one process: the module-level keep lists stay as they were, the pools are refilled rather
+    than drained, and neither pinned host memory nor device memory creeps."""
+    import gc
+    from reconvat_amd import ops
+
+    def host_bytes():
+        st = torch.cuda.host_memory_stats() if hasattr(torch.cuda, 'host_memory_stats') else {}
+        return st.get('allocated_bytes.current', st.get('allocated_bytes.all.current'))
+    seen = []
+    for i in range(12):
+        m, opt, step = _small_step(dev, 'onset', i)
+        step()
+        step()
+        torch.cuda.synchronize()
+        assert len(step._keep) > 0                       # the capture did pin tables ...
+        del step, opt, m
+        gc.collect()
+        torch.cuda.synchronize()
+        seen.append((len(ops._REPLAY_KEEP), len(ops._WGRAD_KEEP), len(ops._GEMM_KEEP), len(ops._pack_cache), host_bytes(),
+                     torch.cuda.memory_allocated(dev)))
+    assert all(s[:3] == seen[0][:3] for s in seen), seen          # ... and none of them outlived its step
+    assert seen[-1][3] <= seen[3][3], [s[3] for s in seen]         # packs of dead models are pruned
+    if seen[0][4] is not None:
+        assert seen[-1][4] <= seen[3][4], [s[4] for s in seen]     # pinned host memory: flat after the first cycles
+    assert seen[-1][5] <= seen[3][5] + (1 << 20), [s[5] for s in seen]
+
+
+def test_two_models_alternating_in_one_process_match_their_solo_runs(dev):
+    """UNet_Onset and UNet steps interleaved in ONE process (two captured graphs, one set of process-wide kernel plans / packed-weight
+    cache / arenas) against each model stepping alone: the first step bit for bit (deterministic data path, identical weights), the
+    following ones to the noise of the fp32-atomic parameter-gradient folds."""
+    solo = {}
+    for kind in ('onset', 'frame'):
+        m, opt, step = _small_step(dev, kind, 0)
+        solo[kind] = []
+        for _ in range(3):
+            step()
+            torch.cuda.synchronize()
+            solo[kind].append({k: float(v) for k, v in step.losses.items()})
+        solo[kind + '_p'] = opt.flat_param.detach().clone()
+        del step, opt, m
+    ma, oa, sa = _small_step(dev, 'onset', 0)
+    mb, ob, sb = _small_step(dev, 'frame', 0)
+    both = {'onset': [], 'frame': []}
+    for _ in range(3):
+        for kind, st in (('onset', sa), ('frame', sb)):
+            st()
+            torch.cuda.synchronize()
+            both[kind].append({k: float(v) for k, v in st.losses.items()})
+    for kind, opt in (('onset', oa), ('frame', ob)):
+        assert both[kind][0] == solo[kind][0], (kind, both[kind][0], solo[kind][0])
+        for a, b in zip(both[kind][1:], solo[kind][1:]):
+            for k in a:
+                tol = 2e-2 if ('LDS' in k or 'r_norm' in k) else 1e-5          # (VAT terms of a 64-frame fixture: chaotic in the weights)
+                assert abs(a[k] - b[k]) <= tol * max(abs(b[k]), 1e-6), (kind, k, a[k], b[k])
+        d = (opt.flat_param - solo[kind + '_p']).abs().max().item()
+        assert d <= 2.5e-3, (kind, d)                     # Adam's first steps move a weight by <= lr per step whatever the gradient noise

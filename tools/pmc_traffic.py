@@ -57,7 +57,10 @@ def main():
         git = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD'], stderr=subprocess.DEVNULL).decode().strip()
     except Exception:  # noqa: BLE001 -- the GPU box has no .git
         git = os.environ.get('RV_GIT_SHA', 'unknown (no .git on the GPU box)')
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from reconvat_amd import plans
     res = {'scope': 'all conv-family launches of one optimiser step (eager launches, B_l=B_ul=8)', 'git': git,
+           'kernel_plan_table': plans.digest(),         # the tile table these launches ran (bench.py flags a mismatch with its own)
            'fetch_bytes': fetch, 'write_bytes': write, 'traffic_bytes': fetch + write,
            'launches': out['FETCH_SIZE']['launches'],
            'correction': 'FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported',

@@ -8,5 +8,5 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-roofline --no-parity --steps 20 --warmup 5 "$@" > $out/bench.json 2> $out/bench.err
 db=$(find $out -name "*results.db" | head -1)
 cd $GRAFT_REPO_ROOT
-python3 tools/rocpd_stats.py $db --last-steps 15 > gpurun_out/prof_${tag}_stats.txt
+python3 tools/rocpd_stats.py $db --last-steps 15 --json gpurun_out/prof_${tag}_stats.json > gpurun_out/prof_${tag}_stats.txt
 rm -rf $out/*/   # keep the table and the bench line, drop the raw trace

@@ -1,7 +1,10 @@
 """Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / average, like --stats, over a window of WHOLE
 optimiser steps.
 
-    python tools/rocpd_stats.py gpurun_out/prof1/r1_results.db [--last-steps N] > profiles/xyz.txt
+    python tools/rocpd_stats.py gpurun_out/prof1/r1_results.db [--last-steps N] [--json out.json] > profiles/xyz.txt
+
+--json also writes the family sums as JSON; `conv_ms_per_step` (every conv* and wgrad* kernel: the four conv families) is what
+bench.py's `roofline.frac_two_stream` divides the executed conv flops by when the trace is one of the shipped two-stream schedule.
 
 The window is cut at optimiser-kernel (`adam_k`) boundaries: it runs from the end of the (N+1)-th-to-last `adam_k` to the end of
 the last one, so it holds exactly N steps (N defaults to every complete step but the first five = warm-up) and "per step"
@@ -63,6 +66,16 @@ def main():
     for f, (c, tot) in fam.items():
         if c:
             print(f'{c / steps:8.1f} launches/step {tot / 1e6 / steps:8.3f} ms/step {100 * tot / total:6.2f} %  {f}')
+    if '--json' in sys.argv:
+        import json
+        conv_fams = [f for f, _ in FAMILIES[:4]]
+        doc = {'steps': steps, 'wall_ms_per_step': (hi - lo) / 1e6 / steps, 'kernel_ms_per_step': total / 1e6 / steps,
+               'conv_ms_per_step': sum(fam[f][1] for f in conv_fams) / 1e6 / steps,
+               'conv_launches_per_step': sum(fam[f][0] for f in conv_fams) / steps,
+               'families_ms_per_step': {f: tot / 1e6 / steps for f, (c, tot) in fam.items() if c},
+               'winograd_ms_per_step': sum(r[2] for r in rows if 'conv3x3_wino_k' in r[0]) / 1e6 / steps}
+        with open(sys.argv[sys.argv.index('--json') + 1], 'w') as fh:
+            json.dump(doc, fh, indent=1)
 
 
 if __name__ == '__main__':
