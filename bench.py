@@ -52,6 +52,21 @@ def conv_flops(name, a):
     return 2.0 * b * hv * wv * ca * cb * {0: 9, 1: 1, 2: 4}[mode]
 
 
+def conv_bytes(name, a):
+    """Algorithmic HBM bytes of one conv launch: input + output (+ weights), fp32, every tensor touched once."""
+    if name == 'rv_conv_fwd':
+        mode, b, h, w, cin, ho, wo, cout = a[0], a[3], a[4], a[5], a[6], a[9], a[10], a[11]
+        taps = {0: 9, 1: 1, 2: 4, 3: 4}[mode]
+        return 4.0 * (b * h * w * cin + b * ho * wo * cout + taps * cin * cout)
+    mode, hu, wu, ca, hv, wv, cb, b = a[0] & 0xff, a[3], a[4], a[5], a[8], a[9], a[10], a[11]
+    return 4.0 * (b * hu * wu * ca + b * hv * wv * cb + {0: 9, 1: 1, 2: 4}[mode] * ca * cb)
+
+
+def conv_is_bf16(name, a):
+    return bool((a[15] >> 20) & 1) if name == 'rv_conv_fwd' else bool(a[0] & 0x100)
+
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0        # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 matrix peak
 CONV_ENTRY_POINTS = ('rv_conv_fwd', 'rv_conv_wgrad', 'rv_conv_wgrad_deferred', 'rv_wgrad_reduce_table')
 ROTATE_BYTES = 320 << 20              # operand sets of one timed launch are rotated until they total more than the 256 MiB Infinity Cache
 
@@ -122,6 +137,8 @@ def measure_conv_phase(step_fn, device):
         return (n + 4095) & ~4095
 
     total_ms, total_flops, per_kernel, min_sets = 0.0, 0.0, [], 1 << 30
+    # per-launch bound of SURVEY 8(d): min(matrix peak of the launch's operand type, arithmetic intensity x HBM bandwidth)
+    bound = {'all': [0.0, 0.0, 0.0], 'bf16': [0.0, 0.0, 0.0]}       # [measured ms, ideal ms at the bound, flops]
     for sig, g in groups.items():
         a0 = list(g['args'])
         if g['name'] == 'rv_conv_fwd':
@@ -171,6 +188,13 @@ def measure_conv_phase(step_fn, device):
         fl = conv_flops(g['name'], g['args'])
         total_ms += ms * g['count']
         total_flops += fl * g['count']
+        is_bf = conv_is_bf16(g['name'], g['args'])
+        peak = (MFMA_BF16_PEAK_TFLOPS if is_bf else MFMA_F32_PEAK_TFLOPS) * 1e12
+        lim = min(peak, fl / conv_bytes(g['name'], g['args']) * HBM_PEAK_TBS * 1e12)
+        for key in (('all', 'bf16') if is_bf else ('all',)):
+            bound[key][0] += ms * g['count']
+            bound[key][1] += fl / lim * 1e3 * g['count']
+            bound[key][2] += fl * g['count']
         per_kernel.append((ms * g['count'], g['count'], ms, fl / ms / 1e9, sig))
     # the batched reductions: every deferrable weight gradient of the step, split over two tables like the two chains of the step
     wg = [list(r[1]) for r in records if r[0] == 'rv_conv_wgrad' and deferrable(r[1])]
@@ -211,7 +235,7 @@ def measure_conv_phase(step_fn, device):
         ntab = len(tables)
         per_kernel.append((ms, ntab, ms / ntab, 0.0, ('rv_wgrad_reduce_table', f'{len(wg)} reductions in {ntab} launches')))
     per_kernel.sort(reverse=True)
-    return total_ms, total_flops, per_kernel, len(records) + ntab, min_sets
+    return total_ms, total_flops, per_kernel, len(records) + ntab, min_sets, bound
 
 
 def measure_in_situ(step_fn, device):
@@ -678,7 +702,7 @@ def main():
     if rank == 0 and world == 1 and args.model == 'onset' and batch_l == args.batch == 8:       # (the roofline / parity legs are written for the headline workload)
         if not args.no_roofline:
             eager = ra.TrainStep(model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=False)
-            conv_ms, conv_flops_total, per_kernel, nlaunch, min_sets = measure_conv_phase(eager, device)
+            conv_ms, conv_flops_total, per_kernel, nlaunch, min_sets, bound = measure_conv_phase(eager, device)
             achieved = conv_flops_total / conv_ms / 1e9
             # in situ: one eager single-stream step, every family launch bracketed by HIP events on the launch stream
             eager1 = ra.TrainStep(model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=False, dual_stream=False)
@@ -740,6 +764,13 @@ def main():
                 # SURVEY 8(d) counts the reference's conv work (1 531 GFLOP incl. the weight gradients of the power
                 # iteration that this build provably does not need); `frac` above credits only what was executed
                 'frac_counting_reference_work': round(1531.0e9 / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                # achieved / min(MFMA peak of the launch's operand type, arithmetic intensity x HBM), launch by launch
+                # (algorithmic bytes: input + output + weights once); `bf16_launches`: the opt-in bf16-operand launches alone
+                'frac_of_min_mfma_ai_hbm': {k: {'frac': round(v[1] / v[0], 4), 'measured_ms': round(v[0], 3), 'ms_at_bound': round(v[1], 3),
+                                                'achieved_tflops': round(v[2] / v[0] / 1e9, 1),
+                                                'mfma_peak_tflops': MFMA_BF16_PEAK_TFLOPS if k == 'bf16' else MFMA_F32_PEAK_TFLOPS,
+                                                'hbm_tb_s': HBM_PEAK_TBS}
+                                            for k, v in (('all_conv_launches', bound['all']), ('bf16_launches', bound['bf16'])) if v[0] > 0},
                 'top': [{'ms_per_step': round(t, 3), 'count': c, 'ms': round(m, 4), 'tflops': round(tf, 1), 'sig': list(map(str, s))}
                         for t, c, m, tf, s in per_kernel[:6]],
                 # every other kernel family of the step against the roofline that bounds it (same isolated re-launch method)

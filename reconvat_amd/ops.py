@@ -201,6 +201,14 @@ def _grad_buf(t):
     return t.grad
 
 
+def drop_packs_of(flat):
+    """Forget every packed copy whose source weight lives in the storage of `flat` (FlatAdam's parameter buffer): the cache holds its
+    source tensors, so the packs of a model that is gone would otherwise keep its whole parameter buffer alive."""
+    sp = flat.untyped_storage().data_ptr()
+    for k in [k for k, v in _pack_cache.items() if v[2].untyped_storage().data_ptr() == sp]:
+        del _pack_cache[k]
+
+
 def invalidate_weight_cache():
     """Call after any out-of-band parameter update (custom optimiser step, load_state_dict)."""
     _EPOCH[0] += 1
@@ -352,6 +360,7 @@ _DGRAD_MODE = {'c3': 0, 't3': 0, 'c1': 1, 'down': 3, 'up': 2}
 
 _algo_cache = {}
 _tune_us = {}             # ('conv' | 'wgrad', key) -> microseconds the on-line tuner measured for its choice
+_tune_top = {}            # ('conv', key) -> [(us, algo)] the three fastest candidates (tools/tune_plans.py --in-situ re-ranks near ties in the step)
 _algo_unchecked = set()    # table entries borrowed from another batch size: legality is checked by their first launch
 # 'table' (default): the shipped per-shape plan table (reconvat_amd/plans.py, tuned_plans.json) -- what bench.py, the scripts and
 # the -m gpu tests all run; True (RV_AUTOTUNE=1): time every legal tile on the first eager call of a shape (how the table is
@@ -470,6 +479,7 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
                     if fams:
                         keep = {int(f, 0) for f in fams.split(',')}
                         cands = [c for c in cands if ((c >> 8) & 15) in keep or c in (1, 2) and ((1 if c == 1 else 2) in keep)]
+                ranked = []
                 for cand in cands:
                     if lib.rv_conv_fwd(*targs, cand | bfbit, scratch, *tail, st.cuda_stream) != 0:
                         continue                                   # tile does not fit this shape
@@ -483,11 +493,13 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
                         e1.synchronize()
                         dt = e0.elapsed_time(e1)
                         t = dt if t is None else min(t, dt)
+                    ranked.append((t / 3 * 1e3, cand))
                     if best is None or t < best:
                         best, algo = t, cand
                 _algo_cache[key] = algo
                 if best is not None:
                     _tune_us[('conv', key)] = best / 3 * 1e3
+                    _tune_top[('conv', key)] = sorted(ranked)[:3]
                 if os.environ.get('RV_TUNE_LOG') and best is not None:
                     print(f'[tune] conv mode={mode} {cin}->{cout} {h}x{wd} B={bb}: algo={algo:#x} {best / 3 * 1e3:.1f} us', file=sys.stderr)
         if key in _algo_unchecked:

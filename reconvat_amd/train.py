@@ -148,6 +148,12 @@ class FlatAdam:
         self.sync_error_word = bool(sync_error_word)
         ops.invalidate_weight_cache()
 
+    def __del__(self):
+        try:
+            ops.drop_packs_of(self.flat_param)     # the packed-weight cache holds views of this buffer
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
     @staticmethod
     def _require_hip(dev):
         if dev.type != 'cuda':
@@ -287,8 +293,8 @@ class TrainStep:
         if dual_stream and self.batch['audio'].is_cuda:
             ops.prepare_replay_pool()
         if graph and self.batch['audio'].is_cuda:
-            ops.prepare_wgrad_tables(len(ops._WGRAD_POOL) + 3)
-            ops.prepare_gemm_tables(len(ops._GEMM_POOL) + 6)
+            ops.prepare_wgrad_tables(4)        # (top-ups: a capture pops what it pins, the rest of the pool is reused)
+            ops.prepare_gemm_tables(8)
 
     def _fwd_bwd(self):
         self.opt.zero_grad()

@@ -598,9 +598,14 @@ def test_grouped_deferred_gemms_vs_torch(dev):
     with ops.deferred_param_gemms() as pend:
         for i, (at, b, c, c0, sk, batch) in enumerate(items):
             ops.gemm(at[0].t(), b[0], c[0], accumulate=True, splitk=sk, deterministic=False, batch=batch,
-                     bstrides=(at.stride(0), b.stride(0), c.stride(0)), a_rowsum=rs if i == 0 else None)
+                     bstrides=(at.stride(0), b.stride(0), c.stride(0)), a_rowsum=rs if i == 0 else None, defer_ok=True)
         torch.cuda.synchronize()
         assert all(torch.equal(c, c0) for _, _, c, c0, _, _ in items), 'nothing may run before flush()'
+        # without the explicit opt-in (a destination autograd may read before the flush) the GEMM runs at once, context or not
+        tmp, tmp0 = items[0][2][0].clone(), items[0][2][0].clone()
+        ops.gemm(items[0][0][0].t(), items[0][1][0], tmp, accumulate=True, splitk=4, deterministic=False)
+        torch.cuda.synchronize()
+        assert not torch.equal(tmp, tmp0)
         assert sum(t.n for t in pend.tables.values()) == len(items)
         pend.flush()
     torch.cuda.synchronize()

@@ -17,6 +17,28 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def measure(variants, reps=3, verbose=True):
+    """variants: [(name, table path or '-', library path or '-')]; returns {name: [ms per step of every run]} (runs interleaved)."""
+    times = {v[0]: [] for v in variants}
+    for _ in range(reps):
+        for name, table, lib in variants:
+            env = dict(os.environ)
+            if table != '-':
+                env['RV_PLAN_FILE'] = os.path.abspath(table)
+            if lib != '-':
+                env['RECONVAT_HIP_LIB'] = os.path.abspath(lib)
+            env.pop('RV_AUTOTUNE', None)
+            r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--no-parity', '--no-roofline', '--no-cpu-baseline'],
+                               capture_output=True, text=True, env=env, cwd=ROOT)
+            if r.returncode != 0:
+                raise SystemExit(f'{name}: bench.py failed\n{r.stderr[-2000:]}')
+            ms = json.loads(r.stdout.strip().split('\n')[-1])['ms_per_step']
+            times[name].append(ms)
+            if verbose:
+                print(f'{name:24s} {ms:.3f} ms', flush=True)
+    return times
+
+
 def main():
     args = sys.argv[1:]
     reps = 3
@@ -29,21 +51,7 @@ def main():
         variants.append((name, parts[0], parts[1] if len(parts) > 1 else '-'))
     if len(variants) < 2:
         raise SystemExit(__doc__)
-    times = {v[0]: [] for v in variants}
-    for _ in range(reps):
-        for name, table, lib in variants:
-            env = dict(os.environ)
-            if table != '-':
-                env['RV_PLAN_FILE'] = os.path.abspath(table)
-            if lib != '-':
-                env['RECONVAT_HIP_LIB'] = os.path.abspath(lib)
-            r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--no-parity', '--no-roofline', '--no-cpu-baseline'],
-                               capture_output=True, text=True, env=env, cwd=ROOT)
-            if r.returncode != 0:
-                raise SystemExit(f'{name}: bench.py failed\n{r.stderr[-2000:]}')
-            ms = json.loads(r.stdout.strip().split('\n')[-1])['ms_per_step']
-            times[name].append(ms)
-            print(f'{name:24s} {ms:.3f} ms', flush=True)
+    times = measure(variants, reps)
     print()
     for name, ts in times.items():
         print(f'{name:24s} min {min(ts):.3f}  median {statistics.median(ts):.3f}  ({len(ts)} runs)')

@@ -6,9 +6,16 @@ of every conv shape times each legal tile / weight-gradient partition with HIP e
 written as one JSON table; commit it as reconvat_amd/tuned_plans.json -- from then on every run (bench, scripts, tests, all
 data-parallel ranks) uses exactly those tiles.
 
-    python tools/tune_plans.py [--out gpurun_out/tuned_plans.json] [--rounds 2]
+    python tools/tune_plans.py [--out gpurun_out/tuned_plans.json] [--rounds 2] [--in-situ [--tie-pct 6]]
 
 --rounds N tunes N times in fresh caches and keeps, per shape, the choice with the lowest measured time (less timing noise).
+
+--in-situ: the table above is tuned on ISOLATED launches, but what ships is the two-stream step, and isolated near-ties have inverted
+there.  So the near-ties are re-ranked by STEP time: every 3x3 shape whose runner-up tile is within --tie-pct of
+its winner is a candidate swap; candidates are grouped by layer resolution (one group = the shapes of one U-Net level), each group's
+swap becomes one variant table, all variants and the isolated-winner table are timed interleaved with tools/insitu_ab.measure
+(fresh bench.py child processes, 3 runs each), and a group's swap is adopted when its median step time beats the winners' by more
+than the run-to-run noise (0.05 ms).  The A/B log is written next to the table (<out>_insitu.txt).
 """
 import argparse
 import os
@@ -40,11 +47,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'tuned_plans.json'))
     ap.add_argument('--rounds', type=int, default=2)
+    ap.add_argument('--in-situ', action='store_true', help='re-rank near-tied 3x3 tiles by two-stream STEP time (see the module docstring)')
+    ap.add_argument('--tie-pct', type=float, default=6.0)
     args = ap.parse_args()
     import reconvat_amd as ra
     from reconvat_amd import ops, plans
     dev = torch.device('cuda:0')
-    best_conv, best_wgrad, best_gemm = {}, {}, {}
+    best_conv, best_wgrad, best_gemm, runner_up = {}, {}, {}, {}
     log = []
     real_print = print
 
@@ -54,6 +63,7 @@ def main():
         ops._wgrad_tuned.clear()
         ops._wgrad_plans.clear()
         ops._tune_us.clear()
+        ops._tune_top.clear()
         ops._gemm_splitk.clear()
         for name, model, bl, bul in workloads(dev):
             torch.manual_seed(7)
@@ -71,6 +81,8 @@ def main():
             log.append(f'round {rnd} conv {k}: algo={ops._algo_cache[k]:#x} {us:.1f} us')
             if k not in best_conv or us < best_conv[k][1]:
                 best_conv[k] = (ops._algo_cache[k], us)
+                alts = [(t, a) for t, a in ops._tune_top.get(('conv', k), []) if a != ops._algo_cache[k]]
+                runner_up[k] = alts[0] if alts else None
         for k in wg_keys:
             us = ops._tune_us[('wgrad', k)]
             log.append(f'round {rnd} wgrad {k}: plan={ops._wgrad_plans[k]} {us:.1f} us')
@@ -101,6 +113,52 @@ def main():
     with open(os.path.splitext(args.out)[0] + '_log.txt', 'w') as fh:
         fh.write('\n'.join(log))
     real_print(f'[tune_plans] wrote {args.out}: {len(best_conv)} conv entries, {len(best_wgrad)} weight-gradient entries, {len(best_gemm)} GEMM entries', file=sys.stderr)
+    if args.in_situ:
+        in_situ(args, best_conv, best_wgrad, best_gemm, runner_up, meta, real_print)
+
+
+def in_situ(args, best_conv, best_wgrad, best_gemm, runner_up, meta, say):
+    import statistics
+    from reconvat_amd import plans
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import insitu_ab
+    # candidate swaps: B = 8 3x3 shapes of the headline workload whose runner-up is within tie-pct of the winner
+    groups = {}
+    for k, ru in runner_up.items():
+        if ru is None or k[0] != 0 or k[1] != 8 or 'bf16' in k:
+            continue
+        us0 = best_conv[k][1]
+        if ru[0] <= us0 * (1.0 + args.tie_pct / 100.0):
+            groups.setdefault(k[2], []).append((k, ru[1], us0, ru[0]))            # grouped by H: one U-Net level per group
+    base = os.path.splitext(args.out)[0]
+    log = [f'in-situ re-ranking of {sum(len(g) for g in groups.values())} near-tied 3x3 shapes (runner-up within {args.tie_pct} % of the '
+           f'isolated winner) in {len(groups)} groups (by layer height)']
+    variants = [('winners', args.out, '-')]
+    for h, items in sorted(groups.items()):
+        conv = {k: v[0] for k, v in best_conv.items()}
+        for k, algo2, us0, us2 in items:
+            conv[k] = algo2
+            log.append(f'  group H={h}: {k}: {best_conv[k][0]:#x} ({us0:.1f} us) <-> {algo2:#x} ({us2:.1f} us)')
+        path = f'{base}_swap_h{h}.json'
+        plans.dump(conv, {k: v[0] for k, v in best_wgrad.items()}, meta, path, gemm={k: v[0] for k, v in best_gemm.items()})
+        variants.append((f'swap_h{h}', path, '-'))
+    if len(variants) > 1:
+        # (the tuning process keeps its GPU context while the bench children run: they are ordinary child processes, nothing execs)
+        times = insitu_ab.measure(variants, reps=3, verbose=False)
+        med = {n: statistics.median(t) for n, t in times.items()}
+        for n, t in times.items():
+            log.append(f'  {n:12s} ' + ' '.join(f'{x:.3f}' for x in t) + f'   median {med[n]:.3f} ms/step')
+        adopted = [n for n in med if n != 'winners' and med[n] < med['winners'] - 0.05]
+        conv = {k: v[0] for k, v in best_conv.items()}
+        for n in adopted:
+            for k, algo2, _, _ in groups[int(n[len('swap_h'):])]:
+                conv[k] = algo2
+        log.append('adopted swaps: ' + (', '.join(adopted) if adopted else 'none -- the isolated winners hold in the step'))
+        meta = dict(meta, in_situ=f'{len(adopted)} of {len(variants) - 1} group swaps adopted (tools/tune_plans.py --in-situ)')
+        plans.dump(conv, {k: v[0] for k, v in best_wgrad.items()}, meta, args.out, gemm={k: v[0] for k, v in best_gemm.items()})
+    with open(base + '_insitu.txt', 'w') as fh:
+        fh.write('\n'.join(log) + '\n')
+    say('\n'.join(log), file=sys.stderr)
 
 
 if __name__ == '__main__':
