@@ -110,8 +110,9 @@ def test_two_stream_schedule_is_timing_independent(dev, seed):
             assert torch.equal(sr, sg), (graph, seed, i)
 
 
-def _small_step(dev, kind, seed, graph=True):
-    """A 64-frame two-stream TrainStep on closed-form weights / inputs / noise (lr > 0: the weights move)."""
+def _small_step(dev, kind, seed, graph=True, n_power=1):
+    """A 64-frame two-stream TrainStep on closed-form weights / inputs / noise (lr > 0: the weights move).  n_power = 0: the injected
+    noise IS the perturbation direction (no chaotic power iteration), so a multi-step trajectory is comparable between runs."""
     import reconvat_amd as ra
     from oracle import fixture as fx
     from test_model_gpu import build
@@ -125,6 +126,7 @@ def _small_step(dev, kind, seed, graph=True):
         state['i'] += 1
         return noise[state['i'] % 2].clone()
     m.vat_loss.noise = draw
+    m.vat_loss.n_power = n_power
     return m, opt, ra.TrainStep(m, opt, bl, bul, alpha=1.0, VAT=True, clip=3.0, graph=graph, dual_stream=True)
 
 
@@ -159,20 +161,25 @@ def test_capturing_and_dropping_steps_does_not_grow_process_state(dev):
 
 def test_two_models_alternating_in_one_process_match_their_solo_runs(dev):
     """UNet_Onset and UNet steps interleaved in ONE process (two captured graphs, one set of process-wide kernel plans / packed-weight
-    cache / arenas) against each model stepping alone: the first step bit for bit (deterministic data path, identical weights), the
-    following ones to the noise of the fp32-atomic parameter-gradient folds."""
-    solo = {}
-    for kind in ('onset', 'frame'):
-        m, opt, step = _small_step(dev, kind, 0)
-        solo[kind] = []
-        for _ in range(3):
+    cache / arenas) against each model stepping alone: the first step bit for bit (deterministic data path, identical weights); the
+    three-step trajectory as close to a solo run as two solo runs are to each other (parameter gradients are folded by fp32 atomics
+    and Adam's first updates are sign-like, so even two identical solo runs drift apart in a few percent of the entries -- that
+    drift, measured here, is the yardstick)."""
+    def run(kind, steps=3):
+        m, opt, step = _small_step(dev, kind, 0, n_power=0)
+        losses = []
+        for _ in range(steps):
             step()
             torch.cuda.synchronize()
-            solo[kind].append({k: float(v) for k, v in step.losses.items()})
-        solo[kind + '_p'] = opt.flat_param.detach().clone()
-        del step, opt, m
-    ma, oa, sa = _small_step(dev, 'onset', 0)
-    mb, ob, sb = _small_step(dev, 'frame', 0)
+            losses.append({k: float(v) for k, v in step.losses.items()})
+        return losses, opt.flat_param.detach().clone()
+
+    def drift(p, q):
+        d = (p - q).abs()
+        return (d > 1e-4).float().mean().item(), d.max().item()
+    solo = {kind: (run(kind), run(kind)) for kind in ('onset', 'frame')}
+    ma, oa, sa = _small_step(dev, 'onset', 0, n_power=0)
+    mb, ob, sb = _small_step(dev, 'frame', 0, n_power=0)
     both = {'onset': [], 'frame': []}
     for _ in range(3):
         for kind, st in (('onset', sa), ('frame', sb)):
@@ -180,15 +187,12 @@ def test_two_models_alternating_in_one_process_match_their_solo_runs(dev):
             torch.cuda.synchronize()
             both[kind].append({k: float(v) for k, v in st.losses.items()})
     for kind, opt in (('onset', oa), ('frame', ob)):
-        assert both[kind][0] == solo[kind][0], (kind, both[kind][0], solo[kind][0])
-        for a, b in zip(both[kind][1:], solo[kind][1:]):
+        (l1, p1), (l2, p2) = solo[kind]
+        assert both[kind][0] == l1[0] == l2[0], (kind, both[kind][0], l1[0])
+        own_frac, own_max = drift(p1, p2)
+        frac, mx = drift(opt.flat_param, p1)
+        assert frac <= 2.0 * own_frac + 0.01 and mx <= 2.0 * own_max + 1e-3, (kind, frac, own_frac, mx, own_max)
+        for a, b, c in zip(both[kind][1:], l1[1:], l2[1:]):
             for k in a:
-                # later steps: Adam's first updates are lr * sign-like, so where the fp32-atomic folds leave a gradient entry's sign to
-                # rounding the weight moves by 2 lr between two runs of the SAME configuration (solo vs solo shows the same spread)
-                tol = 2e-2 if ('LDS' in k or 'r_norm' in k) else 5e-4          # (VAT terms of a 64-frame fixture: chaotic in the weights)
-                assert abs(a[k] - b[k]) <= tol * max(abs(b[k]), 1e-6), (kind, k, a[k], b[k])
-        # Adam's first steps are sign-like (|update| ~ lr): an entry whose gradient sign is rounding noise may end up 2 lr per step
-        # apart between two runs; everything else agrees closely
-        diff = (opt.flat_param - solo[kind + '_p']).abs()
-        assert diff.max().item() <= 3 * 2 * 1e-3 * 1.2, (kind, diff.max().item())
-        assert (diff > 1e-4).float().mean().item() < 0.03, (kind, (diff > 1e-4).float().mean().item())
+                own = abs(b[k] - c[k])
+                assert abs(a[k] - b[k]) <= 3.0 * own + 2e-4 * max(abs(b[k]), 1e-6), (kind, k, a[k], b[k], c[k])
