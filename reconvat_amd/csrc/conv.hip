@@ -1928,6 +1928,25 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
     if (xg != 0) return;
     // D[row = a_local = 4g+r][col = b_local = i]
     float* dst = a.part + (long)blockIdx.x * a.pstride;
+#ifdef RV_ABLATION
+    if (ABL(a) & 2048) {                                     // cost probe: every row partition ADDS into partial 0 (fp32 atomics) instead of storing its own
+        dst = a.part;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int ta = 0; ta < TAW; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < TB; ++tb) {
+                    const int bb = b0 + tb * 16 + i;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int aa = a0 + (hp * TAW + ta) * 16 + 4 * g + r;
+                        if (aa < a.Ca && bb < a.Cb) atomicAdd(&dst[((long)t * a.Ca + aa) * a.Cb + bb], acc[t][ta][tb][r]);
+                    }
+                }
+        return;
+    }
+#endif
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll

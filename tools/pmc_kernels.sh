@@ -4,6 +4,7 @@
 # Pass A: issue/wait split + MFMA busy.  Pass B: LDS bank conflicts / instruction mix.
 set -u
 out=$1; shift
+mkdir -p $GRAFT_REPO_ROOT/$out
 cd /tmp && export TMPDIR=/tmp
 i=0
 for cfg in "$@"; do
