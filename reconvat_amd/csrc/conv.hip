@@ -1971,6 +1971,266 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
 #undef TS
 }
 
+// ------------------------------------------------------------------------------------------
+// Winograd F(3x3, 2x2) form of the 3x3 weight gradient (round 4; plan code nw = 24 of rv_conv_wgrad_set_plan).
+//
+//   dW = G^T [ sum_tiles (B^T d B) .* (A dY A^T) ] G        per 4x4 input patch d and 2x2 tile dY of the output gradient
+//
+// 16 products per tile (4 output pixels) and channel pair instead of 36: 2.25x fewer MFMAs than the direct form.  The MFMA contraction
+// runs over TILES (k = 4 consecutive tiles of a tile row per instruction): lane (i, g) holds channel i of tile g, reads the 16 patch
+// values of its (input channel, tile) and the 4 dY values of its (output channel, tile) from LDS (4-byte reads), transforms both in
+// registers (32 + 12 adds) and issues one MFMA per xi and (a-tile, b-tile) pair.  The accumulators hold M[xi] (16 x 16 per tile pair);
+// the 4x4 -> 3x3 transform G^T M G is applied by the reduction pass (wgrad_reduce_wino_body), so the partial sums are [16][Ca][Cb].
+// Work partition, staging ring, fold and partial-sum stores follow wgrad_mfma_k, with ROW PAIRS instead of rows: one barrier interval
+// covers two output rows (one tile row); the input ring holds 6 rows (4 in use, 2 arriving), dY is double-buffered two rows at a time.
+// LDS images are permuted inside each 1 KiB DMA piece so that the two tiles of a 32-lane read group sit on different bank halves
+// (pixel-major images put them exactly 128 or 256 bytes apart: a 2-way conflict on every read, as in the direct kernel):
+//   32-channel groups: the 16-byte quad q of pixel X is stored at quad position q ^ (4 * ((X >> 1) & 1))
+//   16-channel groups: pixel X is stored in pixel slot X ^ ((X >> 1) & 1)
+// Rows / columns outside the image and unused channels are fetched from rv_zero_piece: every piece of every staged row is written by
+// one unmasked DMA instruction, nothing is zero-filled by stores.
+// ------------------------------------------------------------------------------------------
+template <int C> __device__ __forceinline__ int wgw_pos(int X, int c) {          // float offset of channel c of pixel X inside a staged row
+    return C == 32 ? X * 32 + ((((c >> 4) ^ ((X >> 1) & 1)) << 4) | (c & 15)) : (X ^ ((X >> 1) & 1)) * 16 + c;
+}
+
+template <int TA, int TB, int NW>
+__global__ __launch_bounds__(NW * 64) void wgrad_wino_k(WgradArgs a) {
+    constexpr int CA = TA * 16, CB = TB * 16;
+    constexpr int NH = (NW == 8 && TA == 2 && TB == 2) ? 2 : 1;
+    constexpr int TAW = TA / NH, NXG = NW / NH, NTHR = NW * 64;
+    constexpr int C4A = CA / 4, C4B = CB / 4;
+    constexpr int PPA = 64 / C4A, PPB = 64 / C4B;            // pixels per DMA piece
+    constexpr int NSLOT = 6;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int ga = blockIdx.y / a.ngb, gb = blockIdx.y - ga * a.ngb;
+    const int a0 = ga * CA, b0 = gb * CB;
+    const int H2 = a.Hv >> 1;                                // tile rows per image (Hv even: checked by the host)
+    const int npairs = a.B * H2;
+    const int pair0 = blockIdx.x * a.rows_per_wave;          // row PAIRS per workgroup here
+    const int pair1 = min(pair0 + a.rows_per_wave, npairs);
+    const int WT = (a.Wv + 1) >> 1, WT4 = (WT + 3) & ~3;     // tiles per row, rounded to whole k-steps
+    const int UPp = ((2 * WT4 + 2 + PPA - 1) / PPA) * PPA;   // staged input pixels per row (X = x + 1 = 0 .. 2 WT4 + 1), whole pieces
+    const int VPp = ((2 * WT4 + PPB - 1) / PPB) * PPB;       // staged dY pixels per row
+    float* ubuf = smem;                                      // [NSLOT][UPp][CA]
+    float* vbuf = smem + NSLOT * UPp * CA;                   // [2][2][VPp][CB]
+    const int hp = wave / NXG, xg = (wave + (NH == 2 ? 2 * hp : 0)) % NXG;
+
+    f32x4 acc[16][TAW][TB];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int x = 0; x < TAW; ++x)
+#pragma unroll
+            for (int y = 0; y < TB; ++y) acc[xi][x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 accb[TB];
+    float accbs[TB];
+#pragma unroll
+    for (int y = 0; y < TB; ++y) { accb[y] = (f32x4){0.f, 0.f, 0.f, 0.f}; accbs[y] = 0.f; }
+    const bool do_bias = a.want_bias && ga == 0 && hp == 0;
+    const int ca_valid = min(CA, a.Ca - a0), cb_valid = min(CB, a.Cb - b0);
+    const char* zsrc = reinterpret_cast<const char*>(rv_zero_piece) + lane * 16;
+
+    // ---- staging: which (pixel, quad) this lane fetches for piece k of a row (inverse of the LDS permutation) ----
+    const int upl = lane / C4A, uql = lane - upl * C4A;      // slot pixel inside the piece, quad position
+    const int vpl = lane / C4B, vql = lane - vpl * C4B;
+    auto dma_urow = [&](int b, int r, int slot) {            // input row r of image b -> ring slot
+        float* dst0 = ubuf + slot * UPp * CA;
+        const bool inside = r >= 0 && r < a.Hu;
+        const float* src = a.U + ((long)b * a.Hu + (inside ? r : 0)) * a.Wu * a.u_ld + a0;
+        for (int k = wave; k * PPA < UPp; k += NW) {
+            const int Xs = k * PPA + upl;                                        // pixel slot
+            const int X = CA == 32 ? Xs : (Xs ^ ((Xs >> 1) & 1));                // source pixel (+1)
+            const int q = CA == 32 ? (uql ^ (4 * ((X >> 1) & 1))) : uql;         // source quad
+            const int x = X - 1;
+            const bool real = inside && x >= 0 && x < a.Wu && q * 4 < ca_valid;
+            glds16(real ? src + (long)x * a.u_ld + q * 4 : reinterpret_cast<const float*>(zsrc), dst0 + k * PPA * CA);
+        }
+    };
+    auto dma_vrow = [&](int b, int y, int vslot) {           // dY row y of image b -> vbuf row slot (0..3)
+        float* dst0 = vbuf + vslot * VPp * CB;
+        const float* src = a.V + ((long)b * a.Hv + y) * a.Wv * a.v_ld + b0;
+        for (int k = wave; k * PPB < VPp; k += NW) {
+            const int Xs = k * PPB + vpl;
+            const int X = CB == 32 ? Xs : (Xs ^ ((Xs >> 1) & 1));
+            const int q = CB == 32 ? (vql ^ (4 * ((X >> 1) & 1))) : vql;
+            const bool real = X < a.Wv && q * 4 < cb_valid;
+            glds16(real ? src + (long)X * a.v_ld + q * 4 : reinterpret_cast<const float*>(zsrc), dst0 + k * PPB * CB);
+        }
+    };
+    // tile row yp of an image needs input rows 2 yp - 1 .. 2 yp + 2; input row r lives in ring slot (r + 1) % 6
+    auto uslot = [&](int r) -> int { return (r + 1 + NSLOT) % NSLOT; };
+    auto stage_full = [&](int b, int yp, int vb) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dma_urow(b, 2 * yp - 1 + e, uslot(2 * yp - 1 + e));
+        dma_vrow(b, 2 * yp, vb * 2);
+        dma_vrow(b, 2 * yp + 1, vb * 2 + 1);
+    };
+    auto stage_next = [&](int b, int yp, int vb) {           // the two input rows tile row yp - 1 did not need
+        dma_urow(b, 2 * yp + 1, uslot(2 * yp + 1));
+        dma_urow(b, 2 * yp + 2, uslot(2 * yp + 2));
+        dma_vrow(b, 2 * yp, vb * 2);
+        dma_vrow(b, 2 * yp + 1, vb * 2 + 1);
+    };
+
+    // ---- per-lane fragment offsets (floats) relative to the first pixel of a k-step (4 tiles = 8 pixels; k-steps start at tiles that
+    // are multiples of 4, so the permutation bits of a pixel depend on (g, ec) only) ----
+    int uoff[4][TAW], voff[2][TB];
+#pragma unroll
+    for (int ec = 0; ec < 4; ++ec)
+#pragma unroll
+        for (int ta = 0; ta < TAW; ++ta) uoff[ec][ta] = wgw_pos<CA>(2 * g + ec, (hp * TAW + ta) * 16 + i);
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) voff[dx][tb] = wgw_pos<CB>(2 * g + dx, tb * 16 + i);
+
+    bool prefetched = false;
+    for (int pair = pair0; pair < pair1; ++pair) {
+        const int b = pair / H2, yp = pair - b * H2;
+        const int vb = pair & 1;
+        if (!prefetched) {
+            __syncthreads();                                  // nobody still reads the ring
+            stage_full(b, yp, vb);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                      // tile row (b, yp) is resident for every wave
+        prefetched = (pair + 1 < pair1) && (yp + 1 < H2);
+        if (prefetched) stage_next(b, yp + 1, vb ^ 1);        // DMA under the MFMAs below
+        const float* urow[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) urow[e] = ubuf + uslot(2 * yp - 1 + e) * UPp * CA;
+        const float* vrow0 = vbuf + (vb * 2) * VPp * CB;
+        const float* vrow1 = vrow0 + VPp * CB;
+        // (a source-level software pipeline of the k-steps -- raw operands of step s + 1 loaded under the MFMAs of step s, as in
+        // wgrad_mfma_k -- was measured 2-6 % slower than the schedule the compiler finds for this plain loop)
+        for (int t0 = xg * 4; t0 < WT4; t0 += 4 * NXG) {      // k-step: tiles t0 .. t0 + 3
+            const int ub = 2 * t0 * CA, vbs = 2 * t0 * CB;
+            float d[16][TAW], y[4][TB];
+#pragma unroll
+            for (int er = 0; er < 4; ++er)
+#pragma unroll
+                for (int ec = 0; ec < 4; ++ec)
+#pragma unroll
+                    for (int ta = 0; ta < TAW; ++ta) d[er * 4 + ec][ta] = urow[er][ub + uoff[ec][ta]];
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+                for (int tb = 0; tb < TB; ++tb) {
+                    y[dx][tb] = vrow0[vbs + voff[dx][tb]];
+                    y[2 + dx][tb] = vrow1[vbs + voff[dx][tb]];
+                }
+            // P = B^T d B (rows, then columns)
+#pragma unroll
+            for (int ta = 0; ta < TAW; ++ta) {
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const float e0 = d[cc][ta], e1 = d[4 + cc][ta], e2 = d[8 + cc][ta], e3 = d[12 + cc][ta];
+                    d[cc][ta] = e0 - e2; d[4 + cc][ta] = e1 + e2; d[8 + cc][ta] = e2 - e1; d[12 + cc][ta] = e1 - e3;
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float e0 = d[4 * rr][ta], e1 = d[4 * rr + 1][ta], e2 = d[4 * rr + 2][ta], e3 = d[4 * rr + 3][ta];
+                    d[4 * rr][ta] = e0 - e2; d[4 * rr + 1][ta] = e1 + e2; d[4 * rr + 2][ta] = e2 - e1; d[4 * rr + 3][ta] = e1 - e3;
+                }
+            }
+            // Q = A dY A^T, A = [1 0; 1 1; 1 -1; 0 -1]
+            float q[16][TB];
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) {
+                const float y00 = y[0][tb], y01 = y[1][tb], y10 = y[2][tb], y11 = y[3][tb];
+                const float t[4][2] = {{y00, y01}, {y00 + y10, y01 + y11}, {y00 - y10, y01 - y11}, {-y10, -y11}};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    q[4 * r][tb] = t[r][0]; q[4 * r + 1][tb] = t[r][0] + t[r][1]; q[4 * r + 2][tb] = t[r][0] - t[r][1]; q[4 * r + 3][tb] = -t[r][1];
+                }
+                if (do_bias) accbs[tb] += q[5][tb];          // Q[1][1] = the sum of the tile's four dY values
+            }
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+                for (int ta = 0; ta < TAW; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < TB; ++tb)
+                        acc[xi][ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[xi][ta], q[xi][tb], acc[xi][ta][tb], 0, 0, 0);
+        }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) {
+            float sb = accbs[tb];
+            sb += __shfl_xor(sb, 16, 64);
+            sb += __shfl_xor(sb, 32, 64);
+            accb[tb] = (f32x4){sb, sb, sb, sb};
+        }
+    }
+    // fold the x groups through LDS as a binary tree (as wgrad_mfma_k)
+    constexpr int NACC = (16 * TAW * TB + TB) * 4;
+    static_assert((NXG & (NXG - 1)) == 0, "x groups must be a power of two");
+#pragma unroll
+    for (int half = NXG / 2; half >= 1; half >>= 1) {
+        float* fold = smem + (hp * (NXG / 2) + (xg & (half - 1))) * NACC * 64;
+        __syncthreads();
+        if (xg >= half && xg < 2 * half) {
+            int qn = 0;
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+                for (int ta = 0; ta < TAW; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) fold[(qn++) * 64 + lane] = acc[xi][ta][tb][r];
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fold[(qn++) * 64 + lane] = accb[tb][r];
+        }
+        __syncthreads();
+        if (xg < half) {
+            int qn = 0;
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+                for (int ta = 0; ta < TAW; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[xi][ta][tb][r] += fold[(qn++) * 64 + lane];
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accb[tb][r] += fold[(qn++) * 64 + lane];
+        }
+    }
+    if (xg != 0) return;
+    // partial sums: [xi][a][b] (+ [b] bias); D[row = a_local = 4g + r][col = b_local = i]
+    float* dst = a.part + (long)blockIdx.x * a.pstride;
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int ta = 0; ta < TAW; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) {
+                const int bb = b0 + tb * 16 + i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int aa = a0 + (hp * TAW + ta) * 16 + 4 * g + r;
+                    if (aa < a.Ca && bb < a.Cb) dst[((long)xi * a.Ca + aa) * a.Cb + bb] = acc[xi][ta][tb][r];
+                }
+            }
+    if (do_bias && g == 0) {
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) {
+            const int bb = b0 + tb * 16 + i;
+            if (bb < a.Cb) dst[(long)16 * a.Ca * a.Cb + bb] = accb[tb][0];
+        }
+    }
+}
+
 // VALU version for tiny channel counts (Ca*Cb*taps <= 144).  One wave = one partial.  The wider channel dimension is
 // split into quads across neighbouring lanes (LPP lanes per pixel), so a lane carries 36-72 accumulators instead of 144:
 // several waves fit on a SIMD and hide the load latency, the dY row is read with coalesced 16-byte loads, and the final
@@ -2252,6 +2512,7 @@ struct WreduceArgs {
     float* dw; long s_a, s_b; int flip;     // dw[a*s_a + b*s_b + tap']
     float* dbias;                            // nullable, [Cb]
     int accumulate;
+    int wino;                                // partial sums are Winograd-domain [16][Ca][Cb] (wgrad_wino_k): fold, then dw = G^T M G
 };
 
 // EL output elements x (256 / EL) partial lanes per workgroup.  The host picks EL so that the grid fills the chip:
@@ -2299,6 +2560,85 @@ __device__ __forceinline__ void wgrad_reduce_body(const WreduceArgs& a, long blo
     }
 }
 
+// Winograd-domain partial sums (wgrad_wino_k): 16 (a, b) pairs x 16 partial lanes per workgroup; every thread folds the 16 xi sums of its
+// pair over its share of the partials, the lanes are folded by a fixed tree, and lane 0 applies dw[ky][kx] = sum G[r][ky] G[c][kx] M[r][c]
+// (G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]) and scatters the nine taps.  Workgroups behind the pairs fold the bias sums.
+template <bool ATOMIC>
+__device__ __forceinline__ void wgrad_reduce_wino_body(const WreduceArgs& a, long block, float* sh) {
+    constexpr int EL = 16, PL = 16;
+    const long npair = (long)a.Ca * a.Cb;
+    const long nblk = (npair + EL - 1) / EL;
+    const int el = threadIdx.x % EL, pl = threadIdx.x / EL;
+    if (block >= nblk) {                                   // bias elements: 16 per workgroup
+        const long e = (block - nblk) * EL + el;
+        float s = 0.f;
+        if (e < a.Cb)
+            for (int k = pl; k < a.nparts; k += PL) s += a.part[(long)k * a.pstride + 16 * npair + e];
+        sh[pl * EL + el] = s;
+        __syncthreads();
+#pragma unroll
+        for (int h = PL / 2; h >= 1; h >>= 1) {
+            if (pl < h) sh[pl * EL + el] += sh[(pl + h) * EL + el];
+            __syncthreads();
+        }
+        if (pl == 0 && e < a.Cb && a.dbias) {
+            float* d = a.dbias + e;
+            if (ATOMIC) atomicAdd(d, sh[el]);
+            else *d = a.accumulate ? *d + sh[el] : sh[el];
+        }
+        return;
+    }
+    const long e = block * EL + el;
+    float m[16];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) m[xi] = 0.f;
+    if (e < npair) {
+        for (int k = pl; k < a.nparts; k += PL) {
+            const float* p = a.part + (long)k * a.pstride + e;
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) m[xi] += p[(long)xi * npair];
+        }
+    }
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) sh[(xi * PL + pl) * EL + el] = m[xi];
+    __syncthreads();
+#pragma unroll
+    for (int h = PL / 2; h >= 1; h >>= 1) {               // fixed tree: deterministic
+        if (pl < h) {
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) sh[(xi * PL + pl) * EL + el] += sh[(xi * PL + pl + h) * EL + el];
+        }
+        __syncthreads();
+    }
+    if (pl != 0 || e >= npair) return;
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) m[xi] = sh[(xi * PL) * EL + el];
+    float t[3][4];                                         // rows: G^T M
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        t[0][cc] = m[cc] + 0.5f * (m[4 + cc] + m[8 + cc]);
+        t[1][cc] = 0.5f * (m[4 + cc] - m[8 + cc]);
+        t[2][cc] = 0.5f * (m[4 + cc] + m[8 + cc]) + m[12 + cc];
+    }
+    const int bb = (int)(e % a.Cb), aa = (int)(e / a.Cb);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const float o[3] = {t[ky][0] + 0.5f * (t[ky][1] + t[ky][2]), 0.5f * (t[ky][1] - t[ky][2]), 0.5f * (t[ky][1] + t[ky][2]) + t[ky][3]};
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int tap = ky * 3 + kx, tt = a.flip ? 8 - tap : tap;
+            float* d = a.dw + (long)aa * a.s_a + (long)bb * a.s_b + tt;
+            if (ATOMIC) atomicAdd(d, o[kx]);
+            else *d = a.accumulate ? *d + o[kx] : o[kx];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_wino_k(WreduceArgs a) {
+    __shared__ float sh[256 * 16];
+    wgrad_reduce_wino_body<false>(a, blockIdx.x, sh);
+}
+
 template <int EL>
 __global__ __launch_bounds__(256) void wgrad_reduce_k(WreduceArgs a) {
     __shared__ float sh[256];
@@ -2316,7 +2656,7 @@ struct WreduceEntry {
 };
 __global__ __launch_bounds__(256) void wgrad_reduce_table_k(const WreduceEntry* tab, int count) {
     __shared__ WreduceEntry ent;
-    __shared__ float sh[256];
+    __shared__ float sh[256 * 16];
     if (threadIdx.x == 0) {
         int lo = 0, hi = count - 1;
         while (lo < hi) {
@@ -2327,6 +2667,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_table_k(const WreduceEntry* 
     }
     __syncthreads();
     const long block = (long)blockIdx.x - ent.block0;
+    if (ent.a.wino) { wgrad_reduce_wino_body<true>(ent.a, block, sh); return; }
     if (ent.el == 64) wgrad_reduce_body<64, true>(ent.a, block, sh);
     else if (ent.el == 16) wgrad_reduce_body<16, true>(ent.a, block, sh);
     else wgrad_reduce_body<4, true>(ent.a, block, sh);
@@ -2864,7 +3205,7 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
 }
 
 // wgrad partitioning shared by the workspace query and the launch
-struct WgradPlan { bool small; int TA, TB, nga, ngb, rows_per_wave, nparts, nw; };
+struct WgradPlan { bool small; int TA, TB, nga, ngb, rows_per_wave, nparts, nw; bool wino; };
 
 // per-shape launch partition of wgrad_mfma_k chosen by the host autotuner (rv_conv_wgrad_set_plan): waves per workgroup and
 // workgroups on the chip.  Keyed like rv_conv_wgrad_workspace_bytes, whose result depends on it.
@@ -2882,6 +3223,7 @@ static const WgradTune* wgrad_tuned(int taps, int B, int Hv, int Ca, int Cb) {
 static WgradPlan wgrad_plan(int taps, int B, int Hv, int Ca, int Cb) {
     WgradPlan p;
     p.nw = 0;
+    p.wino = false;
     const int nrows = B * Hv;
     p.small = (Ca * Cb * taps <= 144) && (Ca < 8 || Cb < 8);
     if (p.small) {
@@ -2902,15 +3244,18 @@ static WgradPlan wgrad_plan(int taps, int B, int Hv, int Ca, int Cb) {
     static int want_total = 0;
     if (!want_total) { const char* e = getenv("RV_WGRAD_WGS"); want_total = e ? atoi(e) : 256; }
     int total = want_total;
+    p.wino = false;
     if (const WgradTune* t = wgrad_tuned(taps, B, Hv, Ca, Cb)) {
         if (t->wgs > 0) total = t->wgs;
-        p.nw = t->nw;
+        p.nw = t->nw & 15;
+        p.wino = (t->nw & 16) != 0 && taps == 9 && (Hv & 1) == 0;      // Winograd F(3x3, 2x2) form: tile rows = row pairs
     }
     int want = total / (p.nga * p.ngb);        // one resident workgroup per CU (register-limited): exactly one block wave, no tail
     if (want < 4) want = 4;
-    if (want > nrows) want = nrows;
-    p.rows_per_wave = cdiv(nrows, want);     // rows per WORKGROUP for the LDS-staged kernel
-    p.nparts = cdiv(nrows, p.rows_per_wave);
+    const int units = p.wino ? nrows / 2 : nrows;     // what a workgroup walks: rows, or row pairs
+    if (want > units) want = units;
+    p.rows_per_wave = cdiv(units, want);     // rows (row pairs) per WORKGROUP for the LDS-staged kernels
+    p.nparts = cdiv(units, p.rows_per_wave);
     return p;
 }
 
@@ -2922,7 +3267,7 @@ static inline bool wgrad_sliced(int taps, int Ca, int Cb) { return taps == 9 && 
 // Autotuner hook: the partition rv_conv_wgrad uses for this shape from now on (nw: 4 or 8 waves per workgroup, 0 = default;
 // wgs: workgroups on the chip, 0 = default 256).  Changes what rv_conv_wgrad_workspace_bytes returns for the shape.
 int rv_conv_wgrad_set_plan(int taps, int B, int Hv, int Ca, int Cb, int nw, int wgs) {
-    RV_CHECK_ARG(nw == 0 || nw == 4 || nw == 8, "rv_conv_wgrad_set_plan: nw must be 0, 4 or 8");
+    RV_CHECK_ARG(nw == 0 || nw == 4 || nw == 8 || nw == 24, "rv_conv_wgrad_set_plan: nw must be 0, 4, 8 or 24 (8 waves, Winograd form)");
     RV_CHECK_ARG(wgs == 0 || (wgs >= 32 && wgs <= 4096), "rv_conv_wgrad_set_plan: wgs out of range");
     WgradTune* t = const_cast<WgradTune*>(wgrad_tuned(taps, B, Hv, Ca, Cb));
     if (!t) {
@@ -2936,7 +3281,7 @@ int rv_conv_wgrad_set_plan(int taps, int B, int Hv, int Ca, int Cb, int nw, int 
 long rv_conv_wgrad_workspace_bytes(int taps, int B, int Hv, int Ca, int Cb) {
     if (wgrad_sliced(taps, Ca, Cb)) Cb = 16;
     WgradPlan p = wgrad_plan(taps, B, Hv, Ca, Cb);
-    return (long)p.nparts * ((long)taps * Ca * Cb + Cb) * 4;
+    return (long)p.nparts * ((long)(p.wino ? 16 : taps) * Ca * Cb + Cb) * 4;
 }
 
 // G[tap][a][b] = sum_p U[f(p,tap)][a] * V[p][b], db[b] = sum_p V[p][b]; results scattered to
@@ -3012,7 +3357,25 @@ static int conv_wgrad_impl(int mode, const float* U, int u_ld, int Hu, int Wu, i
     a.pstride = (long)taps * Ca * Cb + Cb;
     a.fd_vplane = fastdiv_make((unsigned)(Hv * Wv)); a.fd_wv = fastdiv_make((unsigned)Wv);
     RV_CHECK_ARG((long)B * Hv * Wv < (1L << 31), "rv_conv_wgrad: more than 2^31 pixels");
-    const WgradPlan plan = wgrad_plan(taps, B, Hv, Ca, Cb);
+    WgradPlan plan = wgrad_plan(taps, B, Hv, Ca, Cb);
+    size_t wino_lds = 0;
+    if (plan.wino) {
+        // the Winograd form needs six input rows and four dY rows in LDS at once (whole 1 KiB DMA pieces) and the direct kernel's geometry
+        const int WT4 = (((Wv + 1) / 2) + 3) & ~3, ppa = 64 / (plan.TA * 4), ppb = 64 / (plan.TB * 4);
+        const int UPp = cdiv(2 * WT4 + 2, ppa) * ppa, VPp = cdiv(2 * WT4, ppb) * ppb;
+        wino_lds = ((size_t)6 * UPp * plan.TA * 16 + (size_t)4 * VPp * plan.TB * 16) * sizeof(float);
+        const int nh_ = (plan.TA == 2 && plan.TB == 2) ? 2 : 1, nxg_ = 8 / nh_;
+        const size_t fold = (size_t)nh_ * (nxg_ / 2) * (16 * (plan.TA / nh_) * plan.TB + plan.TB) * 4 * 64 * sizeof(float);
+        if (wino_lds < fold) wino_lds = fold;
+        if (want_bf || mode != 0 || Hu != Hv || Wu != Wv || wino_lds > 160 * 1024) {
+            const long ws_wino = (long)plan.nparts * (16L * Ca * Cb + Cb) * 4;          // (what the caller sized the workspace for)
+            plan.wino = false;                             // ... this launch runs the direct form on the same partition of ROWS
+            plan.rows_per_wave *= 2;
+            plan.nparts = cdiv((long)B * Hv, plan.rows_per_wave);
+            RV_CHECK_ARG((long)plan.nparts * a.pstride * 4 <= ws_wino, "rv_conv_wgrad: workspace");
+        }
+    }
+    if (plan.wino) a.pstride = 16L * Ca * Cb + Cb;
     RV_CHECK_ARG(workspace_bytes >= (long)plan.nparts * a.pstride * 4, "rv_conv_wgrad: workspace too small");
     a.part = (float*)workspace;
     a.nparts = plan.nparts; a.rows_per_wave = plan.rows_per_wave; a.ngb = plan.ngb;
@@ -3115,7 +3478,20 @@ static int conv_wgrad_impl(int mode, const float* U, int u_ld, int Hu, int Wu, i
         else if (TA == 2 && TB == 1) RV_WG1(kh, kw, ss, pp, 2, 1);                               \
         else RV_WG1(kh, kw, ss, pp, 2, 2);                                                       \
     } while (0)
-        if (bf) {
+        if (plan.wino) {
+#define RV_WW(ta, tb)                                                                             \
+    do {                                                                                         \
+        auto kern = wgrad_wino_k<ta, tb, 8>;                                                     \
+        if (wino_lds > 64 * 1024)                                                                \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino_lds); \
+        hipLaunchKernelGGL(kern, grid, dim3(512), wino_lds, st, a);                              \
+    } while (0)
+            if (TA == 1 && TB == 1) RV_WW(1, 1);
+            else if (TA == 1 && TB == 2) RV_WW(1, 2);
+            else if (TA == 2 && TB == 1) RV_WW(2, 1);
+            else RV_WW(2, 2);
+#undef RV_WW
+        } else if (bf) {
             if (TA == 1 && TB == 1) RV_WG1B(1, 1);
             else if (TA == 1 && TB == 2) RV_WG1B(1, 2);
             else if (TA == 2 && TB == 1) RV_WG1B(2, 1);
@@ -3138,6 +3514,17 @@ reduce:
         WreduceArgs r;
         r.part = a.part; r.pstride = a.pstride; r.nparts = a.nparts; r.taps = taps; r.Ca = Ca; r.Cb = Cb;
         r.dw = dw; r.s_a = s_a; r.s_b = s_b; r.flip = flip; r.dbias = dbias; r.accumulate = accumulate;
+        r.wino = (!plan.small && plan.wino) ? 1 : 0;
+        if (r.wino) {                                      // 16 (a, b) pairs per workgroup, then the bias elements
+            const long nblk = cdiv((long)Ca * Cb, 16) + (dbias ? cdiv(Cb, 16) : 0);
+            if (defer) {
+                defer->a = r; defer->block0 = nblk; defer->el = 16; defer->pad = 0;
+                return RV_OK;
+            }
+            hipLaunchKernelGGL(wgrad_reduce_wino_k, dim3((unsigned)nblk), dim3(256), 0, st, r);
+            RV_LAUNCH_CHECK("rv_conv_wgrad(reduce, winograd)");
+            return RV_OK;
+        }
         long nel = (long)taps * Ca * Cb + (dbias ? Cb : 0);
         const int el = (cdiv(nel, 64) >= 256 || a.nparts <= 8) ? 64 : ((cdiv(nel, 16) >= 256 || a.nparts <= 32) ? 16 : 4);
         if (defer) {

@@ -608,7 +608,10 @@ def _tune_wgrad(lib, mode, taps, u, uld, hu, wu, ca, v, vld, hv, wv, cb, bb, w, 
     dw = torch.empty_like(w)
     db = torch.empty(cb, device=w.device, dtype=torch.float32)
     best, choice = None, (0, 0)
-    for nw, wgs in ((8, 256), (8, 512), (4, 256), (4, 512), (8, 128), (8, 1024)):
+    cands = [(8, 256), (8, 512), (4, 256), (4, 512), (8, 128), (8, 1024)]
+    if taps == 9 and hv % 2 == 0 and os.environ.get('RV_TUNE_WGRAD_WINO', '1') != '0':
+        cands += [(24, 256), (24, 512), (24, 128)]          # nw = 24: eight waves, Winograd F(3x3, 2x2) form (wgrad_wino_k)
+    for nw, wgs in cands:
         if lib.rv_conv_wgrad_set_plan(taps, bb, hv, ca, cb, nw, wgs) != 0:
             continue
         nbytes = lib.rv_conv_wgrad_workspace_bytes(taps, bb, hv, ca, cb)

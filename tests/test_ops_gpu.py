@@ -696,3 +696,52 @@ def test_direct_conv_in_workgroup_splitk_vs_torch(dev, kind, cin, cout, H, W, al
     assert rel_err(nchw(yg), yr) < TOL
     assert rel_err(nchw(g[0].grad), leaves[0].grad) < TOL_G
     assert rel_err(g[1].grad, leaves[1].grad) < TOL_G and rel_err(g[2].grad, leaves[2].grad) < TOL_G
+
+
+WGRAD_WINO_CASES = [('c3', 32, 32, 12, 57), ('c3', 64, 64, 8, 28), ('t3', 96, 48, 10, 57), ('c3', 16, 16, 6, 229), ('c3', 48, 24, 8, 114),
+                    ('t3', 192, 96, 4, 28), ('c3', 16, 32, 4, 114), ('c3', 128, 128, 6, 14), ('c3', 24, 16, 4, 37), ('t3', 16, 8, 6, 229)]
+
+
+@pytest.mark.parametrize('kind,cin,cout,H,W', WGRAD_WINO_CASES)
+def test_wgrad_winograd_form_vs_torch(dev, kind, cin, cout, H, W):
+    """The Winograd F(3x3, 2x2) weight-gradient kernel (plan code nw = 24): dW and db of Conv2d / ConvTranspose2d 3x3 against torch
+    autograd -- odd and even widths, channel counts that pad the 16 / 32-channel groups, fresh and accumulating destinations, the
+    immediate and the deferred (table) reduction -- and against the direct form on the same operands."""
+    import torch.nn.functional as F
+    from reconvat_amd import ops, _lib
+    lib = _lib.load()
+    B = 3
+    x = rnd(B, H, W, cin, seed=1).to(dev)
+    dy = rnd(B, H, W, cout, seed=2).to(dev)
+    wshape = (cout, cin, 3, 3) if kind == 'c3' else (cin, cout, 3, 3)
+    w = rnd(*wshape, seed=3).to(dev)
+    xt = x.cpu().permute(0, 3, 1, 2).double().requires_grad_(False)
+    wt = w.cpu().double().requires_grad_(True)
+    bt = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    yt = F.conv2d(xt, wt, bt, padding=1) if kind == 'c3' else F.conv_transpose2d(xt, wt, bt, padding=1)
+    yt.backward(dy.cpu().permute(0, 3, 1, 2).double())
+    old = ops.AUTOTUNE
+    ops.AUTOTUNE = False                                    # (the plan is pinned by hand below)
+    try:
+        res = {}
+        for name, nw in (('direct', 8), ('wino', 24)):
+            assert lib.rv_conv_wgrad_set_plan(9, B, H, cin, cout, nw, 256) == 0
+            dw, db = ops.conv_wgrad(kind, x, dy, w, True)
+            res[name] = (dw.clone(), db.clone())
+            # accumulate into existing gradients, immediate and deferred reduction
+            for deferred in (False, True):
+                gw, gb = torch.full_like(w, 0.5), torch.full((cout,), -0.25, device=dev)
+                if deferred:
+                    with ops.deferred_wgrad_reductions() as pend:
+                        ops.conv_wgrad(kind, x, dy, w, True, gw, gb)
+                        pend.flush()
+                else:
+                    ops.conv_wgrad(kind, x, dy, w, True, gw, gb)
+                torch.cuda.synchronize()
+                assert rel_err(gw - 0.5, dw) < 1e-5 and rel_err(gb + 0.25, db) < 1e-5, (name, deferred)
+        assert rel_err(res['wino'][0], wt.grad.float()) < 2e-5, rel_err(res['wino'][0], wt.grad.float())
+        assert rel_err(res['wino'][1], bt.grad.float()) < 2e-5
+        assert rel_err(res['wino'][0], res['direct'][0]) < 2e-5
+    finally:
+        lib.rv_conv_wgrad_set_plan(9, B, H, cin, cout, 0, 0)
+        ops.AUTOTUNE = old
