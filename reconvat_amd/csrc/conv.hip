@@ -1886,11 +1886,11 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
     if (ABL(a) & 32) { if (acc[0][0][0][0] == 123.456f) a.part[0] = accbs[0]; return; }
     // fold the x groups through LDS as a binary tree: in every round the upper half of the surviving x groups publishes, the lower
     // half accumulates (log2(NXG) rounds of two barriers instead of NXG - 1: the linear fold was 2.8 us of every launch)
-    constexpr int NACC = (TAPS * TAW * TB + TB) * 4;
+    constexpr int NVEC = TAPS * TAW * TB + TB;              // accumulator vectors per lane: one 16-byte LDS access each
     static_assert((NXG & (NXG - 1)) == 0, "x groups must be a power of two");
 #pragma unroll
     for (int half = NXG / 2; half >= 1; half >>= 1) {
-        float* fold = smem + (hp * (NXG / 2) + (xg & (half - 1))) * NACC * 64;
+        f32x4* fold = reinterpret_cast<f32x4*>(smem) + (hp * (NXG / 2) + (xg & (half - 1))) * NVEC * 64 + lane;
         __syncthreads();
         if (xg >= half && xg < 2 * half) {
             int q = 0;
@@ -1899,13 +1899,9 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
 #pragma unroll
                 for (int ta = 0; ta < TAW; ++ta)
 #pragma unroll
-                    for (int tb = 0; tb < TB; ++tb)
+                    for (int tb = 0; tb < TB; ++tb) fold[(q++) * 64] = acc[t][ta][tb];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) fold[(q++) * 64 + lane] = acc[t][ta][tb][r];
-#pragma unroll
-            for (int tb = 0; tb < TB; ++tb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) fold[(q++) * 64 + lane] = accb[tb][r];
+            for (int tb = 0; tb < TB; ++tb) fold[(q++) * 64] = accb[tb];
         }
         __syncthreads();
         if (xg < half) {
@@ -1915,13 +1911,9 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
 #pragma unroll
                 for (int ta = 0; ta < TAW; ++ta)
 #pragma unroll
-                    for (int tb = 0; tb < TB; ++tb)
+                    for (int tb = 0; tb < TB; ++tb) acc[t][ta][tb] += fold[(q++) * 64];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[t][ta][tb][r] += fold[(q++) * 64 + lane];
-#pragma unroll
-            for (int tb = 0; tb < TB; ++tb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) accb[tb][r] += fold[(q++) * 64 + lane];
+            for (int tb = 0; tb < TB; ++tb) accb[tb] += fold[(q++) * 64];
         }
     }
     TS(4);
@@ -1980,7 +1972,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
 // runs over TILES (k = 4 consecutive tiles of a tile row per instruction): lane (i, g) holds channel i of tile g, reads the 16 patch
 // values of its (input channel, tile) and the 4 dY values of its (output channel, tile) from LDS (4-byte reads), transforms both in
 // registers (32 + 12 adds) and issues one MFMA per xi and (a-tile, b-tile) pair.  The accumulators hold M[xi] (16 x 16 per tile pair);
-// the 4x4 -> 3x3 transform G^T M G is applied by the reduction pass (wgrad_reduce_wino_body), so the partial sums are [16][Ca][Cb].
+// the 4x4 -> 3x3 transform G^T M G is lane-local and applied before the fold, so the partial sums are the direct kernel's [9][Ca][Cb].
 // Work partition, staging ring, fold and partial-sum stores follow wgrad_mfma_k, with ROW PAIRS instead of rows: one barrier interval
 // covers two output rows (one tile row); the input ring holds 6 rows (4 in use, 2 arriving), dY is double-buffered two rows at a time.
 // LDS images are permuted inside each 1 KiB DMA piece so that the two tiles of a 32-lane read group sit on different bank halves
@@ -2167,50 +2159,67 @@ __global__ __launch_bounds__(NW * 64) void wgrad_wino_k(WgradArgs a) {
             accb[tb] = (f32x4){sb, sb, sb, sb};
         }
     }
-    // fold the x groups through LDS as a binary tree (as wgrad_mfma_k)
-    constexpr int NACC = (16 * TAW * TB + TB) * 4;
+    if (ABL(a) & 32) { if (acc[0][0][0][0] == 123.456f) a.part[0] = accbs[0]; return; }     // (timing ablation: no fold / stores)
+    // dW = G^T M G per (a, b) element, G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]: every lane holds all sixteen M[xi] of its elements, so
+    // the 4x4 -> 3x3 transform is lane-local (linear: it commutes with the folds over x groups and workgroups that follow) and the
+    // partial sums leave in the direct kernel's [9][Ca][Cb] layout -- 16/9 fewer bytes, the same reduction pass
+    f32x4 tapv[9][TAW][TB];
+#pragma unroll
+    for (int ta = 0; ta < TAW; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) {
+            f32x4 t[3][4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const f32x4 h = 0.5f * (acc[4 + cc][ta][tb] + acc[8 + cc][ta][tb]);
+                t[0][cc] = acc[cc][ta][tb] + h;
+                t[1][cc] = 0.5f * (acc[4 + cc][ta][tb] - acc[8 + cc][ta][tb]);
+                t[2][cc] = h + acc[12 + cc][ta][tb];
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const f32x4 h = 0.5f * (t[ky][1] + t[ky][2]);
+                tapv[ky * 3 + 0][ta][tb] = t[ky][0] + h;
+                tapv[ky * 3 + 1][ta][tb] = 0.5f * (t[ky][1] - t[ky][2]);
+                tapv[ky * 3 + 2][ta][tb] = h + t[ky][3];
+            }
+        }
+    // fold the x groups through LDS as a binary tree (as wgrad_mfma_k), one 16-byte LDS access per accumulator vector
+    constexpr int NVEC = 9 * TAW * TB + TB;
     static_assert((NXG & (NXG - 1)) == 0, "x groups must be a power of two");
 #pragma unroll
     for (int half = NXG / 2; half >= 1; half >>= 1) {
-        float* fold = smem + (hp * (NXG / 2) + (xg & (half - 1))) * NACC * 64;
+        f32x4* fold = reinterpret_cast<f32x4*>(smem) + (hp * (NXG / 2) + (xg & (half - 1))) * NVEC * 64 + lane;
         __syncthreads();
         if (xg >= half && xg < 2 * half) {
             int qn = 0;
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi)
+            for (int t = 0; t < 9; ++t)
 #pragma unroll
                 for (int ta = 0; ta < TAW; ++ta)
 #pragma unroll
-                    for (int tb = 0; tb < TB; ++tb)
+                    for (int tb = 0; tb < TB; ++tb) fold[(qn++) * 64] = tapv[t][ta][tb];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) fold[(qn++) * 64 + lane] = acc[xi][ta][tb][r];
-#pragma unroll
-            for (int tb = 0; tb < TB; ++tb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) fold[(qn++) * 64 + lane] = accb[tb][r];
+            for (int tb = 0; tb < TB; ++tb) fold[(qn++) * 64] = accb[tb];
         }
         __syncthreads();
         if (xg < half) {
             int qn = 0;
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi)
+            for (int t = 0; t < 9; ++t)
 #pragma unroll
                 for (int ta = 0; ta < TAW; ++ta)
 #pragma unroll
-                    for (int tb = 0; tb < TB; ++tb)
+                    for (int tb = 0; tb < TB; ++tb) tapv[t][ta][tb] += fold[(qn++) * 64];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[xi][ta][tb][r] += fold[(qn++) * 64 + lane];
-#pragma unroll
-            for (int tb = 0; tb < TB; ++tb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) accb[tb][r] += fold[(qn++) * 64 + lane];
+            for (int tb = 0; tb < TB; ++tb) accb[tb] += fold[(qn++) * 64];
         }
     }
     if (xg != 0) return;
-    // partial sums: [xi][a][b] (+ [b] bias); D[row = a_local = 4g + r][col = b_local = i]
+    // partial sums in the direct kernel's layout: [tap][a][b] (+ [b] bias); D[row = a_local = 4g + r][col = b_local = i]
     float* dst = a.part + (long)blockIdx.x * a.pstride;
 #pragma unroll
-    for (int xi = 0; xi < 16; ++xi)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int ta = 0; ta < TAW; ++ta)
 #pragma unroll
@@ -2219,14 +2228,14 @@ __global__ __launch_bounds__(NW * 64) void wgrad_wino_k(WgradArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int aa = a0 + (hp * TAW + ta) * 16 + 4 * g + r;
-                    if (aa < a.Ca && bb < a.Cb) dst[((long)xi * a.Ca + aa) * a.Cb + bb] = acc[xi][ta][tb][r];
+                    if (aa < a.Ca && bb < a.Cb) dst[((long)t * a.Ca + aa) * a.Cb + bb] = tapv[t][ta][tb][r];
                 }
             }
     if (do_bias && g == 0) {
 #pragma unroll
         for (int tb = 0; tb < TB; ++tb) {
             const int bb = b0 + tb * 16 + i;
-            if (bb < a.Cb) dst[(long)16 * a.Ca * a.Cb + bb] = accb[tb][0];
+            if (bb < a.Cb) dst[(long)9 * a.Ca * a.Cb + bb] = accb[tb][0];
         }
     }
 }
@@ -2512,7 +2521,6 @@ struct WreduceArgs {
     float* dw; long s_a, s_b; int flip;     // dw[a*s_a + b*s_b + tap']
     float* dbias;                            // nullable, [Cb]
     int accumulate;
-    int wino;                                // partial sums are Winograd-domain [16][Ca][Cb] (wgrad_wino_k): fold, then dw = G^T M G
 };
 
 // EL output elements x (256 / EL) partial lanes per workgroup.  The host picks EL so that the grid fills the chip:
@@ -2560,85 +2568,6 @@ __device__ __forceinline__ void wgrad_reduce_body(const WreduceArgs& a, long blo
     }
 }
 
-// Winograd-domain partial sums (wgrad_wino_k): 16 (a, b) pairs x 16 partial lanes per workgroup; every thread folds the 16 xi sums of its
-// pair over its share of the partials, the lanes are folded by a fixed tree, and lane 0 applies dw[ky][kx] = sum G[r][ky] G[c][kx] M[r][c]
-// (G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]) and scatters the nine taps.  Workgroups behind the pairs fold the bias sums.
-template <bool ATOMIC>
-__device__ __forceinline__ void wgrad_reduce_wino_body(const WreduceArgs& a, long block, float* sh) {
-    constexpr int EL = 16, PL = 16;
-    const long npair = (long)a.Ca * a.Cb;
-    const long nblk = (npair + EL - 1) / EL;
-    const int el = threadIdx.x % EL, pl = threadIdx.x / EL;
-    if (block >= nblk) {                                   // bias elements: 16 per workgroup
-        const long e = (block - nblk) * EL + el;
-        float s = 0.f;
-        if (e < a.Cb)
-            for (int k = pl; k < a.nparts; k += PL) s += a.part[(long)k * a.pstride + 16 * npair + e];
-        sh[pl * EL + el] = s;
-        __syncthreads();
-#pragma unroll
-        for (int h = PL / 2; h >= 1; h >>= 1) {
-            if (pl < h) sh[pl * EL + el] += sh[(pl + h) * EL + el];
-            __syncthreads();
-        }
-        if (pl == 0 && e < a.Cb && a.dbias) {
-            float* d = a.dbias + e;
-            if (ATOMIC) atomicAdd(d, sh[el]);
-            else *d = a.accumulate ? *d + sh[el] : sh[el];
-        }
-        return;
-    }
-    const long e = block * EL + el;
-    float m[16];
-#pragma unroll
-    for (int xi = 0; xi < 16; ++xi) m[xi] = 0.f;
-    if (e < npair) {
-        for (int k = pl; k < a.nparts; k += PL) {
-            const float* p = a.part + (long)k * a.pstride + e;
-#pragma unroll
-            for (int xi = 0; xi < 16; ++xi) m[xi] += p[(long)xi * npair];
-        }
-    }
-#pragma unroll
-    for (int xi = 0; xi < 16; ++xi) sh[(xi * PL + pl) * EL + el] = m[xi];
-    __syncthreads();
-#pragma unroll
-    for (int h = PL / 2; h >= 1; h >>= 1) {               // fixed tree: deterministic
-        if (pl < h) {
-#pragma unroll
-            for (int xi = 0; xi < 16; ++xi) sh[(xi * PL + pl) * EL + el] += sh[(xi * PL + pl + h) * EL + el];
-        }
-        __syncthreads();
-    }
-    if (pl != 0 || e >= npair) return;
-#pragma unroll
-    for (int xi = 0; xi < 16; ++xi) m[xi] = sh[(xi * PL) * EL + el];
-    float t[3][4];                                         // rows: G^T M
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-        t[0][cc] = m[cc] + 0.5f * (m[4 + cc] + m[8 + cc]);
-        t[1][cc] = 0.5f * (m[4 + cc] - m[8 + cc]);
-        t[2][cc] = 0.5f * (m[4 + cc] + m[8 + cc]) + m[12 + cc];
-    }
-    const int bb = (int)(e % a.Cb), aa = (int)(e / a.Cb);
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const float o[3] = {t[ky][0] + 0.5f * (t[ky][1] + t[ky][2]), 0.5f * (t[ky][1] - t[ky][2]), 0.5f * (t[ky][1] + t[ky][2]) + t[ky][3]};
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int tap = ky * 3 + kx, tt = a.flip ? 8 - tap : tap;
-            float* d = a.dw + (long)aa * a.s_a + (long)bb * a.s_b + tt;
-            if (ATOMIC) atomicAdd(d, o[kx]);
-            else *d = a.accumulate ? *d + o[kx] : o[kx];
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void wgrad_reduce_wino_k(WreduceArgs a) {
-    __shared__ float sh[256 * 16];
-    wgrad_reduce_wino_body<false>(a, blockIdx.x, sh);
-}
-
 template <int EL>
 __global__ __launch_bounds__(256) void wgrad_reduce_k(WreduceArgs a) {
     __shared__ float sh[256];
@@ -2656,7 +2585,7 @@ struct WreduceEntry {
 };
 __global__ __launch_bounds__(256) void wgrad_reduce_table_k(const WreduceEntry* tab, int count) {
     __shared__ WreduceEntry ent;
-    __shared__ float sh[256 * 16];
+    __shared__ float sh[256];
     if (threadIdx.x == 0) {
         int lo = 0, hi = count - 1;
         while (lo < hi) {
@@ -2667,7 +2596,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_table_k(const WreduceEntry* 
     }
     __syncthreads();
     const long block = (long)blockIdx.x - ent.block0;
-    if (ent.a.wino) { wgrad_reduce_wino_body<true>(ent.a, block, sh); return; }
     if (ent.el == 64) wgrad_reduce_body<64, true>(ent.a, block, sh);
     else if (ent.el == 16) wgrad_reduce_body<16, true>(ent.a, block, sh);
     else wgrad_reduce_body<4, true>(ent.a, block, sh);
@@ -3281,7 +3209,7 @@ int rv_conv_wgrad_set_plan(int taps, int B, int Hv, int Ca, int Cb, int nw, int 
 long rv_conv_wgrad_workspace_bytes(int taps, int B, int Hv, int Ca, int Cb) {
     if (wgrad_sliced(taps, Ca, Cb)) Cb = 16;
     WgradPlan p = wgrad_plan(taps, B, Hv, Ca, Cb);
-    return (long)p.nparts * ((long)(p.wino ? 16 : taps) * Ca * Cb + Cb) * 4;
+    return (long)p.nparts * ((long)taps * Ca * Cb + Cb) * 4;
 }
 
 // G[tap][a][b] = sum_p U[f(p,tap)][a] * V[p][b], db[b] = sum_p V[p][b]; results scattered to
@@ -3365,17 +3293,14 @@ static int conv_wgrad_impl(int mode, const float* U, int u_ld, int Hu, int Wu, i
         const int UPp = cdiv(2 * WT4 + 2, ppa) * ppa, VPp = cdiv(2 * WT4, ppb) * ppb;
         wino_lds = ((size_t)6 * UPp * plan.TA * 16 + (size_t)4 * VPp * plan.TB * 16) * sizeof(float);
         const int nh_ = (plan.TA == 2 && plan.TB == 2) ? 2 : 1, nxg_ = 8 / nh_;
-        const size_t fold = (size_t)nh_ * (nxg_ / 2) * (16 * (plan.TA / nh_) * plan.TB + plan.TB) * 4 * 64 * sizeof(float);
+        const size_t fold = (size_t)nh_ * (nxg_ / 2) * (9 * (plan.TA / nh_) * plan.TB + plan.TB) * 4 * 64 * sizeof(float);
         if (wino_lds < fold) wino_lds = fold;
         if (want_bf || mode != 0 || Hu != Hv || Wu != Wv || wino_lds > 160 * 1024) {
-            const long ws_wino = (long)plan.nparts * (16L * Ca * Cb + Cb) * 4;          // (what the caller sized the workspace for)
-            plan.wino = false;                             // ... this launch runs the direct form on the same partition of ROWS
-            plan.rows_per_wave *= 2;
+            plan.wino = false;                             // this launch runs the direct form on the same partition, in ROWS
+            plan.rows_per_wave *= 2;                       // (the workspace was sized for this many partial sums: same layout)
             plan.nparts = cdiv((long)B * Hv, plan.rows_per_wave);
-            RV_CHECK_ARG((long)plan.nparts * a.pstride * 4 <= ws_wino, "rv_conv_wgrad: workspace");
         }
     }
-    if (plan.wino) a.pstride = 16L * Ca * Cb + Cb;
     RV_CHECK_ARG(workspace_bytes >= (long)plan.nparts * a.pstride * 4, "rv_conv_wgrad: workspace too small");
     a.part = (float*)workspace;
     a.nparts = plan.nparts; a.rows_per_wave = plan.rows_per_wave; a.ngb = plan.ngb;
@@ -3514,17 +3439,6 @@ reduce:
         WreduceArgs r;
         r.part = a.part; r.pstride = a.pstride; r.nparts = a.nparts; r.taps = taps; r.Ca = Ca; r.Cb = Cb;
         r.dw = dw; r.s_a = s_a; r.s_b = s_b; r.flip = flip; r.dbias = dbias; r.accumulate = accumulate;
-        r.wino = (!plan.small && plan.wino) ? 1 : 0;
-        if (r.wino) {                                      // 16 (a, b) pairs per workgroup, then the bias elements
-            const long nblk = cdiv((long)Ca * Cb, 16) + (dbias ? cdiv(Cb, 16) : 0);
-            if (defer) {
-                defer->a = r; defer->block0 = nblk; defer->el = 16; defer->pad = 0;
-                return RV_OK;
-            }
-            hipLaunchKernelGGL(wgrad_reduce_wino_k, dim3((unsigned)nblk), dim3(256), 0, st, r);
-            RV_LAUNCH_CHECK("rv_conv_wgrad(reduce, winograd)");
-            return RV_OK;
-        }
         long nel = (long)taps * Ca * Cb + (dbias ? Cb : 0);
         const int el = (cdiv(nel, 64) >= 256 || a.nparts <= 8) ? 64 : ((cdiv(nel, 16) >= 256 || a.nparts <= 32) ? 16 : 4);
         if (defer) {

@@ -52,4 +52,4 @@ def test_shipped_table_digest_is_pinned():
     assert 'MI355X' in meta.get('device', '') and meta.get('git'), meta.get('device')
 
 
-PINNED_DIGEST = 'f36772e6ff5da219'
+PINNED_DIGEST = 'a952625ca66439d2'

@@ -12,7 +12,7 @@ import os
 import sys
 from collections import defaultdict
 
-CONV = ('conv3x3_lds_k', 'conv3x3_wino_k', 'conv_mfma_k', 'conv_small_k', 'conv_narrow_out_k', 'conv_cin12_k', 'wgrad_mfma_k', 'wgrad_small_k', 'wgrad_small_sw_k', 'wgrad_cin1_k', 'wgrad_reduce_k',
+CONV = ('conv3x3_lds_k', 'conv3x3_wino_k', 'conv_mfma_k', 'conv_small_k', 'conv_narrow_out_k', 'conv_cin12_k', 'wgrad_mfma_k', 'wgrad_wino_k', 'wgrad_small_k', 'wgrad_small_sw_k', 'wgrad_cin1_k', 'wgrad_reduce_k',
         'wgrad_reduce_table_k')
 
 

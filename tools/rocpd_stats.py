@@ -19,7 +19,7 @@ FAMILIES = [
     ('conv3x3 fwd+dgrad (MFMA)', ('conv3x3_lds_k', 'conv3x3_wino_k')),
     ('conv direct 3x3/1x1/2x2 (MFMA / HBM)', ('conv_mfma_k',)),
     ('conv C<=2 layers (HBM)', ('conv_small_k', 'wgrad_small_k', 'conv_narrow_out_k', 'conv_cin12_k', 'wgrad_small_sw_k', 'wgrad_cin1_k')),
-    ('weight gradients (MFMA)', ('wgrad_mfma_k', 'wgrad_reduce', 'sums_fold')),
+    ('weight gradients (MFMA)', ('wgrad_mfma_k', 'wgrad_wino_k', 'wgrad_reduce', 'sums_fold')),
     ('linear GEMMs (MFMA)', ('gemm_', 'colsum', 'sigmoid', 'zero_strided')),
     ('local attention', ('attn_',)),
     ('BatchNorm + leaky-ReLU (HBM)', ('bn_',)),
