@@ -48,7 +48,7 @@ def conv_flops(name, a):
         taps = {0: 9, 1: 1, 2: 4, 3: 1}[mode]
         pix = b * h * w * 4 if mode == 3 else b * ho * wo
         return 2.0 * pix * cin * cout * taps
-    mode, ca, hv, wv, cb, b = a[0], a[5], a[8], a[9], a[10], a[11]
+    mode, ca, hv, wv, cb, b = a[0] & 0xff, a[5], a[8], a[9], a[10], a[11]          # (bit 8 of mode: bf16 operands)
     return 2.0 * b * hv * wv * ca * cb * {0: 9, 1: 1, 2: 4}[mode]
 
 
@@ -116,7 +116,7 @@ def measure_conv_phase(step_fn, device):
         if name == 'rv_conv_fwd':
             sig = (name, a[0]) + tuple(a[2:7]) + tuple(a[8:12]) + (a[15], ('bnbwd' if a[17] else 'bn') if a[16] else '')
         else:
-            sig = (name, a[0]) + tuple(a[2:6]) + tuple(a[7:12])
+            sig = (name, a[0]) + tuple(a[2:6]) + tuple(a[7:12])        # (a[0] carries the bf16 bit: bf16 launches are their own group)
         g = groups.setdefault(sig, {'count': 0, 'name': name, 'args': a})
         g['count'] += 1
     arena = torch.empty((3 << 30) // 4, device=device)             # 3 GiB of scratch operands
@@ -128,7 +128,7 @@ def measure_conv_phase(step_fn, device):
     entry_scratch = torch.empty(eb, dtype=torch.uint8)
 
     def deferrable(a):           # mirrors ops.conv_wgrad: accumulating calls, except the 1 -> many 3x3 layer
-        return bool(a[17]) and not (a[0] == 0 and a[5] == 1 and a[10] > 16)
+        return bool(a[17]) and not ((a[0] & 0xff) == 0 and a[5] == 1 and a[10] > 16)
 
     def deferred_fn(*a):
         return 0 if lib.rv_conv_wgrad_deferred(*a) > 0 else -1
@@ -210,7 +210,7 @@ def measure_conv_phase(step_fn, device):
             for i, a in enumerate(half):
                 a[1], a[6] = base, base + (512 << 20)
                 a[12], a[16] = base + (1 << 30), None
-                nbytes = lib.rv_conv_wgrad_workspace_bytes({0: 9, 1: 1, 2: 4}[a[0]], a[11], a[8], a[5], a[10])
+                nbytes = lib.rv_conv_wgrad_workspace_bytes({0: 9, 1: 1, 2: 4}[a[0] & 0xff], a[11], a[8], a[5], a[10])
                 if (off + nbytes) > ws.numel() * 4:
                     off = 0                                  # (scratch partial sums may alias: only the timing matters)
                 da = a[:17] + [ws.data_ptr() + off, nbytes, host.data_ptr() + i * eb, st.cuda_stream]
@@ -701,11 +701,12 @@ def main():
     }
     if rank == 0 and world == 1 and args.model == 'onset' and batch_l == args.batch == 8:       # (the roofline / parity legs are written for the headline workload)
         if not args.no_roofline:
-            eager = ra.TrainStep(model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=False)
+            eager = ra.TrainStep(model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=False, bf16_backward=args.bf16_backward)
             conv_ms, conv_flops_total, per_kernel, nlaunch, min_sets, bound = measure_conv_phase(eager, device)
             achieved = conv_flops_total / conv_ms / 1e9
             # in situ: one eager single-stream step, every family launch bracketed by HIP events on the launch stream
-            eager1 = ra.TrainStep(model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=False, dual_stream=False)
+            eager1 = ra.TrainStep(model, opt, batch, batch_ul, alpha=1.0, VAT=True, clip=3.0, graph=False, dual_stream=False,
+                                  bf16_backward=args.bf16_backward)
             eager1()
             situ, situ_flops, floor_us = measure_in_situ(eager1, device)
             conv_situ_ms, conv_situ_n = situ.get('convolutions', (0.0, 0))
@@ -768,7 +769,7 @@ def main():
                 # (algorithmic bytes: input + output + weights once); `bf16_launches`: the opt-in bf16-operand launches alone
                 'frac_of_min_mfma_ai_hbm': {k: {'frac': round(v[1] / v[0], 4), 'measured_ms': round(v[0], 3), 'ms_at_bound': round(v[1], 3),
                                                 'achieved_tflops': round(v[2] / v[0] / 1e9, 1),
-                                                'mfma_peak_tflops': MFMA_BF16_PEAK_TFLOPS if k == 'bf16' else MFMA_F32_PEAK_TFLOPS,
+                                                'mfma_peak_tflops': MFMA_BF16_PEAK_TFLOPS if k == 'bf16_launches' else 'per launch: 157.3 (f32) / 2500 (bf16)',
                                                 'hbm_tb_s': HBM_PEAK_TBS}
                                             for k, v in (('all_conv_launches', bound['all']), ('bf16_launches', bound['bf16'])) if v[0] > 0},
                 'top': [{'ms_per_step': round(t, 3), 'count': c, 'ms': round(m, 4), 'tflops': round(tf, 1), 'sig': list(map(str, s))}
