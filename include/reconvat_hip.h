@@ -73,8 +73,10 @@ int rv_conv_fwd(int mode, const float* in, int in_ld, int B, int H, int W, int C
                 const float* bn_z, int bn_z_ld, const float* bn_coef, float bn_slope, void* stream);
 long rv_conv_wgrad_workspace_bytes(int taps, int B, int Hv, int Ca, int Cb);
 /* Host autotuner hook (reconvat_amd/ops.py conv_wgrad): the launch partition of the MFMA weight-gradient kernel for this shape
- * from now on -- nw = waves per workgroup (4 / 8, 0 = default), wgs = workgroups on the chip (0 = default 256).  Changes the
- * result of rv_conv_wgrad_workspace_bytes for the shape; not thread-safe against concurrent weight-gradient calls. */
+ * from now on -- nw = waves per workgroup (4 / 8, 0 = default; 24 = eight waves, Winograd F(3x3, 2x2) form of the 3x3 kernel,
+ * wgrad_wino_k: even Hv, falls back to the direct form where its six-row ring does not fit LDS), wgs = workgroups on the chip
+ * (0 = default 256).  Changes the result of rv_conv_wgrad_workspace_bytes for the shape; not thread-safe against concurrent
+ * weight-gradient calls. */
 int rv_conv_wgrad_set_plan(int taps, int B, int Hv, int Ca, int Cb, int nw, int wgs);
 int rv_conv_wgrad(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, const float* V, int v_ld, int Hv, int Wv,
                   int Cb, int B, float* dw, long s_a, long s_b, int flip, float* dbias, int accumulate, void* workspace,
