@@ -48,6 +48,11 @@ struct AttnArgs {
 // dst[r][f] (r < ntotal, f < dhp) = src[(row0 + r) * ld + col0 + f] for r < nvalid, 0 <= row0 + r < L, f < dh; else 0.
 // Rows travel by LDS-DMA (16 bytes per lane when `v4`: rows 16-byte aligned, else 4): all of a wave's rows are in
 // flight at once and nothing passes through VGPRs; the caller waits (stage_wait) before the barrier.
+// Rows outside [0, L) (the zero padding of the key / value windows) and the tail rows r >= nvalid are fetched from a buffer of zeros in
+// global memory instead of being zero-filled by stores: per row the code is one scalar range test, one select of the source pointer and the
+// DMA instructions -- no exec-mask branch around a store loop (the same scheme as the conv kernels' rv_zero_piece, round 4).
+__device__ __attribute__((aligned(16))) const float rv_attn_zero[256] = {0.f};
+
 __device__ __forceinline__ int stage_rows(float* dst, int ldk, const float* src, long ld, int col0, int dh, int dhp,
                                           int row0, int nvalid, int ntotal, int L, bool v4) {
     int issued = 0;                                                  // DMA instructions of this wave (wave-uniform)
@@ -58,25 +63,23 @@ __device__ __forceinline__ int stage_rows(float* dst, int ldk, const float* src,
     const int ninst = (dh + per - 1) / per;
     const int lf = v4 ? lane * 4 : lane;                             // this lane's first float inside an instruction
     const float* s = src + ((long)(row0 + wave) * ld + col0) + lf;   // only dereferenced for rows inside [0, L)
+    const float* z = rv_attn_zero + lf;                              // (one instruction's worth of zeros: every k reads the same piece)
     float* drow = dst + wave * ldk;
     const long sstep = (long)AT_NW * ld;
     const int dstep = AT_NW * ldk;
     const int npad = dhp - dh;
     for (int r = wave; r < ntotal; r += AT_NW, s += sstep, drow += dstep) {
         const int t = row0 + r;
-        if (r < nvalid && t >= 0 && t < L) {
-            if (v4) {
-                for (int k = 0; k < ninst; ++k)
-                    if (k * 256 + lf < dh) glds16(s + k * 256, drow + k * 256);
-            } else {
-                for (int k = 0; k < ninst; ++k)
-                    if (k * 64 + lf < dh) glds4(s + k * 64, drow + k * 64);
-            }
-            issued += ninst;
-            if (lane < npad) drow[dh + lane] = 0.f;                  // npad < 16
+        const bool real = r < nvalid && t >= 0 && t < L;
+        if (v4) {
+            for (int k = 0; k < ninst; ++k)
+                if (k * 256 + lf < dh) glds16(real ? s + k * 256 : z, drow + k * 256);
         } else {
-            for (int f = lane; f < dhp; f += 64) drow[f] = 0.f;
+            for (int k = 0; k < ninst; ++k)
+                if (k * 64 + lf < dh) glds4(real ? s + k * 64 : z, drow + k * 64);
         }
+        issued += ninst;
+        if (lane < npad) drow[dh + lane] = 0.f;                      // npad < 16
     }
     return issued;
 }
