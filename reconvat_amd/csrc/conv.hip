@@ -829,6 +829,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
     constexpr int KC = 16;                       // channels per chunk
     constexpr int WFLOATS = 16 * NT * 256;       // 16 xi x NT fragments x 64 lanes x 4 floats
     const ConvArgs& a = aa.c;
+    if (ABL(aa) & 64) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -906,15 +907,15 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
             ++issued;
         }
         if (wres) {
-            if (sg_u == 0) {
-                for (int c = 0; c < nchunk; ++c) {
-                    const char* wsrc = reinterpret_cast<const char*>(wino + (long)c * a.ntile_n * 256);
+            // resident weights: chunk c arrives with unit c of the first band (not all of them ahead of unit 0: the first wait of
+            // the kernel is then for one chunk's weights, not for nchunk)
+            if (sg_u < nchunk) {
+                const char* wsrc = reinterpret_cast<const char*>(wino + (long)sg_u * a.ntile_n * 256);
 #pragma unroll
-                    for (int t = 0; t < TW; ++t) {
-                        if (wave + NW * t >= NWF) break;
-                        glds16(reinterpret_cast<const float*>(wsrc + w_off[t]), ws0 + c * WFLOATS + (wave + NW * t) * 256);
-                        ++issued;
-                    }
+                for (int t = 0; t < TW; ++t) {
+                    if (wave + NW * t >= NWF) break;
+                    glds16(reinterpret_cast<const float*>(wsrc + w_off[t]), ws0 + sg_u * WFLOATS + (wave + NW * t) * 256);
+                    ++issued;
                 }
             }
         } else if (nchunk > 1 || sg_u == 0) {
@@ -953,7 +954,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
     f32x4 st1[NT], st2[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) st1[n] = st2[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (ABL(aa) & 128) return;
     stage();
+    if (ABL(aa) & 1024) { wait_vmcnt_le(0); return; }
     int ahead = 0;
     int cu_buf = 0, cu_b = b_first, cu_y0 = y_first, cu_c = 0;
     for (int u = 0; u < nunits; ++u) {
@@ -1139,7 +1142,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
             }
         }
     }
-    if (a.bn_sums) {
+    if (a.bn_sums && !(ABL(aa) & 4096)) {
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
