@@ -2571,10 +2571,63 @@ __device__ __forceinline__ void wgrad_reduce_body(const WreduceArgs& a, long blo
     }
 }
 
-template <int EL>
+// The same with 16-byte loads: a thread owns FOUR consecutive elements (EL / 4 threads cover the workgroup's elements, 1024 / EL
+// partial lanes), so a partial-sum vector is fetched with a quarter of the load instructions and every thread has all its loads in
+// flight at once.  Needs nel, pstride % 4 == 0 and a 16-byte aligned partial buffer (the host checks: WreduceEntry::vec4).
+template <int EL, bool ATOMIC>
+__device__ __forceinline__ void wgrad_reduce_body_v4(const WreduceArgs& a, long block, float* sh) {
+    constexpr int VL = EL / 4, PL = 256 / VL;
+    const long nel = (long)a.taps * a.Ca * a.Cb + (a.dbias ? a.Cb : 0);
+    const int vl = threadIdx.x % VL, pl = threadIdx.x / VL;
+    const long e = block * EL + vl * 4;
+    f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (e < nel) {
+        const float* p = a.part + e;
+        int k = pl;
+#pragma unroll 2
+        for (; k + 3 * PL < a.nparts; k += 4 * PL) {
+            s0 += *reinterpret_cast<const f32x4*>(p + (long)k * a.pstride);
+            s1 += *reinterpret_cast<const f32x4*>(p + (long)(k + PL) * a.pstride);
+            s2 += *reinterpret_cast<const f32x4*>(p + (long)(k + 2 * PL) * a.pstride);
+            s3 += *reinterpret_cast<const f32x4*>(p + (long)(k + 3 * PL) * a.pstride);
+        }
+        for (; k < a.nparts; k += PL) s0 += *reinterpret_cast<const f32x4*>(p + (long)k * a.pstride);
+    }
+    f32x4* shv = reinterpret_cast<f32x4*>(sh);
+    shv[pl * VL + vl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+#pragma unroll
+    for (int h = PL / 2; h >= 1; h >>= 1) {               // fixed tree: deterministic
+        if (pl < h) shv[pl * VL + vl] += shv[(pl + h) * VL + vl];
+        __syncthreads();
+    }
+    if (pl != 0 || e >= nel) return;
+    const f32x4 s = shv[vl];
+    const long nw = (long)a.taps * a.Ca * a.Cb;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long eq = e + q;
+        float* d;
+        if (eq < nw) {
+            const int bb = (int)(eq % a.Cb);
+            const long t = eq / a.Cb;
+            const int aa = (int)(t % a.Ca);
+            const int tap = (int)(t / a.Ca);
+            const int tt = a.flip ? (a.taps - 1 - tap) : tap;
+            d = a.dw + (long)aa * a.s_a + (long)bb * a.s_b + tt;
+        } else {
+            d = a.dbias + (eq - nw);
+        }
+        if (ATOMIC) atomicAdd(d, s[q]);
+        else *d = a.accumulate ? *d + s[q] : s[q];
+    }
+}
+
+template <int EL, bool V4 = false>
 __global__ __launch_bounds__(256) void wgrad_reduce_k(WreduceArgs a) {
-    __shared__ float sh[256];
-    wgrad_reduce_body<EL, false>(a, blockIdx.x, sh);
+    __shared__ __attribute__((aligned(16))) float sh[V4 ? 1024 : 256];
+    if (V4) wgrad_reduce_body_v4<EL, false>(a, blockIdx.x, sh);
+    else wgrad_reduce_body<EL, false>(a, blockIdx.x, sh);
 }
 
 // All deferred reductions of a backward pass in ONE launch (rv_wgrad_reduce_table): a workgroup finds its entry by
@@ -2584,11 +2637,11 @@ struct WreduceEntry {
     WreduceArgs a;
     long block0;      // nblocks until rv_wgrad_table_finalize turns it into the exclusive prefix
     int el;           // elements per workgroup: 4, 16 or 64
-    int pad;
+    int vec4;         // el >= 16: 16-byte loads (wgrad_reduce_body_v4)
 };
-__global__ __launch_bounds__(256) void wgrad_reduce_table_k(const WreduceEntry* tab, int count) {
+__global__ __launch_bounds__(256) void wgrad_reduce_table_k(const WreduceEntry* tab, int count, int plain) {
     __shared__ WreduceEntry ent;
-    __shared__ float sh[256];
+    __shared__ __attribute__((aligned(16))) float sh[1024];
     if (threadIdx.x == 0) {
         int lo = 0, hi = count - 1;
         while (lo < hi) {
@@ -2599,7 +2652,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_table_k(const WreduceEntry* 
     }
     __syncthreads();
     const long block = (long)blockIdx.x - ent.block0;
-    if (ent.el == 64) wgrad_reduce_body<64, true>(ent.a, block, sh);
+#ifdef RV_ABLATION
+    if (plain) {                                  // (timing ablation, wrong results: the final add as a plain store)
+        ent.a.accumulate = 0;
+        if (ent.vec4 && ent.el == 64) wgrad_reduce_body_v4<64, false>(ent.a, block, sh);
+        else if (ent.vec4 && ent.el == 16) wgrad_reduce_body_v4<16, false>(ent.a, block, sh);
+        else if (ent.el == 64) wgrad_reduce_body<64, false>(ent.a, block, sh);
+        else if (ent.el == 16) wgrad_reduce_body<16, false>(ent.a, block, sh);
+        else wgrad_reduce_body<4, false>(ent.a, block, sh);
+        return;
+    }
+#endif
+    if (ent.vec4 && ent.el == 1024) wgrad_reduce_body_v4<1024, true>(ent.a, block, sh);
+    else if (ent.vec4 && ent.el == 64) wgrad_reduce_body_v4<64, true>(ent.a, block, sh);
+    else if (ent.vec4 && ent.el == 16) wgrad_reduce_body_v4<16, true>(ent.a, block, sh);
+    else if (ent.el == 64) wgrad_reduce_body<64, true>(ent.a, block, sh);
     else if (ent.el == 16) wgrad_reduce_body<16, true>(ent.a, block, sh);
     else wgrad_reduce_body<4, true>(ent.a, block, sh);
 }
@@ -3256,8 +3323,9 @@ long rv_wgrad_table_finalize(void* table_host, int count) {
 int rv_wgrad_reduce_table(const void* table_dev, int count, long total_blocks, void* stream) {
     if (count <= 0 || total_blocks <= 0) return RV_OK;
     RV_CHECK_ARG(table_dev, "rv_wgrad_reduce_table: null table");
+    static const int plain = getenv("RV_ABL_WREDUCE_PLAIN") ? atoi(getenv("RV_ABL_WREDUCE_PLAIN")) : 0;      // (ablation build only)
     hipLaunchKernelGGL(wgrad_reduce_table_k, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const WreduceEntry*)table_dev, count);
+                       (const WreduceEntry*)table_dev, count, plain);
     RV_LAUNCH_CHECK("rv_wgrad_reduce_table");
     return RV_OK;
 }
@@ -3444,11 +3512,22 @@ reduce:
         r.dw = dw; r.s_a = s_a; r.s_b = s_b; r.flip = flip; r.dbias = dbias; r.accumulate = accumulate;
         long nel = (long)taps * Ca * Cb + (dbias ? Cb : 0);
         const int el = (cdiv(nel, 64) >= 256 || a.nparts <= 8) ? 64 : ((cdiv(nel, 16) >= 256 || a.nparts <= 32) ? 16 : 4);
-        if (defer) {
-            defer->a = r; defer->block0 = cdiv(nel, el); defer->el = el; defer->pad = 0;
+        static const int v4_env = getenv("RV_WREDUCE_V4") ? atoi(getenv("RV_WREDUCE_V4")) : 1;
+        const int vec4 = v4_env && el >= 16 && (nel & 3) == 0 && (a.pstride & 3) == 0 && (((uintptr_t)a.part) & 15) == 0;
+        // deferred (table) form of a large gradient: 1024 elements per workgroup, every thread walks ALL partials of its four elements
+        // -- 4 KiB contiguous per partial and workgroup instead of 256-byte pieces at partial stride; the table's other entries fill the chip
+        static const int wide_env = getenv("RV_WREDUCE_WIDE") ? atoi(getenv("RV_WREDUCE_WIDE")) : 1;
+        if (defer && vec4 && wide_env && nel >= 8192) {
+            defer->a = r; defer->block0 = cdiv(nel, 1024); defer->el = 1024; defer->vec4 = 1;
             return RV_OK;
         }
-        if (el == 64) hipLaunchKernelGGL(wgrad_reduce_k<64>, dim3(cdiv(nel, 64)), dim3(256), 0, st, r);
+        if (defer) {
+            defer->a = r; defer->block0 = cdiv(nel, el); defer->el = el; defer->vec4 = vec4;
+            return RV_OK;
+        }
+        if (vec4 && el == 64) hipLaunchKernelGGL((wgrad_reduce_k<64, true>), dim3(cdiv(nel, 64)), dim3(256), 0, st, r);
+        else if (vec4 && el == 16) hipLaunchKernelGGL((wgrad_reduce_k<16, true>), dim3(cdiv(nel, 16)), dim3(256), 0, st, r);
+        else if (el == 64) hipLaunchKernelGGL(wgrad_reduce_k<64>, dim3(cdiv(nel, 64)), dim3(256), 0, st, r);
         else if (el == 16) hipLaunchKernelGGL(wgrad_reduce_k<16>, dim3(cdiv(nel, 16)), dim3(256), 0, st, r);
         else hipLaunchKernelGGL(wgrad_reduce_k<4>, dim3(cdiv(nel, 4)), dim3(256), 0, st, r);
         RV_LAUNCH_CHECK("rv_conv_wgrad(reduce)");
