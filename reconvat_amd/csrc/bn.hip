@@ -286,9 +286,14 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
     }
 }
 
+// Grid of an apply launch: at most ~4 workgroups per CU, each walking many pixels.  One workgroup per 256 quads (capped at 3072 = 1.5
+// resident rounds of 8 per CU) paid the per-workgroup prologue (replica fold, fp64 coefficient math) twelve times per CU and left the
+// second round half empty: 3072 -> 1023 is -0.2 ms per step in situ (2046 / 1536 / 1023 / 768 within noise of each other, 510 and
+// 255 slower again: too few loads in flight).  RV_BN_MAXBLK overrides (tuning only).
 static int bn_apply_blocks(long total) {
     long b = (total + 255) / 256;
-    if (b > 3072) b = 3072;
+    static const long cap = getenv("RV_BN_MAXBLK") ? atol(getenv("RV_BN_MAXBLK")) : 1023;
+    if (b > cap) b = cap;
     b = ((b + 2) / 3) * 3;          // multiple of 3: see bn_apply_k
     return (int)b;
 }
