@@ -190,13 +190,14 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
     if (fixed) {
         // the thread keeps its channel quad: pixels p0, p0 + pstep, ... ; four pixels per trip, every load of the trip
         // issued before the first use, no division in the loop
+        constexpr int UNR = BWD ? 4 : 8;          // pixels in flight per thread
         const long pstep = stride / C4;
         long p = idx / C4;
-        for (; p < a.P; p += 4 * pstep) {
-            f32x4 zv[4], dv[4], rv[4];
-            bool ok[4];
+        for (; p < a.P; p += UNR * pstep) {
+            f32x4 zv[UNR], dv[UNR], rv[UNR];
+            bool ok[UNR];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UNR; ++u) {
                 const long pu = p + u * pstep;
                 ok[u] = pu < a.P;
                 const long pp = ok[u] ? pu : 0;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
                 if (!BWD && a.res) rv[u] = *reinterpret_cast<const f32x4*>(a.res + pp * a.res_ld + c);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UNR; ++u) {
                 if (!ok[u]) continue;
                 f32x4 o = one(zv[u], dv[u], rv[u]);
                 float* dst = a.out + (p + u * pstep) * a.out_ld + c;
