@@ -43,6 +43,8 @@ struct AttnArgs {
     int B, L, G, dh, dhp;
     int v4, dv4;                     // 16-byte DMA legal for q/k/v rows / for dout and rel^T rows (stride F)
     int seq_kv;                      // attn_bwd_kv_k: one window buffer used twice (see the kernel)
+    int rel_regs;                    // attn_fwd_k / attn_bwd_q_k (wide heads): rel^T fragments straight from global memory into registers
+                                     // instead of a 32-row LDS block, so that two workgroups fit a CU
 };
 
 // dst[r][f] (r < ntotal, f < dhp) = src[(row0 + r) * ld + col0 + f] for r < nvalid, 0 <= row0 + r < L, f < dh; else 0.
@@ -99,16 +101,64 @@ __device__ __forceinline__ f32x4 score_tile(const float* X, const float* Y, int 
     return acc;
 }
 
+// the same with the Y operand in registers: yb[c] = Y[i][16 c + 4 g4 .. + 3]
+__device__ __forceinline__ f32x4 score_tile_regs(const float* X, const f32x4 (&yb)[16], int ldk, int nchunk, int i, int g4) {
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* xp = X + i * ldk + 4 * g4;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        if (c < nchunk) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(xp + 16 * c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[r], yb[c][r], acc, 0, 0, 0);
+        }
+    }
+    return acc;
+}
+
 // O[t][f] = sum_k A[t][k] * Y[k][f] over NCH chunks of 16 k; wave `wave` owns the output tiles wave, wave+5, ...
 // Rows t0 + t of dst (row stride dld, first column col0) receive the result for f < dh.
+// rel^T rows as the B operand of apply_tiles, from global memory: yk[q][c][r] = relT[16 c + 4 g4 + r][col0 + 16 nt + i] (0 past row 30 / column dh)
+struct RelFrag { f32x4 y[AT_MAXT][2]; };
+__device__ __forceinline__ void rel_frag_load(RelFrag& rf, const float* relT, int F, int col0, int dh, int ntiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, g4 = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < AT_MAXT; ++q) {
+        const int f = 16 * (wave + AT_NW * q) + i;
+        const bool fok = wave + AT_NW * q < ntiles && f < dh;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int w = 16 * c + 4 * g4 + r;
+                rf.y[q][c][r] = (fok && w < AT_W) ? relT[(long)w * F + col0 + f] : 0.f;
+            }
+    }
+}
+
+// NCH chunks of 16 k from LDS; with `rf` two more chunks (k = 16 NCH .. 16 NCH + 31 of A) whose Y rows are rel^T fragments in registers
 template <int NCH>
 __device__ __forceinline__ void apply_tiles(const float* A, int lda, const float* Y, int ldk, int ntiles, float* dst,
-                                            long dld, int col0, int dh, int nrows_valid) {
+                                            long dld, int col0, int dh, int nrows_valid, const RelFrag* rf = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, g4 = lane >> 4;
     f32x4 acc[AT_MAXT];
 #pragma unroll
     for (int q = 0; q < AT_MAXT; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (rf) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(A + i * lda + 16 * (NCH + c) + 4 * g4);
+#pragma unroll
+            for (int q = 0; q < AT_MAXT; ++q) {
+                if (wave + AT_NW * q < ntiles) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[r], rf->y[q][c][r], acc[q], 0, 0, 0);
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const f32x4 a4 = *reinterpret_cast<const f32x4*>(A + i * lda + 16 * c + 4 * g4);
@@ -151,8 +201,8 @@ __global__ __launch_bounds__(AT_NTHR) void attn_fwd_k(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int dh = a.dh, dhp = a.dhp, ldk = dhp + 4, nchunk = dhp >> 4, F = a.G * dh;
     float* Qs = smem;                           // [16][ldk]
-    float* Kx = Qs + AT_TT * ldk;               // [80][ldk]  key window | rel^T ; value window over rows 0..47 later
-    float* Sr = Kx + 80 * ldk;                  // [16][80]
+    float* Kx = Qs + AT_TT * ldk;               // [80][ldk]  key window | rel^T ; value window over rows 0..47 later  ([48][ldk] with rel_regs)
+    float* Sr = Kx + (a.rel_regs ? AT_WINP : 80) * ldk;   // [16][80]
     float* A2 = Sr + AT_TT * AT_SLD;            // [16][52]
     const int ntile = (a.L + AT_TT - 1) / AT_TT;
     const int bx = xcd_remap(blockIdx.x, gridDim.x);     // an XCD (one L2) owns a run of neighbouring tiles: window overlap hits
@@ -163,12 +213,25 @@ __global__ __launch_bounds__(AT_NTHR) void attn_fwd_k(AttnArgs a) {
     const long boff = (long)b * a.L * a.ld;
     stage_rows(Qs, ldk, a.q + boff, a.ld, g * dh, dh, dhp, t0, AT_TT, AT_TT, a.L, a.v4);
     stage_rows(Kx, ldk, a.k + boff, a.ld, g * dh, dh, dhp, t0 - AT_P, AT_WIN, AT_WINP, a.L, a.v4);
-    stage_rows(Kx + AT_WINP * ldk, ldk, a.rel, F, g * dh, dh, dhp, 0, AT_W, 32, AT_W, a.dv4);
+    f32x4 yb[16];                               // rel_regs: waves 3, 4 hold their rel^T score operand (row 16 (wave - 3) + i) in registers
+    if (a.rel_regs) {
+        if (wave >= 3) {
+            const int w = 16 * (wave - 3) + i;
+            const float* rp = a.rel + (long)min(w, AT_W - 1) * F + g * dh + 4 * g4;
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yb[c][r] = (c < nchunk && w < AT_W && 16 * c + 4 * g4 + r < dh) ? rp[16 * c + r] : 0.f;
+        }
+    } else {
+        stage_rows(Kx + AT_WINP * ldk, ldk, a.rel, F, g * dh, dh, dhp, 0, AT_W, 32, AT_W, a.dv4);
+    }
     for (int idx = tid; idx < AT_TT * AT_A2LD; idx += AT_NTHR) A2[idx] = 0.f;
     stage_wait();
     __syncthreads();
     {
-        const f32x4 s = score_tile(Qs, Kx + 16 * wave * ldk, ldk, nchunk, i, g4);
+        const f32x4 s = (a.rel_regs && wave >= 3) ? score_tile_regs(Qs, yb, ldk, nchunk, i, g4)
+                                                  : score_tile(Qs, Kx + 16 * wave * ldk, ldk, nchunk, i, g4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) Sr[(4 * g4 + r) * AT_SLD + 16 * wave + i] = s[r];
     }
@@ -201,8 +264,8 @@ __global__ __launch_bounds__(AT_NTHR) void attn_bwd_q_k(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int dh = a.dh, dhp = a.dhp, ldk = dhp + 4, nchunk = dhp >> 4, F = a.G * dh;
     float* Ds = smem;                           // [16][ldk]  dout tile
-    float* Kx = Ds + AT_TT * ldk;               // [80][ldk]  value window, then key window | rel^T
-    float* Sr = Kx + 80 * ldk;                  // [16][80]   dout . v^T (48 columns used)
+    float* Kx = Ds + AT_TT * ldk;               // [80][ldk]  value window, then key window | rel^T   ([48][ldk] with rel_regs)
+    float* Sr = Kx + (a.rel_regs ? AT_WINP : 80) * ldk;   // [16][80]   dout . v^T (48 columns used)
     float* A3 = Sr + AT_TT * AT_SLD;            // [16][84]   [ band(de) | de ]
     const int ntile = (a.L + AT_TT - 1) / AT_TT;
     const int bx = xcd_remap(blockIdx.x, gridDim.x);     // an XCD (one L2) owns a run of neighbouring tiles: window overlap hits
@@ -213,7 +276,9 @@ __global__ __launch_bounds__(AT_NTHR) void attn_bwd_q_k(AttnArgs a) {
     const long boff = (long)b * a.L * a.ld;
     stage_rows(Ds, ldk, a.dout + (long)b * a.L * F, F, g * dh, dh, dhp, t0, AT_TT, AT_TT, a.L, a.dv4);
     stage_rows(Kx, ldk, a.v + boff, a.ld, g * dh, dh, dhp, t0 - AT_P, AT_WIN, AT_WINP, a.L, a.v4);
-    stage_rows(Kx + AT_WINP * ldk, ldk, a.rel, F, g * dh, dh, dhp, 0, AT_W, 32, AT_W, a.dv4);
+    RelFrag rf;
+    if (a.rel_regs) rel_frag_load(rf, a.rel, F, g * dh, dh, nchunk);      // (consumed by the last phase: the loads fly under everything else)
+    else stage_rows(Kx + AT_WINP * ldk, ldk, a.rel, F, g * dh, dh, dhp, 0, AT_W, 32, AT_W, a.dv4);
     for (int idx = tid; idx < AT_TT * AT_A3LD; idx += AT_NTHR) A3[idx] = 0.f;
     stage_wait();
     __syncthreads();
@@ -245,7 +310,8 @@ __global__ __launch_bounds__(AT_NTHR) void attn_bwd_q_k(AttnArgs a) {
     }
     stage_wait();
     __syncthreads();
-    apply_tiles<5>(A3, AT_A3LD, Kx, ldk, nchunk, a.dq + ((long)b * a.L + t0) * a.dld, a.dld, g * dh, dh, a.L - t0);
+    if (a.rel_regs) apply_tiles<3>(A3, AT_A3LD, Kx, ldk, nchunk, a.dq + ((long)b * a.L + t0) * a.dld, a.dld, g * dh, dh, a.L - t0, &rf);
+    else apply_tiles<5>(A3, AT_A3LD, Kx, ldk, nchunk, a.dq + ((long)b * a.L + t0) * a.dld, a.dld, g * dh, dh, a.L - t0);
 }
 
 // backward, key/value side for a 16-frame tile of window rows s:
@@ -325,7 +391,10 @@ int rv_local_attn_fwd(const float* q, const float* k, const float* v, long ld, c
     a.v4 = attn_v4(dh, ld, q) && attn_v4(dh, ld, k) && attn_v4(dh, ld, v);
     a.dv4 = attn_v4(dh, (long)G * dh, relT);
     const int ntile = (L + AT_TT - 1) / AT_TT, ldk = a.dhp + 4;
-    const size_t lds = ((size_t)(AT_TT + 80) * ldk + AT_TT * AT_SLD + AT_TT * AT_A2LD) * sizeof(float);
+    size_t lds = ((size_t)(AT_TT + 80) * ldk + AT_TT * AT_SLD + AT_TT * AT_A2LD) * sizeof(float);
+    static const int relregs_env = getenv("RV_ATTN_REL_REGS") ? atoi(getenv("RV_ATTN_REL_REGS")) : 1;
+    a.rel_regs = relregs_env && lds > 78 * 1024;       // the rel^T block would leave room for only one workgroup per CU
+    if (a.rel_regs) lds -= (size_t)32 * ldk * sizeof(float);
     hipLaunchKernelGGL(attn_fwd_k, dim3(B * ntile, G), dim3(AT_NTHR), lds, (hipStream_t)stream, a);
     RV_LAUNCH_CHECK("rv_local_attn_fwd");
     return RV_OK;
@@ -346,7 +415,10 @@ int rv_local_attn_bwd(const float* dout, const float* q, const float* k, const f
     a.v4 = attn_v4(dh, ld, q) && attn_v4(dh, ld, k) && attn_v4(dh, ld, v);
     a.dv4 = attn_v4(dh, (long)G * dh, relT) && attn_v4(dh, (long)G * dh, dout);
     const int ntile = (L + AT_TT - 1) / AT_TT, ldk = a.dhp + 4;
-    const size_t lds1 = ((size_t)(AT_TT + 80) * ldk + AT_TT * AT_SLD + AT_TT * AT_A3LD) * sizeof(float);
+    size_t lds1 = ((size_t)(AT_TT + 80) * ldk + AT_TT * AT_SLD + AT_TT * AT_A3LD) * sizeof(float);
+    static const int relregs_env = getenv("RV_ATTN_REL_REGS") ? atoi(getenv("RV_ATTN_REL_REGS")) : 1;
+    a.rel_regs = relregs_env && lds1 > 78 * 1024;
+    if (a.rel_regs) lds1 -= (size_t)32 * ldk * sizeof(float);
     hipLaunchKernelGGL(attn_bwd_q_k, dim3(B * ntile, G), dim3(AT_NTHR), lds1, st, a);
     RV_LAUNCH_CHECK("rv_local_attn_bwd(q)");
     const size_t lds_two = ((size_t)2 * AT_WINP * ldk + 2 * AT_WINP * 32 + 2 * AT_TT * AT_A2LD) * sizeof(float);
