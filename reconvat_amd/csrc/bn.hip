@@ -287,13 +287,16 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
     }
 }
 
-// Grid of an apply launch: at most ~4 workgroups per CU, each walking many pixels.  One workgroup per 256 quads (capped at 3072 = 1.5
+// Grid of an apply launch: at most 3-4 workgroups per CU, each walking many pixels.  One workgroup per 256 quads (capped at 3072 = 1.5
 // resident rounds of 8 per CU) paid the per-workgroup prologue (replica fold, fp64 coefficient math) twelve times per CU and left the
 // second round half empty: 3072 -> 1023 is -0.2 ms per step in situ (2046 / 1536 / 1023 / 768 within noise of each other, 510 and
-// 255 slower again: too few loads in flight).  RV_BN_MAXBLK overrides (tuning only).
-static int bn_apply_blocks(long total) {
+// 255 slower again: too few loads in flight).  The backward form (two input streams) likes 768 best: 1023 / 768 / 639 / 510 =
+// 22.29 / 22.19 / 22.24 / 22.30 ms per step.  RV_BN_MAXBLK / RV_BN_MAXBLK_BWD override (tuning only).
+static int bn_apply_blocks(long total, bool bwd = false) {
     long b = (total + 255) / 256;
-    static const long cap = getenv("RV_BN_MAXBLK") ? atol(getenv("RV_BN_MAXBLK")) : 1023;
+    static const long capf = getenv("RV_BN_MAXBLK") ? atol(getenv("RV_BN_MAXBLK")) : 1023;
+    static const long capb = getenv("RV_BN_MAXBLK_BWD") ? atol(getenv("RV_BN_MAXBLK_BWD")) : 768;
+    const long cap = bwd ? capb : capf;
     if (b > cap) b = cap;
     b = ((b + 2) / 3) * 3;          // multiple of 3: see bn_apply_k
     return (int)b;
@@ -382,7 +385,7 @@ int rv_bn_lrelu_bwd(const float* dy, int dy_ld, const float* z, int z_ld, long P
         const int rc = rv_internal_bn_bwd_stats(dy, dy_ld, z, z_ld, P, C, coef, slope, a.sums, st);
         if (rc != RV_OK) return rc;
     }
-    hipLaunchKernelGGL(bn_apply_k<true>, dim3(bn_apply_blocks(P * (C / 4))), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bn_apply_k<true>, dim3(bn_apply_blocks(P * (C / 4), true)), dim3(256), 0, st, a);
     RV_LAUNCH_CHECK("rv_bn_lrelu_bwd(apply)");
     return RV_OK;
 }
