@@ -1993,7 +1993,7 @@ template <int TA, int TB, int NW>
 __global__ __launch_bounds__(NW * 64) void wgrad_wino_k(WgradArgs a) {
     constexpr int CA = TA * 16, CB = TB * 16;
     constexpr int NH = (NW == 8 && TA == 2 && TB == 2) ? 2 : 1;
-    constexpr int TAW = TA / NH, NXG = NW / NH, NTHR = NW * 64;
+    constexpr int TAW = TA / NH, NXG = NW / NH;
     constexpr int C4A = CA / 4, C4B = CB / 4;
     constexpr int PPA = 64 / C4A, PPB = 64 / C4B;            // pixels per DMA piece
     constexpr int NSLOT = 6;
