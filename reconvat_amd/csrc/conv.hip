@@ -500,7 +500,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
             const int gy = sg_y0 - 1 + xs_row[t];
             float* ldst = xb + xs_ldst[t];                               // wave-uniform
             // rows above / below the image fetch zeros (rv_zero_piece) instead of branching into a store: one select, one DMA
-            const bool rowok = gy >= 0 && gy < H;
+            const bool rowok = (unsigned)gy < (unsigned)H;
             if (xs_lane[t]) glds16(reinterpret_cast<const float*>(rowok ? src + xs_goff[t] : zsrc), ldst);
             ++issued;
         }
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
             const int gy = sg_y0 - 1 + row;
             const int px = k * PPI + lane / Q, q = lane - (lane / Q) * Q;
             float* ldst = xb + (row * W2 + 1 + k * PPI) * KC;
-            const bool rowok = gy >= 0 && gy < H;
+            const bool rowok = (unsigned)gy < (unsigned)H;
             if (px < W)
                 glds16(rowok ? reinterpret_cast<const float*>(src) + ((long)row * W + px) * a.in_ld + q * 4 : reinterpret_cast<const float*>(zsrc), ldst);
             ++issued;
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
                 for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        wait_vmcnt_le(ahead);                               // this wave's share of unit u has landed
+        if (nbuf == 3) wait_vmcnt_le(ahead);                // this wave's share of unit u has landed (two buffers: the barrier's vmcnt(0) below)
         if (!(ABL(aa) & 1)) __syncthreads();              // ... and everyone's; unit u-1's buffer is free
         // The waves that share a SIMD stage at opposite ends of the unit (prefetch distance 2 only), so one wave's
         // address arithmetic / DMA issue overlaps the other's MFMAs instead of both idling the matrix pipe together.
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
         for (int t = 0; t < TXF; ++t) {
             if (wave + NW * t >= nx) break;
             const int gy = sg_y0 - 1 + xs_row[t];
-            const bool rowok = gy >= 0 && gy < H;
+            const bool rowok = (unsigned)gy < (unsigned)H;
             glds16(reinterpret_cast<const float*>((rowok && xs_real[t]) ? src + xs_goff[t] : zsrc), xb + xs_ldst[t]);
             ++issued;
         }
@@ -901,7 +901,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
             const int row = i / NP, k = i - row * NP;
             const int gy = sg_y0 - 1 + row;
             const int px = k * 16 + lp - 1;
-            const bool real = gy >= 0 && gy < H && px >= 0 && px < W;
+            const bool real = (unsigned)gy < (unsigned)H && (unsigned)px < (unsigned)W;
             const char* s = real ? src + ((long)(row * W + px) * a.in_ld + lq * 4) * 4 : zsrc;
             glds16(reinterpret_cast<const float*>(s), xb + row * RP + k * 256);
             ++issued;
@@ -957,7 +957,6 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
     if (ABL(aa) & 128) return;
     stage();
     if (ABL(aa) & 1024) { wait_vmcnt_le(0); return; }
-    int ahead = 0;
     int cu_buf = 0, cu_b = b_first, cu_y0 = y_first, cu_c = 0;
     for (int u = 0; u < nunits; ++u) {
         const int b = cu_b, y0 = cu_y0, c = cu_c, buf = cu_buf;
@@ -985,9 +984,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
                     for (int xi = 0; xi < 16; ++xi) acc[m][n][xi] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        wait_vmcnt_le(ahead);
+        // (the barrier's own vmcnt(0) is the wait for unit u's DMA: with two buffers nothing else is in flight)
         if (!(ABL(aa) & 1)) __syncthreads();
-        if (!(ABL(aa) & 2)) ahead = (sg_u < nunits) ? stage() : 0;
+        if (!(ABL(aa) & 2) && sg_u < nunits) stage();
         const unsigned xs_a = lds_addr(xs0 + buf * xfloats);
         const unsigned ws_a = lds_addr(ws0 + (wres ? c : ((nchunk > 1) ? buf : 0)) * WFLOATS) + lane * 16;
         const unsigned rp4 = (unsigned)RP * 4u;
