@@ -346,8 +346,26 @@ struct ConvLdsArgs {
     int ablate;        // ABLATION (timing experiments only)
     int nsplit, xcd;   // n-splits per band group; XCD-aware placement on/off
     int wres;          // conv3x3_wino_k: the weights of ALL chunks stay in LDS for the whole kernel (staged once, with unit 0)
+    unsigned in_bytes; // conv3x3_wino_k: bytes of the input view from c.in (buffer-resource range of the staging loads; < 0x3f000000)
 };
 
+
+// Buffer-resource LDS-DMA: 16 bytes per lane from `base + voff` into the wave's LDS slot (lane i -> lds + 16 i); a lane whose offset is
+// outside [0, bytes) gets ZEROS written (tools/probes/buffer_lds_oob.hip).  The builtins exist in the device pass only: the host pass
+// (which instantiates kernel templates to emit their launch stubs) sees placeholders.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t rv_rsrc_t;
+__device__ __forceinline__ rv_rsrc_t rv_make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void rv_buf_lds16(rv_rsrc_t rs, void* lds, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, 0, 0, 0);
+}
+#else
+struct rv_rsrc_t { int unused; };
+__device__ inline rv_rsrc_t rv_make_rsrc(const void*, unsigned) { return rv_rsrc_t{0}; }
+__device__ inline void rv_buf_lds16(rv_rsrc_t, void*, unsigned) {}
+#endif
 
 // wait until at most n of this wave's VMEM operations are outstanding (n wave-uniform; clamping down is safe)
 __device__ __forceinline__ void wait_vmcnt_le(int n) {
@@ -860,19 +878,22 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
     const int nx = nrow * NP;
     int lp, lq;
     wino_lane<LAY>(lane, lp, lq);
-    const char* zsrc = reinterpret_cast<const char*>(rv_zero_piece) + lane * 16;
+    // The input rows are fetched through a BUFFER RESOURCE over the input view: a lane whose byte offset lies outside it gets ZEROS
+    // written to its LDS slot (measured: tools/probes/buffer_lds_oob.hip).  So "this lane is a halo column" and "this row is above /
+    // below the image" are both just an offset bump of OOB = 0x40000000 (the view is < 0x3f000000 bytes: host check) -- no per-lane
+    // mask, no pointer select, no 64-bit address arithmetic; per slot: one scalar row test, one scalar select, one vector add, the DMA.
+    constexpr unsigned OOB = 0x40000000u;
+    const rv_rsrc_t rs_in = rv_make_rsrc(a.in, aa.in_bytes);
     int xs_row[TXF], xs_ldst[TXF];
     unsigned xs_goff[TXF];
-    bool xs_real[TXF];
 #pragma unroll
     for (int t = 0; t < TXF; ++t) {
         const int i = wave + NW * t;
         const int row = i / NP, k = i - row * NP;
         const int px = k * 16 + lp - 1;
         xs_row[t] = row;
-        xs_ldst[t] = row * RP + k * 256;
-        xs_real[t] = px >= 0 && px < W;
-        xs_goff[t] = xs_real[t] ? (unsigned)((row * W + px) * a.in_ld + lq * 4) * 4u : 0u;
+        xs_ldst[t] = (row * RP + k * 256) * 4;               // bytes
+        xs_goff[t] = (unsigned)px < (unsigned)W ? (unsigned)((row * W + px) * a.in_ld + lq * 4) * 4u : OOB;
     }
     unsigned w_off[TW];
 #pragma unroll
@@ -888,22 +909,22 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
     auto stage = [&]() -> int {
         int issued = 0;
         float* xb = xs0 + sg_buf * xfloats;
-        const char* src = reinterpret_cast<const char*>(a.in + ((long)(sg_b * H + sg_y0 - 1) * W) * a.in_ld + sg_c * KC);
+        // byte offset of the unit's first staged row (row y0 - 1: may be "negative" -- all arithmetic is mod 2^32 and the sum with a real
+        // lane's offset is the true offset whenever the row is inside the image)
+        const unsigned ubase = (unsigned)((((sg_b * H + sg_y0 - 1) * W) * a.in_ld + sg_c * KC) * 4);
 #pragma unroll
         for (int t = 0; t < TXF; ++t) {
             if (wave + NW * t >= nx) break;
-            const int gy = sg_y0 - 1 + xs_row[t];
-            const bool rowok = (unsigned)gy < (unsigned)H;
-            glds16(reinterpret_cast<const float*>((rowok && xs_real[t]) ? src + xs_goff[t] : zsrc), xb + xs_ldst[t]);
+            const unsigned add = (unsigned)(sg_y0 - 1 + xs_row[t]) < (unsigned)H ? ubase : ubase + OOB;
+            rv_buf_lds16(rs_in, reinterpret_cast<char*>(xb) + xs_ldst[t], xs_goff[t] + add);
             ++issued;
         }
         for (int i = wave + NW * TXF; i < nx; i += NW) {                    // narrow workgroups on wide rows
             const int row = i / NP, k = i - row * NP;
-            const int gy = sg_y0 - 1 + row;
             const int px = k * 16 + lp - 1;
-            const bool real = (unsigned)gy < (unsigned)H && (unsigned)px < (unsigned)W;
-            const char* s = real ? src + ((long)(row * W + px) * a.in_ld + lq * 4) * 4 : zsrc;
-            glds16(reinterpret_cast<const float*>(s), xb + row * RP + k * 256);
+            const unsigned add = (unsigned)(sg_y0 - 1 + row) < (unsigned)H ? ubase : ubase + OOB;
+            const unsigned goff = (unsigned)px < (unsigned)W ? (unsigned)((row * W + px) * a.in_ld + lq * 4) * 4u : OOB;
+            rv_buf_lds16(rs_in, xb + row * RP + k * 256, goff + add);
             ++issued;
         }
         if (wres) {
@@ -2849,6 +2870,9 @@ static int launch_conv3x3_wino(const ConvArgs& a0, int NT, int MTW, int force_th
     if (NW == 12 && a0.bn_z) return RV_EUNSUPPORTED;      // the fused BatchNorm-backward epilogue does not fit three waves per SIMD without scratch
     ConvLdsArgs aa;
     aa.c = a0;
+    const long in_bytes = (((long)a0.B * a0.H * a0.W - 1) * a0.in_ld + a0.Cin) * 4;
+    if (in_bytes >= 0x3f000000L) return RV_EUNSUPPORTED;      // the staging loads address the input view with 30-bit offsets (see the kernel)
+    aa.in_bytes = (unsigned)in_bytes;
     const int WT = (a0.W + 1) / 2;
     aa.c.fd_pw = fastdiv_make((unsigned)WT);
     int trows = (NW * MTW * 16) / WT;
@@ -3146,15 +3170,8 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
     const int fam = (algo >> 8) & 15, f_nt = (algo >> 4) & 15, f_mt = algo & 15, f_th = (algo >> 12) & 255;
     if (fam == 6 || fam == 10 || fam == 12) {   // Winograd F(2x2,3x3): 0x6NM = 8 waves, 0xANM = 8 waves + half-chunk patch, 0xCNM = 12 waves + half-chunk patch
         if (mode != 0 || R != 4) { rv_set_error("rv_conv_fwd: the Winograd kernel needs a 3x3 conv with Cin %% 16 == 0"); return RV_EUNSUPPORTED; }
-        // (RV_WINO_LAYOUT=0: the 2-way-conflict even / odd plane image instead of the conflict-free one -- A/B experiments only)
-        static const int lay_env = getenv("RV_WINO_LAYOUT") ? atoi(getenv("RV_WINO_LAYOUT")) : 1;
-        int rcw;
-        if (lay_env == 0)
-            rcw = fam == 6 ? launch_conv3x3_wino<8, false, 0>(a, f_nt, f_mt, f_th, st)
-                           : (fam == 10 ? launch_conv3x3_wino<8, true, 0>(a, f_nt, f_mt, f_th, st) : launch_conv3x3_wino<12, true, 0>(a, f_nt, f_mt, f_th, st));
-        else
-            rcw = fam == 6 ? launch_conv3x3_wino<8>(a, f_nt, f_mt, f_th, st)
-                           : (fam == 10 ? launch_conv3x3_wino<8, true>(a, f_nt, f_mt, f_th, st) : launch_conv3x3_wino<12, true>(a, f_nt, f_mt, f_th, st));
+        const int rcw = fam == 6 ? launch_conv3x3_wino<8>(a, f_nt, f_mt, f_th, st)
+                                 : (fam == 10 ? launch_conv3x3_wino<8, true>(a, f_nt, f_mt, f_th, st) : launch_conv3x3_wino<12, true>(a, f_nt, f_mt, f_th, st));
         if (rcw != RV_OK) { rv_set_error("rv_conv_fwd: forced Winograd tile NT=%d MTW=%d TH=%d does not fit", f_nt, f_mt, f_th); return rcw; }
         RV_LAUNCH_CHECK("rv_conv_fwd(winograd)");
         *sums_done = true;
