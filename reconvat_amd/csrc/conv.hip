@@ -1603,6 +1603,7 @@ struct WgradArgs {
                                              // 2 no fragment reads, 4 stage the first row only, 8 no row barriers
     unsigned long long* dbg;                 // -DRV_ABLATION: s_memtime stamps of workgroup (0,0) / wave 0 (RV_DBG_PTR)
     FastDiv fd_vplane, fd_wv;                // divide by Hv*Wv, by Wv (small-channel kernel)
+    unsigned u_bytes, v_bytes;               // wgrad_wino_k: bytes of the U / V views (buffer-resource ranges of its staging loads; < 0x3f000000)
 };
 
 // LDS-staged pixel-reduction GEMM.  One workgroup owns a run of V rows (b, y) and one (a-group, b-group)
@@ -2047,34 +2048,53 @@ __global__ __launch_bounds__(NW * 64) void wgrad_wino_k(WgradArgs a) {
     for (int y = 0; y < TB; ++y) { accb[y] = (f32x4){0.f, 0.f, 0.f, 0.f}; accbs[y] = 0.f; }
     const bool do_bias = a.want_bias && ga == 0 && hp == 0;
     const int ca_valid = min(CA, a.Ca - a0), cb_valid = min(CB, a.Cb - b0);
-    const char* zsrc = reinterpret_cast<const char*>(rv_zero_piece) + lane * 16;
 
-    // ---- staging: which (pixel, quad) this lane fetches for piece k of a row (inverse of the LDS permutation) ----
+    // ---- staging: which (pixel, quad) this lane fetches for piece k of a row (inverse of the LDS permutation).  Rows travel through
+    // buffer resources over the U / V views (as in conv3x3_wino_k): a halo column, a padded channel quad and a row outside the image are
+    // all just an offset bump of OOB, which the hardware turns into zeros in LDS.  The per-lane byte offsets of a wave's pieces
+    // (k = wave, wave + NW, ...) do not depend on the row: computed once. ----
+    constexpr unsigned OOB = 0x40000000u;
+    constexpr int MAXP = 4;                                  // pieces per row and wave planned in registers (any further: generic loop)
+    const rv_rsrc_t rs_u = rv_make_rsrc(a.U, a.u_bytes), rs_v = rv_make_rsrc(a.V, a.v_bytes);
     const int upl = lane / C4A, uql = lane - upl * C4A;      // slot pixel inside the piece, quad position
     const int vpl = lane / C4B, vql = lane - vpl * C4B;
+    auto u_off = [&](int k) -> unsigned {
+        const int Xs = k * PPA + upl;                                            // pixel slot
+        const int X = CA == 32 ? Xs : (Xs ^ ((Xs >> 1) & 1));                    // source pixel (+1)
+        const int q = CA == 32 ? (uql ^ (4 * ((X >> 1) & 1))) : uql;             // source quad
+        const int x = X - 1;
+        return ((unsigned)x < (unsigned)a.Wu && q * 4 < ca_valid) ? (unsigned)(x * a.u_ld + q * 4) * 4u : OOB;
+    };
+    auto v_off = [&](int k) -> unsigned {
+        const int Xs = k * PPB + vpl;
+        const int X = CB == 32 ? Xs : (Xs ^ ((Xs >> 1) & 1));
+        const int q = CB == 32 ? (vql ^ (4 * ((X >> 1) & 1))) : vql;
+        return (X < a.Wv && q * 4 < cb_valid) ? (unsigned)(X * a.v_ld + q * 4) * 4u : OOB;
+    };
+    unsigned u_goff[MAXP], v_goff[MAXP];
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) { u_goff[j] = u_off(wave + NW * j); v_goff[j] = v_off(wave + NW * j); }
     auto dma_urow = [&](int b, int r, int slot) {            // input row r of image b -> ring slot
         float* dst0 = ubuf + slot * UPp * CA;
-        const bool inside = r >= 0 && r < a.Hu;
-        const float* src = a.U + ((long)b * a.Hu + (inside ? r : 0)) * a.Wu * a.u_ld + a0;
-        for (int k = wave; k * PPA < UPp; k += NW) {
-            const int Xs = k * PPA + upl;                                        // pixel slot
-            const int X = CA == 32 ? Xs : (Xs ^ ((Xs >> 1) & 1));                // source pixel (+1)
-            const int q = CA == 32 ? (uql ^ (4 * ((X >> 1) & 1))) : uql;         // source quad
-            const int x = X - 1;
-            const bool real = inside && x >= 0 && x < a.Wu && q * 4 < ca_valid;
-            glds16(real ? src + (long)x * a.u_ld + q * 4 : reinterpret_cast<const float*>(zsrc), dst0 + k * PPA * CA);
+        const unsigned base = (unsigned)r < (unsigned)a.Hu ? (unsigned)(((b * a.Hu + r) * a.Wu) * a.u_ld + a0) * 4u : OOB;
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) {
+            const int k = wave + NW * j;
+            if (k * PPA >= UPp) break;
+            rv_buf_lds16(rs_u, dst0 + k * PPA * CA, u_goff[j] + base);
         }
+        for (int k = wave + NW * MAXP; k * PPA < UPp; k += NW) rv_buf_lds16(rs_u, dst0 + k * PPA * CA, u_off(k) + base);
     };
     auto dma_vrow = [&](int b, int y, int vslot) {           // dY row y of image b -> vbuf row slot (0..3)
         float* dst0 = vbuf + vslot * VPp * CB;
-        const float* src = a.V + ((long)b * a.Hv + y) * a.Wv * a.v_ld + b0;
-        for (int k = wave; k * PPB < VPp; k += NW) {
-            const int Xs = k * PPB + vpl;
-            const int X = CB == 32 ? Xs : (Xs ^ ((Xs >> 1) & 1));
-            const int q = CB == 32 ? (vql ^ (4 * ((X >> 1) & 1))) : vql;
-            const bool real = X < a.Wv && q * 4 < cb_valid;
-            glds16(real ? src + (long)X * a.v_ld + q * 4 : reinterpret_cast<const float*>(zsrc), dst0 + k * PPB * CB);
+        const unsigned base = (unsigned)(((b * a.Hv + y) * a.Wv) * a.v_ld + b0) * 4u;
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) {
+            const int k = wave + NW * j;
+            if (k * PPB >= VPp) break;
+            rv_buf_lds16(rs_v, dst0 + k * PPB * CB, v_goff[j] + base);
         }
+        for (int k = wave + NW * MAXP; k * PPB < VPp; k += NW) rv_buf_lds16(rs_v, dst0 + k * PPB * CB, v_off(k) + base);
     };
     // tile row yp of an image needs input rows 2 yp - 1 .. 2 yp + 2; input row r lives in ring slot (r + 1) % 6
     auto uslot = [&](int r) -> int { return (r + 1 + NSLOT) % NSLOT; };
@@ -3382,7 +3402,9 @@ static int conv_wgrad_impl(int mode, const float* U, int u_ld, int Hu, int Wu, i
         const int nh_ = (plan.TA == 2 && plan.TB == 2) ? 2 : 1, nxg_ = 8 / nh_;
         const size_t fold = (size_t)nh_ * (nxg_ / 2) * (9 * (plan.TA / nh_) * plan.TB + plan.TB) * 4 * 64 * sizeof(float);
         if (wino_lds < fold) wino_lds = fold;
-        if (want_bf || mode != 0 || Hu != Hv || Wu != Wv || wino_lds > 160 * 1024) {
+        const long ub = (((long)B * Hu * Wu - 1) * u_ld + Ca) * 4, vb = (((long)B * Hv * Wv - 1) * v_ld + Cb) * 4;
+        a.u_bytes = (unsigned)ub; a.v_bytes = (unsigned)vb;   // (the staging loads address the views with 30-bit offsets: see the kernel)
+        if (want_bf || mode != 0 || Hu != Hv || Wu != Wv || wino_lds > 160 * 1024 || ub >= 0x3f000000L || vb >= 0x3f000000L) {
             plan.wino = false;                             // this launch runs the direct form on the same partition, in ROWS
             plan.rows_per_wave *= 2;                       // (the workspace was sized for this many partial sums: same layout)
             plan.nparts = cdiv((long)B * Hv, plan.rows_per_wave);
