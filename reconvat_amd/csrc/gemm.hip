@@ -19,6 +19,10 @@
 #define LDK (GBK + 4)    // row stride of a [rows][k] tile
 #define LDM (GBM + 4)    // row stride of a [k][rows] tile
 
+// 16-byte accesses to rows that are only 4-byte aligned (row strides 229, 317, ...): legal on this target (unaligned access mode is on for
+// global memory -- hipcc itself emits global_load_dwordx4 for such a type) and a quarter of the instructions of the scalar path
+typedef f32x4 f32x4u __attribute__((aligned(4)));
+
 struct GemmArgs {
     const float* A; long sam, sak;
     const float* B; long sbk, sbn;
@@ -58,7 +62,7 @@ struct TileIO {
             if (KFAST) {
                 if (gr < nrows) {
                     const float* p = base + (long)gr * s_row + (long)gk * s_k;
-                    if (vec && gk + 3 < k_end) v = *reinterpret_cast<const f32x4*>(p);
+                    if (vec && gk + 3 < k_end) v = *reinterpret_cast<const f32x4u*>(p);
                     else {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) if (gk + j < k_end) v[j] = p[(long)j * s_k];
@@ -67,7 +71,7 @@ struct TileIO {
             } else {
                 if (gk < k_end) {
                     const float* p = base + (long)gr * s_row + (long)gk * s_k;
-                    if (vec && gr + 3 < nrows) v = *reinterpret_cast<const f32x4*>(p);
+                    if (vec && gr + 3 < nrows) v = *reinterpret_cast<const f32x4u*>(p);
                     else {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) if (gr + j < nrows) v[j] = p[(long)j * s_row];
@@ -196,7 +200,7 @@ __device__ __forceinline__ void gemm_tile(GemmArgs a, const int bx, const int by
         else a.a_rowsum[m0 + tid] += rowsum;                             // one workgroup per row block: plain read-modify-write
     }
     const bool atomic_k = (a.splitk > 1 && !a.part) || a.atomic_out;     // atomic split-K (parameter gradients: order-dependent rounding is acceptable)
-    const bool vec_ok = a.scn == 1 && (a.scm & 3) == 0 && ((((uintptr_t)a.C) & 15) == 0) && !a.C2 && !atomic_k;
+    const bool vec_ok = a.scn == 1 && !a.C2 && !atomic_k;                  // (rows need not be 16-byte aligned: f32x4u)
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -216,8 +220,8 @@ __device__ __forceinline__ void gemm_tile(GemmArgs a, const int bx, const int by
             }
             float* c = a.C + (long)m * a.scm + (long)nb * a.scn;
             if (vec_ok && nb + 3 < a.N) {
-                if (a.accumulate) { f32x4 o = *reinterpret_cast<f32x4*>(c); v += o; }
-                *reinterpret_cast<f32x4*>(c) = v;
+                if (a.accumulate) { f32x4 o = *reinterpret_cast<f32x4u*>(c); v += o; }
+                *reinterpret_cast<f32x4u*>(c) = v;
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -296,8 +300,9 @@ static int gemm_args_make(GemmArgs& a, const float* A, long sam, long sak, const
     const bool a_kfast = (sak <= sam), b_kfast = (sbk <= sbn);
     // 16-byte loads need a unit stride along the fast dimension, a 16-byte multiple along the slow one and an
     // aligned base; K-split offsets are multiples of GBK so they preserve alignment
-    a.a_vec = ((a_kfast ? sak : sam) == 1) && (((a_kfast ? sam : sak) & 3) == 0) && ((((uintptr_t)A) & 15) == 0) && (batch == 1 || (bsa & 3) == 0);
-    a.b_vec = ((b_kfast ? sbk : sbn) == 1) && (((b_kfast ? sbn : sbk) & 3) == 0) && ((((uintptr_t)B) & 15) == 0) && (batch == 1 || (bsb & 3) == 0);
+    static const int uvec_env = getenv("RV_GEMM_UNALIGNED_VEC") ? atoi(getenv("RV_GEMM_UNALIGNED_VEC")) : 1;
+    a.a_vec = ((a_kfast ? sak : sam) == 1) && (uvec_env || ((((a_kfast ? sam : sak) & 3) == 0) && ((((uintptr_t)A) & 15) == 0) && (batch == 1 || (bsa & 3) == 0)));
+    a.b_vec = ((b_kfast ? sbk : sbn) == 1) && (uvec_env || ((((b_kfast ? sbn : sbk) & 3) == 0) && ((((uintptr_t)B) & 15) == 0) && (batch == 1 || (bsb & 3) == 0)));
     return RV_OK;
 }
 
