@@ -61,8 +61,12 @@ __device__ __forceinline__ int stage_rows(float* dst, int ldk, const float* src,
     // Lean on purpose: the kernels are bound by the instructions spent here, not by bytes.  Everything per lane is
     // hoisted (byte offset inside a row, lane mask); per row there is a pointer bump, a range test and the DMA.
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // v4: the whole quads of a row travel 16 bytes per lane -- the source needs 4-byte alignment only (tools/probes/glds16_unaligned.hip), so this
+    // also serves dh = 229 (57 quads + one 4-byte tail instruction instead of four 4-byte instructions per row); else 4 bytes per lane
     const int per = v4 ? 256 : 64;                                   // floats one DMA instruction moves
-    const int ninst = (dh + per - 1) / per;
+    const int nfull = v4 ? (dh & ~3) : dh;                           // floats covered by the main instructions
+    const int ninst = (nfull + per - 1) / per;
+    const int rem = dh - nfull;                                      // v4: 0..3 floats left for one 4-byte instruction
     const int lf = v4 ? lane * 4 : lane;                             // this lane's first float inside an instruction
     const float* s = src + ((long)(row0 + wave) * ld + col0) + lf;   // only dereferenced for rows inside [0, L)
     const float* z = rv_attn_zero + lf;                              // (one instruction's worth of zeros: every k reads the same piece)
@@ -75,7 +79,11 @@ __device__ __forceinline__ int stage_rows(float* dst, int ldk, const float* src,
         const bool real = r < nvalid && t >= 0 && t < L;
         if (v4) {
             for (int k = 0; k < ninst; ++k)
-                if (k * 256 + lf < dh) glds16(real ? s + k * 256 : z, drow + k * 256);
+                if (k * 256 + lf < nfull) glds16(real ? s + k * 256 : z, drow + k * 256);
+            if (rem) {
+                if (lane < rem) glds4(real ? s - lf + nfull + lane : rv_attn_zero + lane, drow + nfull);
+                ++issued;
+            }
         } else {
             for (int k = 0; k < ninst; ++k)
                 if (k * 64 + lf < dh) glds4(real ? s + k * 64 : z, drow + k * 64);
@@ -363,7 +371,13 @@ __global__ __launch_bounds__(AT_NTHR) void attn_bwd_kv_k(AttnArgs a) {
     apply_tiles<3>(A5, AT_A2LD, Yq, ldk, nchunk, a.dk + orow, a.dld, g * dh, dh, a.L - s0);
 }
 
-static bool attn_v4(int dh, long ld, const void* p) { return (dh % 4) == 0 && (ld % 4) == 0 && (((uintptr_t)p) & 15) == 0; }
+// 16-byte DMA lanes are legal for every fp32 row (the source needs 4-byte alignment only; a row tail of dh % 4 floats goes 4 bytes per lane).
+// RV_ATTN_V4_ALIGNED=1 restores the round-3 rule (16-byte aligned rows of a multiple of four floats) for A/B runs.
+static bool attn_v4(int dh, long ld, const void* p) {
+    static const int aligned_only = getenv("RV_ATTN_V4_ALIGNED") ? atoi(getenv("RV_ATTN_V4_ALIGNED")) : 0;
+    if (!aligned_only) return true;
+    return (dh % 4) == 0 && (ld % 4) == 0 && (((uintptr_t)p) & 15) == 0;
+}
 
 static int attn_setup(AttnArgs& a, int dh, const char* who) {
     RV_CHECK_ARG(dh >= 1 && dh <= 256, "%s: head dim %d unsupported", who, dh);
