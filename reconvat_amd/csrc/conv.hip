@@ -2142,22 +2142,37 @@ __global__ __launch_bounds__(NW * 64) void wgrad_wino_k(WgradArgs a) {
         const float* vrow1 = vrow0 + VPp * CB;
         // (a source-level software pipeline of the k-steps -- raw operands of step s + 1 loaded under the MFMAs of step s, as in
         // wgrad_mfma_k -- was measured 2-6 % slower than the schedule the compiler finds for this plain loop)
-        for (int t0 = xg * 4; t0 < WT4; t0 += 4 * NXG) {      // k-step: tiles t0 .. t0 + 3
-            const int ub = 2 * t0 * CA, vbs = 2 * t0 * CB;
+        // Fragment pointers of this wave's FIRST k-step of the tile row; k-step s of the wave reads at the compile-time distance
+        // s * USTEP / s * VSTEP floats behind them (an instruction immediate), so the up-to-KMAX steps of a row are unrolled and cost
+        // no address arithmetic at all (the rolled loop spent 55 vector adds per 32 MFMAs on it).
+        constexpr int USTEP = 2 * 4 * NXG * CA, VSTEP = 2 * 4 * NXG * CB, KMAX = 8;
+        const float* up[4][4][TAW];
+        const float* vp[4][TB];
+#pragma unroll
+        for (int er = 0; er < 4; ++er)
+#pragma unroll
+            for (int ec = 0; ec < 4; ++ec)
+#pragma unroll
+                for (int ta = 0; ta < TAW; ++ta) up[er][ec][ta] = urow[er] + 2 * (xg * 4) * CA + uoff[ec][ta];
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) {
+                vp[dx][tb] = vrow0 + 2 * (xg * 4) * CB + voff[dx][tb];
+                vp[2 + dx][tb] = vrow1 + 2 * (xg * 4) * CB + voff[dx][tb];
+            }
+        auto kstep = [&](const int uo, const int vo) __attribute__((always_inline)) {       // k-step at float offsets (uo, vo) from the pointers
             float d[16][TAW], y[4][TB];
 #pragma unroll
             for (int er = 0; er < 4; ++er)
 #pragma unroll
                 for (int ec = 0; ec < 4; ++ec)
 #pragma unroll
-                    for (int ta = 0; ta < TAW; ++ta) d[er * 4 + ec][ta] = urow[er][ub + uoff[ec][ta]];
+                    for (int ta = 0; ta < TAW; ++ta) d[er * 4 + ec][ta] = up[er][ec][ta][uo];
 #pragma unroll
-            for (int dx = 0; dx < 2; ++dx)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int tb = 0; tb < TB; ++tb) {
-                    y[dx][tb] = vrow0[vbs + voff[dx][tb]];
-                    y[2 + dx][tb] = vrow1[vbs + voff[dx][tb]];
-                }
+                for (int tb = 0; tb < TB; ++tb) y[e][tb] = vp[e][tb][vo];
             // P = B^T d B (rows, then columns)
 #pragma unroll
             for (int ta = 0; ta < TAW; ++ta) {
@@ -2191,7 +2206,13 @@ __global__ __launch_bounds__(NW * 64) void wgrad_wino_k(WgradArgs a) {
 #pragma unroll
                     for (int tb = 0; tb < TB; ++tb)
                         acc[xi][ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[xi][ta], q[xi][tb], acc[xi][ta][tb], 0, 0, 0);
-        }
+        };
+        const int nk = (WT4 - xg * 4 + 4 * NXG - 1) / (4 * NXG);          // k-steps of this wave on this tile row
+        sfor<0, KMAX>([&](auto sc) {
+            constexpr int S = decltype(sc)::value;
+            if (S < nk) kstep(S * USTEP, S * VSTEP);
+        });
+        for (int sk = KMAX; sk < nk; ++sk) kstep(sk * USTEP, sk * VSTEP);      // (rows wider than 8 k-steps per wave: rolled)
     }
     if (do_bias) {
 #pragma unroll
