@@ -416,9 +416,8 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N > 15 ? 15 : N) : "memory");
 }
 
-// 1 KiB of zeros in global memory: the DMA source of everything that must read as zero (rows above / below the image, the halo
-// columns) -- every piece of every staged row is then written by exactly one unmasked DMA instruction per unit, and the staging code
-// has no exec-mask or row branches left
+// 1 KiB of zeros in global memory: conv3x3_lds_k's DMA source for rows above / below the image (no row branch around a store loop).
+// The Winograd kernels stage through buffer resources instead, where out-of-range offsets read as zeros (rv_buf_lds16 below).
 __device__ __attribute__((aligned(16))) const float rv_zero_piece[256] = {0.f};
 
 // BF (R == 4 only; opt-in experiment, BASELINE config 3): the operands are rounded to bf16 (round-to-nearest-even,
@@ -2003,8 +2002,8 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
 // (pixel-major images put them exactly 128 or 256 bytes apart: a 2-way conflict on every read, as in the direct kernel):
 //   32-channel groups: the 16-byte quad q of pixel X is stored at quad position q ^ (4 * ((X >> 1) & 1))
 //   16-channel groups: pixel X is stored in pixel slot X ^ ((X >> 1) & 1)
-// Rows / columns outside the image and unused channels are fetched from rv_zero_piece: every piece of every staged row is written by
-// one unmasked DMA instruction, nothing is zero-filled by stores.
+// Rows / columns outside the image and unused channels are out-of-range offsets of the buffer resources the rows are staged through (the
+// hardware writes zeros for them): every piece of every staged row is written by one unmasked DMA instruction, nothing is zero-filled by stores.
 // ------------------------------------------------------------------------------------------
 template <int C> __device__ __forceinline__ int wgw_pos(int X, int c) {          // float offset of channel c of pixel X inside a staged row
     return C == 32 ? X * 32 + ((((c >> 4) ^ ((X >> 1) & 1)) << 4) | (c & 15)) : (X ^ ((X >> 1) & 1)) * 16 + c;
