@@ -417,7 +417,7 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
 }
 
 // 1 KiB of zeros in global memory: conv3x3_lds_k's DMA source for rows above / below the image (no row branch around a store loop).
-// The Winograd kernels stage through buffer resources instead, where out-of-range offsets read as zeros (rv_buf_lds16 below).
+// The Winograd kernels stage through buffer resources instead, where out-of-range offsets read as zeros (rv_buf_lds16 above).
 __device__ __attribute__((aligned(16))) const float rv_zero_piece[256] = {0.f};
 
 // BF (R == 4 only; opt-in experiment, BASELINE config 3): the operands are rounded to bf16 (round-to-nearest-even,
