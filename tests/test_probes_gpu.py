@@ -1,0 +1,32 @@
+"""The two hardware facts the Winograd staging and the unaligned 16-byte accesses rely on, checked on the device under test
+(tools/probes/*.hip are stand-alone HIP programs: compiled with hipcc here, run on cuda:0)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_probe(name, tmp_path):
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    exe = str(tmp_path / name)
+    src = os.path.join(ROOT, 'tools', 'probes', name + '.hip')
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O2', src, '-o', exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    return r.returncode, r.stdout
+
+
+def test_buffer_lds_dma_zero_fills_out_of_range_lanes(tmp_path):
+    """conv3x3_wino_k / wgrad_wino_k: halo columns, padded channel quads and rows outside the image are out-of-range buffer offsets."""
+    rc, out = _run_probe('buffer_lds_oob', tmp_path)
+    assert rc == 0 and 'zero-filled (0 mismatches)' in out, out
+
+
+def test_lds_dma_16_bytes_takes_4_byte_aligned_sources(tmp_path):
+    """attention staging of 229-float rows: 16-byte DMA lanes on sources that are only 4-byte aligned."""
+    rc, out = _run_probe('glds16_unaligned', tmp_path)
+    assert rc == 0 and out.count(': ok') == 4, out
