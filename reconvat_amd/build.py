@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libreconvat_hip.so')
-SOURCES = ['conv.hip', 'bn.hip', 'gemm.hip', 'attn.hip', 'elementwise.hip', 'mel.hip', 'data.hip', 'lstm.hip', 'api.cpp']
+SOURCES = ['conv.hip', 'conv_wino2.hip', 'bn.hip', 'gemm.hip', 'attn.hip', 'elementwise.hip', 'mel.hip', 'data.hip', 'lstm.hip', 'api.cpp']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
@@ -23,7 +23,7 @@ def _stale(target, deps):
 def _compile(src):
     obj = os.path.join(CSRC, os.path.splitext(src)[0] + '.o')
     path = os.path.join(CSRC, src)
-    deps = [path, os.path.join(CSRC, 'common.h')]
+    deps = [path, os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_shared.h')]
     if _stale(obj, deps):
         cmd = [HIPCC] + FLAGS + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', path, '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -339,6 +339,12 @@ class _Base(nn.Module):
         self.reconstruction = reconstruction
         self.vat_loss = UNet_VAT(XI, eps, 1, False)
 
+    def __del__(self):
+        try:
+            ops.drop_packs_of_params(list(self.parameters()))     # the packed-weight cache holds its source weights: they go with the model
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
     def _front(self, audio, ref_len):
         audio = audio.reshape(-1, ref_len)[:, :-1]
         if self.normalize.mode == 'imagewise':

@@ -209,6 +209,20 @@ def drop_packs_of(flat):
         del _pack_cache[k]
 
 
+def drop_packs_of_params(params):
+    """Forget every packed copy whose source weight shares storage with one of `params` (a model that is going away: _Base.__del__).
+    Together with drop_packs_of (FlatAdam.__del__) this is what bounds the cache: entries die with their OWNER, not with their age --
+    a live but idle model (an evaluation copy, the frame model while the onset model trains) keeps its packs."""
+    sps = set()
+    for p in params:
+        try:
+            sps.add(p.untyped_storage().data_ptr())
+        except Exception:  # noqa: BLE001 -- a parameter without storage (meta / already freed)
+            pass
+    for k in [k for k, v in _pack_cache.items() if v[2].untyped_storage().data_ptr() in sps]:
+        del _pack_cache[k]
+
+
 def invalidate_weight_cache():
     """Call after any out-of-band parameter update (custom optimiser step, load_state_dict)."""
     _EPOCH[0] += 1
@@ -329,9 +343,7 @@ class PackPlan:
     def __init__(self, device):
         import ctypes
         lib = _lib.load()
-        # packs of weights that were not refreshed for a while belong to models that are gone: drop them (they hold the weight alive)
-        for k in [k for k, v in _pack_cache.items() if v[0][0] < _EPOCH[0] - 64]:
-            del _pack_cache[k]
+        # (the cache is pruned by OWNER -- FlatAdam.__del__ -> drop_packs_of, _Base.__del__ -> drop_packs_of_params --, never by age)
         self.entries = [(k, v) for k, v in _pack_cache.items() if v[2].device == device]
         self.count = len(self.entries)
         if not self.count:

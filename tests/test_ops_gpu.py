@@ -226,7 +226,15 @@ WINO_CASES = [(16, 16, 12, 229, 0x611), (32, 32, 22, 114, 0x611), (64, 64, 31, 5
               (32, 32, 22, 114, 0xa21), (64, 64, 31, 57, 0xa21), (128, 128, 40, 28, 0x8a21), (96, 64, 21, 57, 0xa21), (16, 16, 12, 229, 0xa11), (48, 48, 9, 57, 0xa11),
               (64, 64, 31, 57, 0xac11), (16, 16, 12, 229, 0xc11), (128, 128, 40, 28, 0xc11), (32, 16, 9, 114, 0x4c11),
               # round 4: rows of exactly one / two 1 KiB pieces, weights too large to stay resident (double-buffered per chunk), resident at 4 chunks
-              (128, 128, 10, 14, 0x611), (32, 32, 8, 30, 0x611), (192, 96, 20, 28, 0x611), (64, 48, 12, 57, 0xa11), (192, 64, 9, 28, 0xc11)]
+              (128, 128, 10, 14, 0x611), (32, 32, 8, 30, 0x611), (192, 96, 20, 28, 0x611), (64, 48, 12, 57, 0xa11), (192, 64, 9, 28, 0xc11),
+              # round 5: the software-pipelined kernel (conv_wino2.hip) -- 0x8NM / 0x9NM: 8 waves with the full / half-chunk patch, 0xBNM / 0xDNM: 4 waves;
+              # one chunk, resident weights, the three-slot weight ring (> 3 chunks that do not fit), ragged last bands, forced rows per band
+              (16, 16, 12, 229, 0x811), (32, 32, 22, 114, 0x811), (64, 64, 31, 57, 0x811), (16, 32, 9, 114, 0x811), (128, 128, 40, 28, 0x811),
+              (96, 48, 21, 57, 0x811), (48, 24, 10, 114, 0x811), (32, 16, 3, 17, 0x811), (192, 96, 20, 28, 0x811), (16, 8, 8, 229, 0x811),
+              (64, 32, 20, 57, 0x911), (16, 16, 6, 57, 0x911), (32, 32, 22, 114, 0x921), (64, 64, 31, 57, 0x921), (128, 128, 40, 28, 0x8921),
+              (96, 64, 21, 57, 0x921), (192, 96, 20, 28, 0x921), (64, 64, 31, 57, 0x912), (16, 16, 12, 229, 0x912), (128, 128, 40, 28, 0x912),
+              (32, 32, 24, 114, 0x4811), (64, 64, 16, 28, 0x2811), (128, 128, 10, 14, 0x811), (32, 32, 8, 30, 0x811),
+              (64, 64, 31, 57, 0xb12), (16, 16, 12, 229, 0xb12), (96, 48, 21, 57, 0xb12), (64, 64, 31, 57, 0xb21), (128, 128, 40, 28, 0xb21), (192, 96, 20, 28, 0xb21)]
 
 
 @pytest.mark.parametrize('cin,cout,H,W,algo', WINO_CASES)
@@ -259,7 +267,8 @@ def test_conv3x3_winograd_vs_torch(dev, cin, cout, H, W, algo, monkeypatch):
                 assert torch.equal(ops.ConvFn.apply(g[0], g[1], g[2], 'c3', None), yg)
 
 
-@pytest.mark.parametrize('cin,cout,H,W,algo', [(32, 32, 22, 114, 0x611), (64, 32, 13, 57, 0xa21), (16, 16, 10, 229, 0xc11), (48, 16, 9, 57, 0xa11)])
+@pytest.mark.parametrize('cin,cout,H,W,algo', [(32, 32, 22, 114, 0x611), (64, 32, 13, 57, 0xa21), (16, 16, 10, 229, 0xc11), (48, 16, 9, 57, 0xa11),
+                                               (32, 32, 22, 114, 0x811), (64, 32, 13, 57, 0x921), (16, 16, 10, 229, 0x911), (48, 16, 9, 57, 0xb12)])
 def test_conv3x3_winograd_accumulate_and_colsum(dev, cin, cout, H, W, algo, monkeypatch):
     """The Winograd form behind the other two epilogue options of the persistent kernel: ``accumulate`` (a GradShare consumer adds its
     input gradient into the shared buffer) and the plain per-channel sums of what it stores (ColsumLink) -- against the direct form."""
@@ -301,7 +310,8 @@ def test_winograd_12_wave_tile_refuses_the_fused_bn_backward(dev, monkeypatch):
 
 
 @pytest.mark.parametrize('c1,c2,H,W,algo', [(16, 16, 12, 37, 0), (24, 16, 9, 57, 0x211), (64, 32, 8, 28, 0x321), (8, 2, 6, 19, 0), (8, 2, 37, 300, 0), (32, 32, 8, 30, 1),
-                                            (24, 16, 11, 114, 0x713), (64, 24, 9, 57, 0x726), (32, 32, 11, 114, 0x611), (16, 16, 9, 57, 0x611), (48, 32, 8, 28, 0xa11), (64, 64, 12, 57, 0xa21), (48, 48, 14, 229, 0x611), (96, 32, 9, 114, 0xa11)])
+                                            (24, 16, 11, 114, 0x713), (64, 24, 9, 57, 0x726), (32, 32, 11, 114, 0x611), (16, 16, 9, 57, 0x611), (48, 32, 8, 28, 0xa11), (64, 64, 12, 57, 0xa21), (48, 48, 14, 229, 0x611), (96, 32, 9, 114, 0xa11),
+                                            (32, 32, 11, 114, 0x811), (16, 16, 9, 57, 0x811), (48, 32, 8, 28, 0x911), (16, 16, 14, 229, 0x811), (64, 64, 12, 57, 0xb12)])
 def test_conv_dgrad_fused_bn_backward_reduction(dev, c1, c2, H, W, algo, monkeypatch):
     """conv2(lrelu(bn(z))): with a BnLink the input-gradient kernel of conv2 also produces the BatchNorm's backward
     reduction (epilogue of the persistent kernel, reduction pass behind the others); gradients must not change."""
