@@ -139,6 +139,8 @@ def measure_conv_phase(step_fn, device):
     total_ms, total_flops, per_kernel, min_sets = 0.0, 0.0, [], 1 << 30
     # per-launch bound of SURVEY 8(d): min(matrix peak of the launch's operand type, arithmetic intensity x HBM bandwidth)
     bound = {'all': [0.0, 0.0, 0.0], 'bf16': [0.0, 0.0, 0.0]}       # [measured ms, ideal ms at the bound, flops]
+    split = {'hbm_bound': [0.0, 0.0, 0.0, 0], 'mfma_bound': [0.0, 0.0, 0.0, 0]}      # [ms, flops, algorithmic bytes, launches] per step
+    bound['split'] = split
     for sig, g in groups.items():
         a0 = list(g['args'])
         if g['name'] == 'rv_conv_fwd':
@@ -190,7 +192,13 @@ def measure_conv_phase(step_fn, device):
         total_flops += fl * g['count']
         is_bf = conv_is_bf16(g['name'], g['args'])
         peak = (MFMA_BF16_PEAK_TFLOPS if is_bf else MFMA_F32_PEAK_TFLOPS) * 1e12
-        lim = min(peak, fl / conv_bytes(g['name'], g['args']) * HBM_PEAK_TBS * 1e12)
+        cbytes = conv_bytes(g['name'], g['args'])
+        lim = min(peak, fl / cbytes * HBM_PEAK_TBS * 1e12)
+        half = 'hbm_bound' if lim < peak else 'mfma_bound'          # which roof is the lower one for this launch
+        split[half][0] += ms * g['count']
+        split[half][1] += fl * g['count']
+        split[half][2] += cbytes * g['count']
+        split[half][3] += g['count']
         for key in (('all', 'bf16') if is_bf else ('all',)):
             bound[key][0] += ms * g['count']
             bound[key][1] += fl / lim * 1e3 * g['count']
@@ -412,7 +420,7 @@ def cpu_baseline():
     """The oracle (CPU restatement pinned to the reference by tests/golden) timed on this host's cores: one labelled + one
     unlabelled full-length segment per step (B = 1 + 1: a bounded sample of the B = 8 + 8 workload, same step definition:
     front-end, 2 x VAT, forward, backward, Adam) at 8 threads, and the workload's own B = 8 + 8 at 8 / 32 / 64 threads (capped at
-    the physical core count); `value` is the fastest of them, every run is listed."""
+    the physical core count); `value` is the fastest B = 8 + 8 run (the headline's own batch), every run is listed."""
     try:
         import psutil
         physical = psutil.cpu_count(logical=False) or os.cpu_count()
@@ -431,7 +439,7 @@ def cpu_baseline():
         runs.append({'threads': n, 'batch': '8+8', 's_per_step': round(per_step, 3), 'timed_steps': timed,
                      'audio_s_per_s': round(16 * SEG_SECONDS / per_step, 3)})
     torch.set_num_threads(prev)
-    best = max(runs, key=lambda r: r['audio_s_per_s'])
+    best = max((r for r in runs if r['batch'] == '8+8'), key=lambda r: r['audio_s_per_s'])     # `value`: the workload's own batch
     return {'value': best['audio_s_per_s'], 'unit': 'audio-s/s', 'cores': best['threads'], 'kind': 'port',
             'physical_cores': physical, 'logical_cpus': os.cpu_count(), 'runs': runs,
             'sample': f'B_l + B_ul = {best["batch"]} full 327680-sample segments per step, UNet_Onset VAT+recon fp32 (oracle = CPU port pinned '
@@ -491,6 +499,93 @@ def parity_leg(device):
             'kernel_plan_table': plans.digest()}
 
 
+def _time_steps(step, n):
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        step()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def deterministic_leg(args, device):
+    """The same step with RV_DETERMINISTIC=1 (ops.DETERMINISTIC): parameter gradients folded in a fixed order instead of by fp32 atomics
+    (per-layer weight-gradient reductions, ticketed in-order split-K of the parameter-gradient GEMMs) -- what bit-exact replica / solo-run
+    comparisons cost (tests/test_stress_gpu.py, tests/test_dp_gpu.py run in this mode).  A fresh model and capture; ms per step."""
+    from reconvat_amd import ops as ops_
+    prev = ops_.DETERMINISTIC[0]
+    ops_.DETERMINISTIC[0] = True
+    try:
+        _m, _o, _b, _bu, dstep = make_rank_step(args.model, args.batch, args.batch, 0, device)
+        dstep.capture()
+        return round(_time_steps(dstep, 10), 3)
+    except Exception as e:  # noqa: BLE001 -- a reported figure, never a reason to lose the line
+        return f'failed: {type(e).__name__}: {e}'
+    finally:
+        ops_.DETERMINISTIC[0] = prev
+
+
+def dp_seam_leg(step, args, device):
+    """What the data-parallel seam of a step costs on ONE GPU: the step is graph replay -> [gradient all-reduce] -> Adam -> repack, and
+    the collective is an eager RCCL call between a graph and a kernel.  Measured back to back in this process: K steps without a
+    process group, then K steps with a single-rank RCCL group and the all-reduce forced (RV_DP_FORCE_ALLREDUCE=1: the real
+    ncclAllReduce launch on the 14.6 MB bucket, in place, in stream order).  seam_ms = the difference."""
+    import torch.distributed as dist_
+    from reconvat_amd import dp
+    if dp.active():
+        return None
+    prev = {k: os.environ.get(k) for k in ('RV_DP_FORCE_ALLREDUCE', 'MASTER_ADDR', 'MASTER_PORT', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    try:
+        base = _time_steps(step, 10)
+        import socket
+        with socket.socket() as s_:
+            s_.bind(('127.0.0.1', 0))
+            port = s_.getsockname()[1]
+        os.environ.update(RV_DP_FORCE_ALLREDUCE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK=str(device.index or 0))
+        dp.init(device)
+        calls0 = int(getattr(step.opt, 'allreduce_calls', 0))
+        forced = _time_steps(step, 10)
+        calls = int(getattr(step.opt, 'allreduce_calls', 0)) - calls0
+        backend = dist_.get_backend()
+        dp.shutdown()
+        step.opt.grad_scale = 1.0
+        again = _time_steps(step, 10)
+        return {'ms_per_step_no_group': round(base, 3), 'ms_per_step_forced_allreduce': round(forced, 3), 'ms_per_step_no_group_again': round(again, 3),
+                'seam_ms': round(forced - 0.5 * (base + again), 3), 'allreduce_calls': calls, 'backend': backend, 'bucket_mb': round(step.opt.n * 4 / 1e6, 1)}
+    except Exception as e:  # noqa: BLE001
+        return {'failed': f'{type(e).__name__}: {e}'}
+    finally:
+        for k, v in prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def visible_gpus():
+    """GPUs this process may use, WITHOUT initialising the HIP runtime: the *_VISIBLE_DEVICES lists if set, else the KFD topology
+    (nodes with compute units); None when neither can be read (the ranks then fail on their own if a device is missing)."""
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(',') if x.strip() != ''])
+    root = '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        count = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, 'properties')) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            if int(props.get('simd_count', '0')) > 0:
+                count += 1
+        return count
+    except OSError:
+        return None
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: spawn N fresh rank processes (one per GPU) BEFORE this process touches
     the GPU, watch ALL of them, relay rank 0's JSON line; if any rank exits non-zero the others are terminated and the launcher
@@ -499,13 +594,13 @@ def self_launch(args):
     import subprocess
     import tempfile
     n = args.gpus
-    have = torch.cuda.device_count()              # (the ranks are fresh child processes: this process never execs and never runs GPU work)
+    have = visible_gpus()                         # (the launcher never touches the HIP runtime: the ranks are fresh child processes)
     if os.environ.get('RV_DP_SAME_GPU') == '1':   # every rank on cuda:0 over gloo (rank logic with the real kernels on a one-GPU box)
         if os.environ.get('RV_DP_BACKEND', 'nccl').lower() != 'gloo':
             raise SystemExit('RV_DP_SAME_GPU=1 needs RV_DP_BACKEND=gloo (RCCL refuses two ranks on one device)')
-        if have < 1:
+        if have is not None and have < 1:
             raise SystemExit('bench.py: no GPU')
-    elif have < n:
+    elif have is not None and have < n:
         raise SystemExit(f'bench.py --gpus {n}: this node exposes {have} GPU(s)')
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
@@ -627,7 +722,8 @@ def main():
         # the first optimiser step of this rank, seen from inside FlatAdam.step(): bucket before / after the collective, then the
         # parameters that step produced (written below, after the warm-up steps have been issued and synchronised)
         dump = {'rank': rank, 'world': world, 'audio_checksum_l': float(batch['audio'].double().sum()),
-                'audio_checksum_ul': float(batch_ul['audio'].double().sum()), 'cuda_seed': int(torch.cuda.initial_seed())}
+                'audio_checksum_ul': float(batch_ul['audio'].double().sum()), 'cuda_seed': int(torch.cuda.initial_seed()),
+                'omp_num_threads': os.environ.get('OMP_NUM_THREADS'), 'device': str(device), 'pid': os.getpid()}
 
         def dp_hook(when, o):
             if when + '_bucket' not in dump:
@@ -647,7 +743,13 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     t0 = time.perf_counter()
+    # test instrumentation (tests/test_dp_gpu.py): this rank dies in the middle of the timed loop -- its peers are then blocked in the
+    # next collective and it is the LAUNCHER's job to notice, terminate them and exit non-zero
+    fail_at = int(os.environ.get('RV_TEST_FAIL_AT', '0')) if os.environ.get('RV_TEST_FAIL_RANK') == str(rank) else None
     for i in range(args.steps):
+        if fail_at is not None and i == fail_at:
+            torch.cuda.synchronize()
+            os._exit(17)
         step()
         if dump is not None and i == 0:
             grab_params()
@@ -717,23 +819,40 @@ def main():
             # HBM bytes of the same launches from the committed PMC passes (rocprofv3 cannot run inside this process):
             # tools/pmc_traffic.py over separate FETCH_SIZE / WRITE_SIZE runs of `bench.py --no-graph`, gfx950-corrected
             traffic, traffic_src, traffic_digest, two_stream = None, None, None, None
-            for rnd in ('r04', 'r03', 'r02', 'r01'):
+            traffic_fam = None
+            for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
                 tpath = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_traffic.json')
                 if os.path.exists(tpath):
                     with open(tpath) as fh:
                         tj = json.load(fh)
                     traffic, traffic_digest = tj.get('traffic_bytes'), tj.get('kernel_plan_table')
+                    traffic_fam = tj.get('families')        # round 5: measured bytes of EVERY family of the step, not only the convs
                     traffic_src = f"profiles/{rnd}_pmc_traffic.json (committed PMC pass, {tj.get('git', 'commit not recorded')})"
                     break
             # the conv fraction INSIDE the shipped two-stream schedule: rocprofv3 kernel-trace of the timed command, summed by
             # tools/rocpd_stats.py (committed table; a profiler cannot run inside this process)
-            for rnd in ('r04',):
+            for rnd in ('r05', 'r04'):
                 spath = os.path.join(ROOT, 'profiles', f'{rnd}_two_stream_conv.json')
                 if os.path.exists(spath):
                     with open(spath) as fh:
                         two_stream = json.load(fh)
                     two_stream['source'] = f'profiles/{rnd}_two_stream_conv.json (tools/rocpd_stats.py --json over profiles/{rnd}_step_kernel_stats.txt\'s trace)'
+                    break
+            # the committed trace describes the tile table (and library) it ran: with another table the kernel times are not this build's
+            two_stream_ok = bool(two_stream) and two_stream.get('kernel_plan_table') == plans.digest()
+            if two_stream:
+                two_stream['kernel_plan_table_matches'] = two_stream_ok
             families = measure_families(eager, device)
+            if traffic_fam:
+                # measured HBM bytes (committed PMC passes) next to the algorithmic bytes each HBM-bound family is graded on
+                key = {'BatchNorm + leaky-ReLU': 'BatchNorm + leaky-ReLU (HBM)', 'local attention': 'local attention',
+                       'linear GEMMs': 'linear GEMMs (MFMA)', 'log-Mel front-end': 'front-end (HBM)'}
+                for f in families:
+                    t = traffic_fam.get(key.get(f['family'], ''))
+                    if t:
+                        f['measured_gb'] = round(t['traffic_bytes'] / 1e9, 2)
+                        if f['bound'] == 'hbm' and f['work_per_step']:
+                            f['measured_over_algorithmic'] = round(t['traffic_bytes'] / 1e9 / f['work_per_step'], 3)
             line['roofline'] = {
                 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,
@@ -741,9 +860,11 @@ def main():
                                  + str(traffic_src),
                 # the PMC pass ran the tile table with this digest; a mismatch means the committed traffic figure describes other tiles
                 'traffic_plan_table': traffic_digest, 'traffic_plan_table_matches': (traffic_digest == plans.digest()) if traffic_digest else None,
+                'traffic_by_family': traffic_fam,
                 # executed conv flops / summed conv kernel time of the SHIPPED two-stream schedule (kernels stretched by the concurrent chain)
+                # (None when the committed trace was taken with another tile table: ADVICE r04)
                 'frac_two_stream': (round(conv_flops_total / (two_stream['conv_ms_per_step'] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
-                                    if two_stream else None),
+                                    if two_stream_ok else None),
                 'two_stream': two_stream,
                 'kernel': 'conv3x3_lds_k / conv_mfma_k / wgrad_mfma_k family (all conv launches of one step)',
                 'conv_ms_source': 'isolated re-launch of every distinct conv launch of one step, HIP events on the launch stream, after the '
@@ -772,6 +893,17 @@ def main():
                                                 'mfma_peak_tflops': MFMA_BF16_PEAK_TFLOPS if k == 'bf16_launches' else 'per launch: 157.3 (f32) / 2500 (bf16)',
                                                 'hbm_tb_s': HBM_PEAK_TBS}
                                             for k, v in (('all_conv_launches', bound['all']), ('bf16_launches', bound['bf16'])) if v[0] > 0},
+                # the same launches split by WHICH roof is the lower one: the HBM-bound ones (1x1 skip, 2x2 down / up,
+                # C <= 2 layers, the 16-channel 3x3 layers) against HBM peak on their algorithmic bytes, the rest against the f32 MFMA peak
+                'conv_launches_by_roof': {
+                    'hbm_bound': {'ms_per_step': round(bound['split']['hbm_bound'][0], 3), 'launches': bound['split']['hbm_bound'][3],
+                                  'algorithmic_gb': round(bound['split']['hbm_bound'][2] / 1e9, 2),
+                                  'tb_s': round(bound['split']['hbm_bound'][2] / max(bound['split']['hbm_bound'][0], 1e-9) / 1e9, 3),
+                                  'frac_of_hbm_peak': round(bound['split']['hbm_bound'][2] / max(bound['split']['hbm_bound'][0], 1e-9) / 1e9 / HBM_PEAK_TBS, 4)},
+                    'mfma_bound': {'ms_per_step': round(bound['split']['mfma_bound'][0], 3), 'launches': bound['split']['mfma_bound'][3],
+                                   'gflop': round(bound['split']['mfma_bound'][1] / 1e9, 1),
+                                   'tflops': round(bound['split']['mfma_bound'][1] / max(bound['split']['mfma_bound'][0], 1e-9) / 1e9, 2),
+                                   'frac_of_mfma_peak': round(bound['split']['mfma_bound'][1] / max(bound['split']['mfma_bound'][0], 1e-9) / 1e9 / MFMA_F32_PEAK_TFLOPS, 4)}},
                 'top': [{'ms_per_step': round(t, 3), 'count': c, 'ms': round(m, 4), 'tflops': round(tf, 1), 'sig': list(map(str, s))}
                         for t, c, m, tf, s in per_kernel[:6]],
                 # every other kernel family of the step against the roofline that bounds it (same isolated re-launch method)
@@ -780,6 +912,8 @@ def main():
                               'unit': 'TFLOP/s', 'peak': MFMA_F32_PEAK_TFLOPS, 'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                               'work_per_step': round(conv_flops_total / 1e9, 1), 'work_unit': 'GFLOP'}] + families,
             }
+            line['deterministic_ms_per_step'] = deterministic_leg(args, device)
+            line['dp_seam'] = dp_seam_leg(step, args, device)
         if not args.no_parity:
             line['parity'] = parity_leg(device)
         if not args.no_cpu_baseline:

@@ -142,6 +142,10 @@ int rv_gemm_table_run(const void* table_dev, int count, long total_blocks, int o
 int rv_sigmoid_bwd(const float* g1, int ld1, const float* g2, int ld2, const float* y, int ldy, float* dz, int ldz, long M,
                    int N, void* stream);
 int rv_colsum(const float* x, int ld, long M, int N, float* out, int accumulate, void* stream);
+/* the same without atomics (the host side's RV_DETERMINISTIC=1 mode: bit-reproducible parameter gradients): row blocks leave their
+ * partial sums in ws (rv_colsum_ordered_workspace_bytes, uninitialised), a second pass folds them in block order */
+long rv_colsum_ordered_workspace_bytes(long M, int N);
+int rv_colsum_ordered(const float* x, int ld, long M, int N, float* out, int accumulate, void* ws, void* stream);
 /* out[i] (+)= per-channel sum c0 + i of a statistics workspace a conv's fused epilogue filled (rv_conv_fwd bn_sums, C channels): the
  * column sums of that conv's output = the bias gradient of the layer consuming it as dY (the 2x2 up-conv), without re-reading it */
 int rv_sums_fold(const double* sums, int C, int c0, int n, float* out, int accumulate, void* stream);

@@ -50,6 +50,8 @@ SIGNATURES = {
     'rv_gemm_table_run': (I, [P, I, L, I, P]),
     'rv_sigmoid_bwd': (I, [P, I, P, I, P, I, P, I, L, I, P]),
     'rv_colsum': (I, [P, I, L, I, P, I, P]),
+    'rv_colsum_ordered_workspace_bytes': (L, [L, I]),
+    'rv_colsum_ordered': (I, [P, I, L, I, P, I, P, P]),
     'rv_sums_fold': (I, [P, I, I, I, P, I, P]),
     'rv_local_attn_fwd': (I, [P, P, P, L, P, P, P, I, I, I, I, P]),
     'rv_local_attn_bwd': (I, [P, P, P, P, L, P, P, P, P, P, L, P, I, I, I, I, P]),

@@ -506,7 +506,10 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
                 for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        if (nbuf == 3) wait_vmcnt_le(ahead);                // this wave's share of unit u has landed (two buffers: the barrier's vmcnt(0) below)
+        if (nbuf == 3) wait_vmcnt_le(ahead);                // this wave's share of unit u has landed
+        // two buffers: nothing but unit u's DMA is in flight, wait for all of it.  EXPLICIT: the tap loop's ds_reads are inline asm, invisible
+        // to the compiler's wait-count insertion, so the landing of the LDS-DMA must not hang on what it happens to emit for the barrier
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(ABL(aa) & 1)) __syncthreads();              // ... and everyone's; unit u-1's buffer is free
         // The waves that share a SIMD stage at opposite ends of the unit (prefetch distance 2 only), so one wave's
         // address arithmetic / DMA issue overlaps the other's MFMAs instead of both idling the matrix pipe together.
@@ -872,7 +875,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
                     for (int xi = 0; xi < 16; ++xi) acc[m][n][xi] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        // (the barrier's own vmcnt(0) is the wait for unit u's DMA: with two buffers nothing else is in flight)
+        // unit u's DMA has landed (two buffers: nothing else is in flight).  EXPLICIT wait: the patch / weight ds_reads below are inline asm,
+        // invisible to the compiler's wait-count insertion -- the barrier must not depend on the vmcnt(0) it happens to emit today
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(ABL(aa) & 1)) __syncthreads();
         if (!(ABL(aa) & 2) && sg_u < nunits) stage();
         const unsigned xs_a = lds_addr(xs0 + buf * xfloats);

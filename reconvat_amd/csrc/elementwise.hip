@@ -356,6 +356,45 @@ int rv_colsum(const float* x, int ld, long M, int N, float* out, int accumulate,
     return RV_OK;
 }
 
+// Deterministic form of rv_colsum (RV_DETERMINISTIC=1 of the host side): no atomics.  Pass 1: row block b leaves its per-column sums in
+// ws[b][N] (plain stores, a fixed row order inside the block); pass 2: one thread per column folds the blocks in index order and
+// writes / accumulates.  ws: rv_colsum_ordered_workspace_bytes(M, N), uninitialised.
+__global__ __launch_bounds__(256) void colsum_part_k(const float* x, int ld, long M, int N, float* ws, long rows_per_block) {
+    __shared__ float sh[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = min(r0 + rows_per_block, M);
+    float s = 0.f;
+    if (col < N)
+        for (long r = r0 + rl; r < r1; r += 4) s += x[r * ld + col];
+    sh[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && col < N) ws[(long)blockIdx.y * N + col] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void colsum_fold_k(const float* ws, int nblk, int N, float* out, int accumulate) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= N) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += ws[(long)b * N + col];
+    out[col] = accumulate ? out[col] + s : s;
+}
+static long colsum_ordered_blocks(long M) {
+    long nblk = (M + 255) / 256;
+    return nblk > 1024 ? 1024 : (nblk < 1 ? 1 : nblk);
+}
+long rv_colsum_ordered_workspace_bytes(long M, int N) { return colsum_ordered_blocks(M) * (long)N * 4; }
+int rv_colsum_ordered(const float* x, int ld, long M, int N, float* out, int accumulate, void* ws, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    RV_CHECK_ARG(ws, "rv_colsum_ordered: null workspace");
+    const long nblk = colsum_ordered_blocks(M);
+    const long rpb = (M + nblk - 1) / nblk;
+    hipLaunchKernelGGL(colsum_part_k, dim3(cdiv(N, 64), (unsigned)nblk), dim3(256), 0, st, x, ld, M, N, (float*)ws, rpb);
+    hipLaunchKernelGGL(colsum_fold_k, dim3(cdiv(N, 256)), dim3(256), 0, st, (const float*)ws, (int)nblk, N, out, accumulate);
+    RV_LAUNCH_CHECK("rv_colsum_ordered");
+    return RV_OK;
+}
+
 // One Adam step on flat buffers; lr = lr0 * decay_rate^(step // decay_steps) (StepLR); *step is NOT modified
 // (call rv_counter_add afterwards, with the same skip word).  grad_scale multiplies g on the fly (1/world_size after an all-reduce sum).
 int rv_adam_step(float* p, const float* g, float* m, float* v, long n, const long* step, float lr0, long decay_steps,

@@ -19,6 +19,14 @@ BN_MOMENTUM = 0.1       # model/UNet_onset.py:183
 BN_EPS = 1e-5
 
 _EPOCH = [0]
+# RV_DETERMINISTIC=1 (or ops.DETERMINISTIC[0] = True): bit-reproducible PARAMETER GRADIENTS.  The data path -- forward passes and
+# input-gradient chains, hence every loss term and running statistic -- is free of fp32 atomics in every mode; what is order-dependent by
+# default are the folds onto the gradient bucket: the table-driven weight-gradient reductions (several passes of a step target the same
+# layer: fp32 atomics), the atomic split-K of the parameter-gradient GEMMs with the bias row sums riding on them, the column-sum bias
+# gradients.  In this mode the weight-gradient reductions run per layer in stream order (fixed tree, read-modify-write), the
+# parameter-gradient GEMMs use the ticketed in-order split-K of the data path, column sums the two-pass ordered form.  Slower (see
+# `deterministic_ms_per_step` in bench.py's line); the default stays the atomic folds.
+DETERMINISTIC = [os.environ.get('RV_DETERMINISTIC') == '1']
 _DIRECT = [False]
 
 
@@ -686,7 +694,7 @@ def conv_wgrad(kind, x, dy, w, want_bias=True, dw_acc=None, db_acc=None, bf16=Fa
     nbytes = lib.rv_conv_wgrad_workspace_bytes(taps, bb, hv, ca, cb)
     ws = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
     tables = _WGRAD_DEFER[0]
-    if tables is not None and acc and not (taps == 9 and ca == 1 and cb > 16):
+    if tables is not None and acc and not DETERMINISTIC[0] and not (taps == 9 and ca == 1 and cb > 16):
         cur = torch.cuda.current_stream(w.device)
         tab = tables.get(cur.cuda_stream)
         if tab is None:
@@ -705,7 +713,7 @@ def conv_wgrad(kind, x, dy, w, want_bias=True, dw_acc=None, db_acc=None, bf16=Fa
             # dY's column sums came with the kernel that produced dY (ColsumLink): fold the replicas, no pass over dY
             call('rv_sums_fold', ptr(colsum.sums), colsum.c, 0, cout, ptr(db), acc, stream())
         else:
-            call('rv_colsum', ptr(dy), yld, bb * ho * wo, cout, ptr(db), acc, stream())
+            _colsum_into(dy, yld, bb * ho * wo, cout, db, acc)
     return (None, None) if acc else (dw, db)
 
 
@@ -1165,8 +1173,16 @@ def colsum(x2d, out=None, accumulate=False):
     if out is None:
         out = torch.empty(x2d.shape[1], device=x2d.device, dtype=torch.float32)
     assert x2d.stride(1) == 1
-    call('rv_colsum', ptr(x2d), x2d.stride(0), x2d.shape[0], x2d.shape[1], ptr(out), 1 if accumulate else 0, stream())
+    _colsum_into(x2d, x2d.stride(0), x2d.shape[0], x2d.shape[1], out, accumulate)
     return out
+
+
+def _colsum_into(x, ld, m, n, out, accumulate):
+    if DETERMINISTIC[0]:
+        ws = torch.empty(_lib.load().rv_colsum_ordered_workspace_bytes(m, n) // 4, device=out.device, dtype=torch.float32)
+        call('rv_colsum_ordered', ptr(x), ld, m, n, ptr(out), 1 if accumulate else 0, ptr(ws), stream())
+    else:
+        call('rv_colsum', ptr(x), ld, m, n, ptr(out), 1 if accumulate else 0, stream())
 
 
 def _param_wgrad(a_t, b, param, splitk=None, bias_param=None):
@@ -1177,14 +1193,14 @@ def _param_wgrad(a_t, b, param, splitk=None, bias_param=None):
     if bias_param is not None:
         gb = _grad_buf(bias_param)
         if g is not None and gb is not None:
-            gemm(a_t, b, g.view(a_t.shape[0], b.shape[1]), accumulate=True, splitk=splitk, a_rowsum=gb, deterministic=False, defer_ok=True)
+            gemm(a_t, b, g.view(a_t.shape[0], b.shape[1]), accumulate=True, splitk=splitk, a_rowsum=gb, deterministic=DETERMINISTIC[0], defer_ok=True)
             return None, True
         return _param_wgrad(a_t, b, param, splitk), False
     if g is not None:
-        gemm(a_t, b, g.view(a_t.shape[0], b.shape[1]), accumulate=True, splitk=splitk, deterministic=False, defer_ok=True)
+        gemm(a_t, b, g.view(a_t.shape[0], b.shape[1]), accumulate=True, splitk=splitk, deterministic=DETERMINISTIC[0], defer_ok=True)
         return None
     dw = torch.empty((a_t.shape[0], b.shape[1]), device=b.device, dtype=torch.float32)
-    gemm(a_t, b, dw, splitk=splitk, deterministic=False)
+    gemm(a_t, b, dw, splitk=splitk, deterministic=DETERMINISTIC[0])
     return dw.view_as(param)
 
 
@@ -1367,10 +1383,10 @@ class LocalAttnFn(Function):
         if ctx.needs_input_grad[1]:
             gk, gq, gv = _grad_buf(pwk), _grad_buf(pwq), _grad_buf(pwv)
             if fused and _adjacent(gk, gq, gv):
-                gemm(dqkv.t(), x2, torch.as_strided(gk, (3 * f, fin), (fin, 1)), accumulate=True, deterministic=False, defer_ok=True)
+                gemm(dqkv.t(), x2, torch.as_strided(gk, (3 * f, fin), (fin, 1)), accumulate=True, deterministic=DETERMINISTIC[0], defer_ok=True)
             elif fused:
                 dw3 = torch.empty((3 * f, fin), device=x2.device, dtype=torch.float32)
-                gemm(dqkv.t(), x2, dw3, deterministic=False)
+                gemm(dqkv.t(), x2, dw3, deterministic=DETERMINISTIC[0])
                 dwk, dwq, dwv = dw3[:f], dw3[f:2 * f], dw3[2 * f:]
             else:
                 sk = None
@@ -1384,7 +1400,7 @@ class LocalAttnFn(Function):
             drel = grel.view(f, 31) if direct else torch.zeros((f, 31), device=q.device, dtype=torch.float32)
             de2 = de.view(m, g, 31)
             # one batched split-K launch over the heads: head h reads q[:, h*dh:], de[:, h, :], writes drel[h*dh:]
-            gemm(q[:, :dh].t(), de2[:, 0, :], drel[:dh], accumulate=True, deterministic=False, batch=g, bstrides=(dh, 31, dh * 31),
+            gemm(q[:, :dh].t(), de2[:, 0, :], drel[:dh], accumulate=True, deterministic=DETERMINISTIC[0], batch=g, bstrides=(dh, 31, dh * 31),
                  defer_ok=direct)       # (a zero-filled temporary handed back to autograd is filled NOW, never by a deferred launch)
             drel = None if direct else drel.view_as(rel)
         return dx, dwq, dwk, dwv, drel, None

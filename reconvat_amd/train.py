@@ -290,11 +290,20 @@ class TrainStep:
         self._dual_ready = False              # ... from the second step on: the first one packs weights and autotunes
         if getattr(model, 'has_recurrence', False):
             opt.sync_error_word = True
-        if dual_stream and self.batch['audio'].is_cuda:
+        self._top_up_pools()
+
+    def _top_up_pools(self):
+        """Pinned host tables a hipGraph capture pops from the process-wide pools (one per stream and table kind; they are freed with
+        the graph, never returned): topped up to what ONE capture of this step needs, here and again at the top of every capture() --
+        so re-capturing the same object, or building several steps before any of them captures, never runs a pool dry."""
+        if not self.batch['audio'].is_cuda:
+            return
+        streams = 1 + (getattr(self.model, 'side_streams', 1) if self.dual_stream else 0)
+        if self.dual_stream:
             ops.prepare_replay_pool()
-        if graph and self.batch['audio'].is_cuda:
-            ops.prepare_wgrad_tables(4)        # (top-ups: a capture pops what it pins, the rest of the pool is reused)
-            ops.prepare_gemm_tables(8)
+        if self.use_graph:
+            ops.prepare_wgrad_tables(max(4, streams))          # one table per stream
+            ops.prepare_gemm_tables(max(8, 2 * streams))       # one per stream and operand orientation
 
     def _fwd_bwd(self):
         self.opt.zero_grad()
@@ -309,7 +318,8 @@ class TrainStep:
             twins = self.opt.enable_side_bucket(n_side)
             ops.SIDE_GRADS[0] = (self.opt.flat_grad, {ops.side_stream(dev, i).cuda_stream: twins[i] for i in range(n_side)})
         try:
-            defer = os.environ.get('RV_DEFER_WGRAD', '1') != '0' and getattr(self.model, 'defer_wgrad_reductions', True)
+            # (RV_DETERMINISTIC=1: per-layer reductions in stream order instead of the table launch with its fp32 atomics, ops.DETERMINISTIC)
+            defer = os.environ.get('RV_DEFER_WGRAD', '1') != '0' and getattr(self.model, 'defer_wgrad_reductions', True) and not ops.DETERMINISTIC[0]
             defer_g = os.environ.get('RV_DEFER_GEMM', '1') != '0' and getattr(self.model, 'defer_param_gemms', True)
             with ops.bf16_final_graphs(fwd=False, bwd=self.bf16_backward), ops.direct_param_grads(), \
                     (ops.deferred_wgrad_reductions() if defer else contextlib.nullcontext()) as pending, \
@@ -352,6 +362,7 @@ class TrainStep:
         BatchNorm running statistics / `num_batches_tracked` / dropout epoch they advance are restored afterwards, so the
         first replay sees exactly the state the reference loop would (checkpointed buffers stay comparable)."""
         self.model.train()
+        self._top_up_pools()
         state = self._bn_state()
         saved = [b.clone() for b in state]
         s = torch.cuda.Stream()

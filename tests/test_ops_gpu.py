@@ -755,3 +755,41 @@ def test_wgrad_winograd_form_vs_torch(dev, kind, cin, cout, H, W):
     finally:
         lib.rv_conv_wgrad_set_plan(9, B, H, cin, cout, 0, 0)
         ops.AUTOTUNE = old
+
+
+def test_deterministic_mode_parameter_gradients(dev, monkeypatch):
+    """RV_DETERMINISTIC=1 (ops.DETERMINISTIC): the parameter-gradient folds without fp32 atomics -- ordered column sums, ticketed in-order
+    split-K with the bias row sums riding on it, per-layer weight-gradient reductions.  Repeated runs are bit-identical, and the values
+    agree with the default (atomic) folds to rounding."""
+    from reconvat_amd import ops, _lib
+    x = torch.rand(5000, 229, device=dev) - 0.5
+    out = torch.full((229,), 3.0, device=dev)
+    ws = torch.empty(_lib.load().rv_colsum_ordered_workspace_bytes(5000, 229) // 4, device=dev)
+    _lib.call('rv_colsum_ordered', x.data_ptr(), 229, 5000, 229, out.data_ptr(), 1, ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rel_err(out - 3.0, x.double().sum(0).float()) < 1e-5
+    # a strided narrow view over many rows (the up-conv bias gradient shape) -- accumulate = 0 overwrites
+    y = torch.rand(300000, 24, device=dev)[:, :16]
+    o2 = torch.full((16,), 9.0, device=dev)
+    ws2 = torch.empty(_lib.load().rv_colsum_ordered_workspace_bytes(300000, 16) // 4, device=dev)
+    _lib.call('rv_colsum_ordered', y.data_ptr(), 24, 300000, 16, o2.data_ptr(), 0, ws2.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rel_err(o2, y.double().sum(0).float()) < 1e-5
+
+    def grads(det):
+        monkeypatch.setattr(ops, 'DETERMINISTIC', [det])
+        torch.manual_seed(3)
+        xin = (torch.rand(5120, 176, device=dev) - 0.5).requires_grad_(True)
+        w = ((torch.rand(88, 176, device=dev) - 0.5) * 0.1).requires_grad_(True)
+        b = torch.zeros(88, device=dev, requires_grad=True)
+        yv = ops.LinearFn.apply(xin, w, b, 1)
+        (yv * (torch.rand(5120, 88, device=dev) - 0.5)).sum().backward()
+        cw = ((torch.rand(32, 16, 3, 3, device=dev) - 0.5) * 0.2).requires_grad_(True)
+        cb = torch.zeros(32, device=dev, requires_grad=True)
+        xi = torch.rand(2, 40, 57, 16, device=dev) - 0.5
+        z = ops.ConvFn.apply(xi, cw, cb, 'c3', None)
+        (z * (torch.rand_like(z) - 0.5)).sum().backward()
+        return [t.grad.clone() for t in (xin, w, b, cw, cb)]
+    d1, d2, a1 = grads(True), grads(True), grads(False)
+    for p, q in zip(d1, d2):
+        assert torch.equal(p, q)
+    for p, q in zip(d1, a1):
+        assert rel_err(p, q) < 1e-5

@@ -12,8 +12,45 @@ import os
 import sys
 from collections import defaultdict
 
-CONV = ('conv3x3_lds_k', 'conv3x3_wino_k', 'conv_mfma_k', 'conv_small_k', 'conv_narrow_out_k', 'conv_cin12_k', 'wgrad_mfma_k', 'wgrad_wino_k', 'wgrad_small_k', 'wgrad_small_sw_k', 'wgrad_cin1_k', 'wgrad_reduce_k',
+CONV = ('conv3x3_lds_k', 'conv3x3_wino_k', 'conv3x3_wino2_k', 'conv_mfma_k', 'conv_small_k', 'conv_narrow_out_k', 'conv_cin12_k', 'wgrad_mfma_k', 'wgrad_wino_k', 'wgrad_small_k', 'wgrad_small_sw_k', 'wgrad_cin1_k', 'wgrad_reduce_k',
         'wgrad_reduce_table_k')
+
+
+# round 5: every family of the step, same names as tools/rocpd_stats.py (bench.py prints measured / algorithmic bytes per family)
+FAMILIES = [
+    ('conv3x3 fwd+dgrad (MFMA)', ('conv3x3_lds_k', 'conv3x3_wino_k', 'conv3x3_wino2_k')),
+    ('conv direct 3x3/1x1/2x2 (MFMA / HBM)', ('conv_mfma_k',)),
+    ('conv C<=2 layers (HBM)', ('conv_small_k', 'wgrad_small_k', 'conv_narrow_out_k', 'conv_cin12_k', 'wgrad_small_sw_k', 'wgrad_cin1_k')),
+    ('weight gradients (MFMA)', ('wgrad_mfma_k', 'wgrad_wino_k', 'wgrad_reduce', 'sums_fold')),
+    ('linear GEMMs (MFMA)', ('gemm_', 'colsum', 'sigmoid', 'zero_strided')),
+    ('local attention', ('attn_',)),
+    ('BatchNorm + leaky-ReLU (HBM)', ('bn_',)),
+    ('front-end (HBM)', ('mel_',)),
+    ('losses / VAT elementwise (HBM)', ('reduce_', 'loss_bwd', 'vat_', 'elementwise', 'vectorized', 'Philox', 'distribution')),
+    ('optimiser + weight repack', ('adam_k', 'pack_', 'clip', 'counter_add')),
+]
+
+
+def family_pass(path, counter):
+    """{family: (reported KB, launches)} over the last complete optimiser step of one PMC pass."""
+    per = defaultdict(float)
+    name = {}
+    for row in csv.DictReader(open(path)):
+        if row['Counter_Name'] != counter:
+            continue
+        d = int(row['Dispatch_Id'])
+        per[d] += float(row['Counter_Value'])
+        name[d] = row['Kernel_Name']
+    ids = sorted(per)
+    adam = [d for d in ids if name[d].startswith('adam_k')]
+    lo, hi = adam[-2], adam[-1]
+    fam = defaultdict(lambda: [0.0, 0])
+    for d in ids:
+        if lo < d <= hi:
+            key = next((f for f, pats in FAMILIES if any(p in name[d] for p in pats)), 'other')
+            fam[key][0] += per[d]
+            fam[key][1] += 1
+    return fam
 
 
 def one_pass(path, counter):
@@ -41,7 +78,7 @@ def one_pass(path, counter):
 
 def main():
     root = sys.argv[1]
-    out = {}
+    out, fams = {}, {}
     for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
         for f in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True):
             with open(f) as fh:
@@ -49,7 +86,13 @@ def main():
             if counter in head:
                 kb, n, fam = one_pass(f, counter)
                 out[counter] = {'kb_reported': kb, 'launches': n, 'by_kernel_kb': dict(fam)}
+                fams[counter] = family_pass(f, counter)
                 break
+    families = {}
+    for fam in sorted(set(fams['FETCH_SIZE']) | set(fams['WRITE_SIZE'])):
+        fk, fn = fams['FETCH_SIZE'].get(fam, (0.0, 0))
+        wk, _ = fams['WRITE_SIZE'].get(fam, (0.0, 0))
+        families[fam] = {'fetch_bytes': fk * 1024 * 2, 'write_bytes': wk * 1024, 'traffic_bytes': fk * 1024 * 2 + wk * 1024, 'launches': fn}
     fetch = out['FETCH_SIZE']['kb_reported'] * 1024 * 2       # gfx950: x2
     write = out['WRITE_SIZE']['kb_reported'] * 1024
     import subprocess
@@ -63,6 +106,7 @@ def main():
            'kernel_plan_table': plans.digest(),         # the tile table these launches ran (bench.py flags a mismatch with its own)
            'fetch_bytes': fetch, 'write_bytes': write, 'traffic_bytes': fetch + write,
            'launches': out['FETCH_SIZE']['launches'],
+           'families': families,          # every family of the step (eager single-stream launches), gfx950-corrected like the conv total
            'correction': 'FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported',
            'raw': out}
     print(json.dumps(res, indent=1))

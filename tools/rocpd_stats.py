@@ -16,7 +16,7 @@ import sqlite3
 import sys
 
 FAMILIES = [
-    ('conv3x3 fwd+dgrad (MFMA)', ('conv3x3_lds_k', 'conv3x3_wino_k')),
+    ('conv3x3 fwd+dgrad (MFMA)', ('conv3x3_lds_k', 'conv3x3_wino_k', 'conv3x3_wino2_k')),
     ('conv direct 3x3/1x1/2x2 (MFMA / HBM)', ('conv_mfma_k',)),
     ('conv C<=2 layers (HBM)', ('conv_small_k', 'wgrad_small_k', 'conv_narrow_out_k', 'conv_cin12_k', 'wgrad_small_sw_k', 'wgrad_cin1_k')),
     ('weight gradients (MFMA)', ('wgrad_mfma_k', 'wgrad_wino_k', 'wgrad_reduce', 'sums_fold')),
@@ -69,11 +69,17 @@ def main():
     if '--json' in sys.argv:
         import json
         conv_fams = [f for f, _ in FAMILIES[:4]]
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from reconvat_amd import plans
         doc = {'steps': steps, 'wall_ms_per_step': (hi - lo) / 1e6 / steps, 'kernel_ms_per_step': total / 1e6 / steps,
+               # the tile table (and commit) the traced command ran: bench.py only uses the conv time of a trace whose table is its own
+               'kernel_plan_table': plans.digest(), 'git': os.environ.get('RV_GIT_SHA', 'not recorded'),
+               'launches_per_step': sum(r[1] for r in rows) / steps,
                'conv_ms_per_step': sum(fam[f][1] for f in conv_fams) / 1e6 / steps,
                'conv_launches_per_step': sum(fam[f][0] for f in conv_fams) / steps,
                'families_ms_per_step': {f: tot / 1e6 / steps for f, (c, tot) in fam.items() if c},
-               'winograd_ms_per_step': sum(r[2] for r in rows if 'conv3x3_wino_k' in r[0]) / 1e6 / steps}
+               'winograd_ms_per_step': sum(r[2] for r in rows if 'conv3x3_wino' in r[0]) / 1e6 / steps}
         with open(sys.argv[sys.argv.index('--json') + 1], 'w') as fh:
             json.dump(doc, fh, indent=1)
 
