@@ -30,3 +30,15 @@ def test_lds_dma_16_bytes_takes_4_byte_aligned_sources(tmp_path):
     """attention staging of 229-float rows: 16-byte DMA lanes on sources that are only 4-byte aligned."""
     rc, out = _run_probe('glds16_unaligned', tmp_path)
     assert rc == 0 and out.count(': ok') == 4, out
+
+
+def test_vector_alu_instructions_are_not_free_next_to_f32_mfma(tmp_path):
+    """Round 5: the fact behind the shape of the conv kernels' remaining inefficiency.  v_mfma_f32_16x16x4_f32 runs at the vector-ALU
+    rate on this chip (157.3 TFLOP/s for both), and VALU instructions issued between such MFMAs are NOT hidden behind them: four
+    v_add_f32 per MFMA stretch the loop by tens of percent (measured +60..80 %), i.e. a kernel's time is (MFMA time + VALU time), and the
+    Winograd transforms / epilogues / address arithmetic are paid in full."""
+    rc, out = _run_probe('mfma_valu_overlap', tmp_path)
+    assert rc == 0, out
+    line = [l for l in out.splitlines() if l.startswith('f32 MFMA: 4 VALU per MFMA cost')][-1]
+    pct = float(line.split('cost')[1].split('%')[0])
+    assert pct > 25.0, out
