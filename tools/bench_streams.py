@@ -1,5 +1,8 @@
 """Does running two independent transcriber chains on two HIP streams beat running them back to back?
-(forward + input-gradient backward of the VAT power iteration, B=8 each, captured in hipGraphs)"""
+(forward + input-gradient backward of the VAT power iteration, B=8 each, captured in hipGraphs)
+Round 5: ... and what would ONE chain on the concatenated batch of 16 cost (`merged16`: the unlabelled and the labelled VAT branch of a step
+in lock step -- the COST of that schedule; its BatchNorm statistics would have to stay per group of 8, which this probe does not do)?
+`FULL=1`: the grad-enabled final pass with parameter gradients instead of the detached power-iteration pass."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,6 +29,24 @@ def chain(x):
     return g
 
 
+FULL = os.environ.get('FULL') == '1'
+if FULL:
+    opt = ra.FlatAdam(m.parameters(), lr=0.0)
+
+    def chain(x):                                   # the final VAT pass: grad-enabled forward, full backward into the flat bucket
+        with ops.deferred_bn_updates(), ops.direct_param_grads():
+            roll, onset, _ = m.transcriber(x)
+            (roll.sum() + onset.sum()).backward()
+        return opt.flat_grad
+
+
+def merged16():
+    return [chain(torch.cat(xs, 0))] if not FULL else [chain(x16)]
+
+
+x16 = torch.cat(xs, 0)
+
+
 def both_serial():
     return [chain(x) for x in xs]
 
@@ -46,7 +67,7 @@ def both_parallel():
     return outs
 
 
-for fn in (both_serial, both_parallel):
+for fn in (both_serial, both_parallel, merged16):
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
