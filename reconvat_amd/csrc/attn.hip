@@ -407,7 +407,8 @@ int rv_local_attn_fwd(const float* q, const float* k, const float* v, long ld, c
     const int ntile = (L + AT_TT - 1) / AT_TT, ldk = a.dhp + 4;
     size_t lds = ((size_t)(AT_TT + 80) * ldk + AT_TT * AT_SLD + AT_TT * AT_A2LD) * sizeof(float);
     static const int relregs_env = getenv("RV_ATTN_REL_REGS") ? atoi(getenv("RV_ATTN_REL_REGS")) : 1;
-    a.rel_regs = relregs_env && lds > 78 * 1024;       // the rel^T block would leave room for only one workgroup per CU
+    static const size_t occ_kb = getenv("RV_ATTN_OCC_KB") ? (size_t)atoi(getenv("RV_ATTN_OCC_KB")) : 78;      // (experiment: 50 -> three workgroups per CU at dh = 128)
+    a.rel_regs = relregs_env && lds > occ_kb * 1024;       // the rel^T block would leave room for only one workgroup per CU
     if (a.rel_regs) lds -= (size_t)32 * ldk * sizeof(float);
     hipLaunchKernelGGL(attn_fwd_k, dim3(B * ntile, G), dim3(AT_NTHR), lds, (hipStream_t)stream, a);
     RV_LAUNCH_CHECK("rv_local_attn_fwd");
@@ -431,12 +432,13 @@ int rv_local_attn_bwd(const float* dout, const float* q, const float* k, const f
     const int ntile = (L + AT_TT - 1) / AT_TT, ldk = a.dhp + 4;
     size_t lds1 = ((size_t)(AT_TT + 80) * ldk + AT_TT * AT_SLD + AT_TT * AT_A3LD) * sizeof(float);
     static const int relregs_env = getenv("RV_ATTN_REL_REGS") ? atoi(getenv("RV_ATTN_REL_REGS")) : 1;
-    a.rel_regs = relregs_env && lds1 > 78 * 1024;
+    static const size_t occ_kb = getenv("RV_ATTN_OCC_KB") ? (size_t)atoi(getenv("RV_ATTN_OCC_KB")) : 78;
+    a.rel_regs = relregs_env && lds1 > occ_kb * 1024;
     if (a.rel_regs) lds1 -= (size_t)32 * ldk * sizeof(float);
     hipLaunchKernelGGL(attn_bwd_q_k, dim3(B * ntile, G), dim3(AT_NTHR), lds1, st, a);
     RV_LAUNCH_CHECK("rv_local_attn_bwd(q)");
     const size_t lds_two = ((size_t)2 * AT_WINP * ldk + 2 * AT_WINP * 32 + 2 * AT_TT * AT_A2LD) * sizeof(float);
-    a.seq_kv = lds_two > 78 * 1024;            // two windows at once would leave room for only one workgroup per CU
+    a.seq_kv = lds_two > occ_kb * 1024;            // two windows at once would leave room for only one workgroup per CU
     const size_t lds2 = lds_two - (a.seq_kv ? (size_t)AT_WINP * ldk * sizeof(float) : 0);
     hipLaunchKernelGGL(attn_bwd_kv_k, dim3(B * ntile, G), dim3(AT_NTHR), lds2, st, a);
     RV_LAUNCH_CHECK("rv_local_attn_bwd(kv)");

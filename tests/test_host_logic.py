@@ -261,3 +261,64 @@ def test_every_run_training_option_is_injected_by_the_scripts():
         injected, cfg = set(inspect.signature(mod.train).parameters), set(mod.config({}))
         assert not (options & cfg) - injected, (script, sorted((options & cfg) - injected))
         assert not injected - cfg, (script, sorted(injected - cfg))
+
+
+def test_launcher_counts_gpus_without_the_hip_runtime(monkeypatch):
+    """bench.py's self-launcher decides how many ranks fit WITHOUT initialising the runtime (round 5): the *_VISIBLE_DEVICES lists first,
+    else the KFD topology, else None (the ranks then fail on their own)."""
+    import bench
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,1,2')
+    assert bench.visible_gpus() == 3
+    monkeypatch.setenv('ROCR_VISIBLE_DEVICES', '4')              # takes precedence
+    assert bench.visible_gpus() == 1
+    monkeypatch.setenv('ROCR_VISIBLE_DEVICES', '')
+    assert bench.visible_gpus() == 0
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES'):
+        monkeypatch.delenv(var, raising=False)
+    n = bench.visible_gpus()
+    assert n is None or n >= 0                                    # KFD topology (0 compute nodes in the build container) or unreadable
+
+
+def test_deterministic_mode_switch_is_read_from_the_environment():
+    import subprocess
+    import sys
+    code = "from reconvat_amd import ops; print(ops.DETERMINISTIC[0])"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for val, want in (('1', 'True'), ('0', 'False'), (None, 'False')):
+        env = dict(os.environ, PYTHONPATH=root)
+        env.pop('RV_DETERMINISTIC', None)
+        if val is not None:
+            env['RV_DETERMINISTIC'] = val
+        out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, cwd=root)
+        assert out.returncode == 0 and out.stdout.strip() == want, (val, out.stdout, out.stderr[-500:])
+
+
+def test_numerics_emulation_helpers():
+    """The two emulation scripts behind DESIGN section 7 (split-bf16, Winograd F(4x4)): the 3-way bf16 split reproduces an fp32 value exactly,
+    the 2-way split to 2^-16, and the fp32 Winograd forms agree with a direct convolution to their known error levels."""
+    import torch
+    import torch.nn.functional as F
+    sys_path = os.path.dirname(os.path.abspath(__file__))
+    import sys
+    sys.path.insert(0, sys_path)
+    import emulate_bf16_split as eb
+    import emulate_winograd_f4 as ew
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(4096, generator=g) - 0.5) * 37.0
+    h, m, l = eb.split(x, 3)
+    assert torch.equal(h + m + l, x)
+    h2, l2 = eb.split(x, 2)
+    assert float(((h2 + l2) - x).abs().max() / x.abs().max()) < 2.0 ** -15
+    xi = torch.rand(2, 16, 19, 30, generator=g) - 0.5
+    w = (torch.rand(24, 16, 3, 3, generator=g) - 0.5) * 0.3
+    ref = F.conv2d(xi.double(), w.double(), padding=1)
+    e2 = float((ew.winograd_conv(xi, w, 2).double() - ref).abs().max() / ref.abs().max())
+    e4 = float((ew.winograd_conv(xi, w, 4).double() - ref).abs().max() / ref.abs().max())
+    assert e2 < 2e-6 and e4 < 5e-5 and e4 > e2
+    op = lambda a, b: F.conv2d(a, b, None, padding=1)
+    e6 = float((eb.emulated(op, xi, w, 'bf16x6').double() - ref).abs().max() / ref.abs().max())
+    e3 = float((eb.emulated(op, xi, w, 'bf16x3').double() - ref).abs().max() / ref.abs().max())
+    e1 = float((eb.emulated(op, xi, w, 'bf16').double() - ref).abs().max() / ref.abs().max())
+    assert e6 < 2e-6 and e6 < e3 < e1 and e1 > 1e-3
