@@ -21,6 +21,11 @@
 #include "common.h"
 #include <stdlib.h>
 
+// Timing ablations of attn_fwd_k (tools/attn_ablate.sh; wrong results by design; 0 in every product build):
+//   1 no staging (q tile, key / value windows, rel^T) | 2 no score MFMAs | 4 no softmax | 8 no banded apply | 16 return at entry
+#ifndef RV_ATTN_ABL
+#define RV_ATTN_ABL 0
+#endif
 #define AT_W 31
 #define AT_P 15
 #define AT_TT 16
@@ -219,8 +224,11 @@ __global__ __launch_bounds__(AT_NTHR) void attn_fwd_k(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g4 = lane >> 4;
     const long boff = (long)b * a.L * a.ld;
+    if (RV_ATTN_ABL & 16) return;
+    if (!(RV_ATTN_ABL & 1)) {
     stage_rows(Qs, ldk, a.q + boff, a.ld, g * dh, dh, dhp, t0, AT_TT, AT_TT, a.L, a.v4);
     stage_rows(Kx, ldk, a.k + boff, a.ld, g * dh, dh, dhp, t0 - AT_P, AT_WIN, AT_WINP, a.L, a.v4);
+    }
     f32x4 yb[16];                               // rel_regs: waves 3, 4 hold their rel^T score operand (row 16 (wave - 3) + i) in registers
     if (a.rel_regs) {
         if (wave >= 3) {
@@ -231,21 +239,21 @@ __global__ __launch_bounds__(AT_NTHR) void attn_fwd_k(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) yb[c][r] = (c < nchunk && w < AT_W && 16 * c + 4 * g4 + r < dh) ? rp[16 * c + r] : 0.f;
         }
-    } else {
+    } else if (!(RV_ATTN_ABL & 1)) {
         stage_rows(Kx + AT_WINP * ldk, ldk, a.rel, F, g * dh, dh, dhp, 0, AT_W, 32, AT_W, a.dv4);
     }
     for (int idx = tid; idx < AT_TT * AT_A2LD; idx += AT_NTHR) A2[idx] = 0.f;
     stage_wait();
     __syncthreads();
-    {
+    if (!(RV_ATTN_ABL & 2)) {
         const f32x4 s = (a.rel_regs && wave >= 3) ? score_tile_regs(Qs, yb, ldk, nchunk, i, g4)
                                                   : score_tile(Qs, Kx + 16 * wave * ldk, ldk, nchunk, i, g4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) Sr[(4 * g4 + r) * AT_SLD + 16 * wave + i] = s[r];
     }
     __syncthreads();                            // scores complete, key window dead
-    stage_rows(Kx, ldk, a.v + boff, a.ld, g * dh, dh, dhp, t0 - AT_P, AT_WIN, AT_WINP, a.L, a.v4);
-    if (tid < 256) {                            // softmax: 16 lanes per frame, two window slots per lane
+    if (!(RV_ATTN_ABL & 1)) stage_rows(Kx, ldk, a.v + boff, a.ld, g * dh, dh, dhp, t0 - AT_P, AT_WIN, AT_WINP, a.L, a.v4);
+    if (tid < 256 && !(RV_ATTN_ABL & 4)) {      // softmax: 16 lanes per frame, two window slots per lane
         const int t = tid >> 4, l = tid & 15;
         const float* sr = Sr + t * AT_SLD;
         const float e0 = sr[t + l] + sr[AT_WINP + l];
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(AT_NTHR) void attn_fwd_k(AttnArgs a) {
     }
     stage_wait();
     __syncthreads();
-    apply_tiles<3>(A2, AT_A2LD, Kx, ldk, nchunk, a.out + ((long)b * a.L + t0) * F, F, g * dh, dh, a.L - t0);
+    if (!(RV_ATTN_ABL & 8)) apply_tiles<3>(A2, AT_A2LD, Kx, ldk, nchunk, a.out + ((long)b * a.L + t0) * F, F, g * dh, dh, a.L - t0);
 }
 
 // backward, query side: de (softmax backward) and dq for a 16-frame tile
