@@ -1,3 +1,5 @@
+"""Raw f32 MFMA issue rate of the chip (rv_debug_mfma_peak: NACC independent accumulators per wave, no memory traffic): the 146-156 TFLOP/s the
+conv kernels are graded against."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reconvat_amd import _lib
