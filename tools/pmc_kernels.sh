@@ -15,6 +15,6 @@ for cfg in "$@"; do
       --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/b$i -- python3 $GRAFT_REPO_ROOT/tools/bench_conv.py $cfg 8 > $GRAFT_REPO_ROOT/$out/b$i.log 2>&1
 done
 cd $GRAFT_REPO_ROOT
-for d in $out/a* $out/b*; do [ -d $d ] && python3 tools/pmc_summary.py $d mfma_k; [ -d $d ] && python3 tools/pmc_summary.py $d lds_k; done > $out/summary.txt 2>&1
+for d in $out/a* $out/b*; do [ -d $d ] && python3 tools/pmc_summary.py $d mfma_k; [ -d $d ] && python3 tools/pmc_summary.py $d lds_k; [ -d $d ] && python3 tools/pmc_summary.py $d wino; done > $out/summary.txt 2>&1
 # keep only the summaries (the raw csv files are large)
 find $out -name "*.csv" -size +2M -delete
