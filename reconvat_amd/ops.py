@@ -495,6 +495,16 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
                                 th_max = min(h, 2 * ((nwv * mt * 16) // wt_))
                                 ths = [0] + [t for t in range(2, th_max, 2) if -(-h // t) != -(-h // (t + 2))]
                                 cands += [t << 12 | fam << 8 | nt << 4 | mt for t in ths]
+                        if os.environ.get('RV_TUNE_WINO2', '1') != '0':
+                            # ... and its software-pipelined form (conv_wino2.hip, round 5): 0x8NM / 0x9NM = 8 waves with the full / half-chunk patch,
+                            # 0xBNM = 4 waves; the taller half of the legal band heights only (short bands lose to their halo)
+                            for fam, nwv, tiles in ((8, 8, ((1, 1),)), (9, 8, ((1, 1), (2, 1), (1, 2))), (11, 4, ((1, 2), (2, 1)))):
+                                for nt, mt in tiles:
+                                    if ntile_n % nt:
+                                        continue
+                                    th_max = min(h, 2 * ((nwv * mt * 16) // wt_))
+                                    ths = [0] + [t for t in range(2, th_max, 2) if -(-h // t) != -(-h // (t + 2)) and t >= th_max // 2]
+                                    cands += [t << 12 | fam << 8 | nt << 4 | mt for t in ths]
                     fams = os.environ.get('RV_TUNE_FAMILIES')          # experiment: restrict the LDS tile families the tuner may pick
                     if fams:
                         keep = {int(f, 0) for f in fams.split(',')}
