@@ -50,9 +50,9 @@ int rv_melspec_lognorm_fwd(const float* audio, long audio_stride, int B, int nsa
  *   12 waves per workgroup (MTW in {3,5,6} for 12 waves: 9/15/18 tiles per SIMD and band), optionally TH<<12 = rows per band
  *   (<= what the tile slots hold); 0x600 |NT<<4|MTW: Winograd F(2x2,3x3) form of the persistent 3x3 kernel with 8 waves per
  *   workgroup (Cin % 16 == 0; NT = MTW = 1; TH<<12 = even rows per band), same epilogue fusions; 0xA00 / 0xC00: the same with the
- *   patch read half a chunk at a time, 8 waves (NT in {1,2}, MTW = 1) / 12 waves (NT = MTW = 1); 0x800 / 0x900 / 0xB00 |NT<<4|MTW (round 5,
+ *   patch read half a chunk at a time, 8 waves (NT in {1,2}, MTW = 1) / 12 waves (NT = MTW = 1); 0x800 / 0x900 / 0xB00 / 0xD00 |NT<<4|MTW (round 5,
  *   conv_wino2.hip): the software-pipelined Winograd kernel -- 8 waves with the full-chunk patch (NT = MTW = 1), 8 waves with the
- *   half-chunk patch ((NT, MTW) in {(1,1), (2,1), (1,2)}), 4 waves with 512 registers ((1,2), (2,1)); same results as 0x600 up to the
+ *   half-chunk patch ((NT, MTW) in {(1,1), (2,1), (1,2)}), 4 waves with 512 registers ((1,2), (2,1)), 12 waves with the half-chunk patch (NT = MTW = 1); same results as 0x600 up to the
  *   fp32 summation order, same epilogue fusions (the 8-wave NT = 2 tile refuses bn_z).  bn_sums (nullable,
  *   rv_bn_workspace_bytes(Cout) bytes of fp64 = 8 replicas of [2*Cout] that the consumer adds up, += ): per-channel sum / sum of squares of the written output, i.e. the batch statistics of the
  *   BatchNorm2d that consumes it (conv -> bn call sites, model/UNet_onset.py:196-198,221-223), produced in the conv

@@ -3090,9 +3090,9 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
         *sums_done = true;
         return RV_OK;
     }
-    if (fam == 8 || fam == 9 || fam == 11 || fam == 13) {   // software-pipelined Winograd (conv_wino2.hip): 0x8NM / 0x9NM = 8 waves, full / half-chunk patch; 0xBNM / 0xDNM = 4 waves
+    if (fam == 8 || fam == 9 || fam == 11 || fam == 13) {   // software-pipelined Winograd (conv_wino2.hip): 0x8NM / 0x9NM = 8 waves, full / half-chunk patch; 0xBNM = 4 waves; 0xDNM = 12 waves, half-chunk patch
         if (mode != 0 || R != 4) { rv_set_error("rv_conv_fwd: the Winograd kernel needs a 3x3 conv with Cin %% 16 == 0"); return RV_EUNSUPPORTED; }
-        const int rcw = rv_launch_conv3x3_wino2(a, f_nt, f_mt, (fam == 8 || fam == 9) ? 8 : 4, (fam == 9 || fam == 13) ? 1 : 0, f_th, st);
+        const int rcw = rv_launch_conv3x3_wino2(a, f_nt, f_mt, fam == 13 ? 12 : ((fam == 8 || fam == 9) ? 8 : 4), (fam == 9 || fam == 13) ? 1 : 0, f_th, st);
         if (rcw != RV_OK) { rv_set_error("rv_conv_fwd: forced pipelined Winograd tile NT=%d MTW=%d TH=%d does not fit", f_nt, f_mt, f_th); return rcw; }
         RV_LAUNCH_CHECK("rv_conv_fwd(winograd, pipelined)");
         *sums_done = true;

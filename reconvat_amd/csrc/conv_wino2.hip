@@ -67,7 +67,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wino2_k(ConvLdsArgs aa) {
     // whose byte offset lies outside it gets ZEROS written to its LDS slot (tools/probes/buffer_lds_oob.hip), so the rows above / below the
     // image need no test at all (their offsets wrap below zero / run past the image) and a halo column is an offset bump of 2^30.  Per slot:
     // one vector add and the DMA instruction; per lane one offset register per slot. ----
-    constexpr int TXF = 8;
+    constexpr int TXF = NW == 12 ? 4 : 8;            // (three waves per SIMD leave 168 registers)
     constexpr int NWF = 16 * NT;                         // weight fragments per chunk
     constexpr int TW = (NWF + NW - 1) / NW;
     const int nx = nrow * NP;
@@ -534,6 +534,13 @@ int rv_launch_conv3x3_wino2(const ConvArgs& a0, int NT, int MTW, int nw, int hal
 #endif
     RV_W2(1, 1, 8, false) RV_W2(1, 1, 8, true) RV_W2(2, 1, 8, true) RV_W2(1, 2, 8, true)
     RV_W2(1, 2, 4, false) RV_W2(2, 1, 4, false)
+    if (nw == 12 && a0.bn_z) return RV_EUNSUPPORTED;       // (three waves per SIMD: no room for the fused BatchNorm-backward epilogue)
+    if (NT == 1 && MTW == 1 && nw == 12 && half) {
+        static bool attr12 = false;
+        if (!attr12) { (void)hipFuncSetAttribute((const void*)conv3x3_wino2_k<1, 1, 12, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); attr12 = true; }
+        hipLaunchKernelGGL((conv3x3_wino2_k<1, 1, 12, true, false>), grid, dim3(768), lds, st, aa);
+        return RV_OK;
+    }
 #undef RV_W2
     return RV_EUNSUPPORTED;
 }

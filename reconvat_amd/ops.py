@@ -497,8 +497,8 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
                                 cands += [t << 12 | fam << 8 | nt << 4 | mt for t in ths]
                         if os.environ.get('RV_TUNE_WINO2', '1') != '0':
                             # ... and its software-pipelined form (conv_wino2.hip, round 5): 0x8NM / 0x9NM = 8 waves with the full / half-chunk patch,
-                            # 0xBNM = 4 waves; the taller half of the legal band heights only (short bands lose to their halo)
-                            for fam, nwv, tiles in ((8, 8, ((1, 1),)), (9, 8, ((1, 1), (2, 1), (1, 2))), (11, 4, ((1, 2), (2, 1)))):
+                            # 0xBNM = 4 waves, 0xDNM = 12 waves (half-chunk patch); the taller half of the legal band heights only (short bands lose to their halo)
+                            for fam, nwv, tiles in ((8, 8, ((1, 1),)), (9, 8, ((1, 1), (2, 1), (1, 2))), (11, 4, ((1, 2), (2, 1))), (13, 12, ((1, 1),))):
                                 for nt, mt in tiles:
                                     if ntile_n % nt:
                                         continue

@@ -12,7 +12,7 @@ def test_table_parses_and_is_default():
     for key, algo in conv.items():
         assert len(key) == 10 and key[0] in (0, 1, 2, 3) and key[1] in (1, 8)
         fam, nt, mt, th = (algo >> 8) & 15, (algo >> 4) & 15, algo & 15, algo >> 12
-        assert algo in (0, 1, 2) or (fam in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12) and 1 <= nt <= 4 and 1 <= mt <= 8 and 0 <= th < 256), hex(algo)
+        assert algo in (0, 1, 2) or (fam in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13) and 1 <= nt <= 4 and 1 <= mt <= 8 and 0 <= th < 256), hex(algo)
         if key[0] != 0:
             assert fam in (0, 1, 5), 'only the 3x3 mode has LDS tile families'
     gemm = plans.gemm_entries()

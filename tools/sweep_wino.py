@@ -50,18 +50,18 @@ for cin, cout, h, w in SHAPES:
     res = []
     ntile_n = (cout + 15) // 16
     only_new = os.environ.get('SWEEP_ONLY_NEW') == '1'
-    for fam, nw in ((6, 8), (10, 8), (12, 12), (8, 8), (9, 8), (11, 4)):
+    for fam, nw in ((6, 8), (10, 8), (12, 12), (8, 8), (9, 8), (11, 4), (13, 12)):
         if only_new and fam in (6, 10, 12):
             continue
         for nt, mt in ((1, 1), (2, 1), (1, 2), (2, 2), (1, 4)):
             legal = {6: ((1, 1),), 10: ((1, 1), (2, 1)), 12: ((1, 1),), 8: ((1, 1),), 9: ((1, 1), (2, 1), (1, 2)),
-                     11: ((1, 2), (2, 1))}[fam]
+                     11: ((1, 2), (2, 1)), 13: ((1, 1),)}[fam]
             if ntile_n % nt or (nt, mt) not in legal:
                 continue
             wt_ = (w + 1) // 2
             th_max = min(h, 2 * ((nw * mt * 16) // wt_))
             ths = [0] + [t for t in range(2, th_max, 2) if -(-h // t) != -(-h // (t + 2))]
-            if fam in (8, 9, 11) and os.environ.get('SWEEP_ALL_TH') != '1':
+            if fam in (8, 9, 11, 13) and os.environ.get('SWEEP_ALL_TH') != '1':
                 ths = [0] + [t for t in ths[1:] if t >= th_max // 2]
             for th in ths:
                 algo = th << 12 | fam << 8 | nt << 4 | mt
