@@ -192,3 +192,23 @@ def test_two_models_alternating_in_one_process_match_their_solo_runs(dev, monkey
         assert l1 == l2 and torch.equal(p1, p2), kind                 # two solo runs: identical trajectories
         assert both[kind] == l1, (kind, both[kind], l1)               # interleaved == solo, every loss term of every step
         assert torch.equal(opt.flat_param, p1), (kind, float((opt.flat_param - p1).abs().max()))
+
+
+def test_recapturing_one_step_does_not_run_the_pinned_pools_dry(dev):
+    """a capture pops its pinned host tables from process-wide pools and they go with the graph.  `release()` + a second and third
+    capture of the SAME TrainStep, and two steps built before either captures, must find the pools topped up (TrainStep._top_up_pools at the top
+    of every capture), and every capture must replay to the same losses."""
+    m, opt, step = _small_step(dev, 'onset', 0, n_power=0)
+    m2, opt2, step2 = _small_step(dev, 'frame', 0, n_power=0)         # built before either captures
+    seen = []
+    for _ in range(4):
+        step.capture()
+        step.graph.replay()
+        torch.cuda.synchronize()
+        seen.append({k: float(v) for k, v in step.losses.items()})
+        step.release()
+    assert all(s == seen[0] for s in seen), seen
+    step2()
+    step2()
+    torch.cuda.synchronize()
+    step2.check()
