@@ -24,6 +24,7 @@ ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'search', 'bes
 ap.add_argument('--start', default=os.path.join(ROOT, 'reconvat_amd', 'tuned_plans.json'))
 ap.add_argument('--reps', type=int, default=3)
 ap.add_argument('--margin', type=float, default=0.04)
+ap.add_argument('--skip-conv', action='store_true')
 args = ap.parse_args()
 os.makedirs(os.path.dirname(args.out), exist_ok=True)
 cur = json.load(open(args.start))
@@ -63,7 +64,7 @@ def best_of(variants, label):
     log.append(line)
 
 
-for h in heights:
+for h in ([] if args.skip_conv else heights):
     variants = []
     for name, alt in alts:
         doc = json.loads(json.dumps(cur))
@@ -76,14 +77,28 @@ for h in heights:
             variants.append((name, doc))
     if variants:
         best_of(variants, f'conv H={h}')
+# the weight-gradient partitions, level by level (key: taps,B,Hv,Wv,Ca,Cb), then the GEMM split-K factors as one group
+for h in sorted({group_of(k) for k in cur['wgrad'] if group_of(k) is not None}, reverse=True):
+    variants = []
+    for name, alt in alts:
+        doc = json.loads(json.dumps(cur))
+        changed = 0
+        for k, v in alt['wgrad'].items():
+            if group_of(k) == h and k in doc['wgrad'] and doc['wgrad'][k] != v:
+                doc['wgrad'][k] = v
+                changed += 1
+        if changed:
+            variants.append((name, doc))
+    if variants:
+        best_of(variants, f'wgrad Hv={h}')
 variants = []
 for name, alt in alts:
     doc = json.loads(json.dumps(cur))
-    if alt['wgrad'] != doc['wgrad']:
-        doc['wgrad'] = {k: alt['wgrad'].get(k, v) for k, v in doc['wgrad'].items()}
+    if alt.get('gemm') and alt['gemm'] != doc['gemm']:
+        doc['gemm'] = {k: alt['gemm'].get(k, v) for k, v in doc['gemm'].items()}
         variants.append((name, doc))
 if variants:
-    best_of(variants, 'weight-gradient partitions')
+    best_of(variants, 'GEMM split-K factors')
 cur.setdefault('meta', {})['table_search'] = 'tools/table_search.py: per-level coordinate descent by step time over ' + ', '.join(n for n, _ in alts)
 dump(cur, os.path.splitext(os.path.basename(args.out))[0])
 with open(os.path.splitext(args.out)[0] + '_log.txt', 'w') as fh:
