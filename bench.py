@@ -910,7 +910,19 @@ def main():
                 'families': [{'family': 'convolutions (3x3 / 1x1 / 2x2, fwd + dgrad + wgrad)', 'bound': 'mfma',
                               'ms_per_step': round(conv_ms, 3), 'launches_per_step': nlaunch, 'achieved': round(achieved, 2),
                               'unit': 'TFLOP/s', 'peak': MFMA_F32_PEAK_TFLOPS, 'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
-                              'work_per_step': round(conv_flops_total / 1e9, 1), 'work_unit': 'GFLOP'}] + families,
+                              'work_per_step': round(conv_flops_total / 1e9, 1), 'work_unit': 'GFLOP'},
+                             # the same launches split by which roof is the lower one
+                             {'family': 'conv launches whose AI x HBM roof is the lower one (1x1, 2x2, C <= 2, 16-channel 3x3)', 'bound': 'hbm',
+                              'ms_per_step': round(bound['split']['hbm_bound'][0], 3), 'launches_per_step': bound['split']['hbm_bound'][3],
+                              'achieved': round(bound['split']['hbm_bound'][2] / max(bound['split']['hbm_bound'][0], 1e-9) / 1e9, 3), 'unit': 'TB/s', 'peak': HBM_PEAK_TBS,
+                              'frac': round(bound['split']['hbm_bound'][2] / max(bound['split']['hbm_bound'][0], 1e-9) / 1e9 / HBM_PEAK_TBS, 4),
+                              'work_per_step': round(bound['split']['hbm_bound'][2] / 1e9, 2), 'work_unit': 'GB (algorithmic)', 'subset_of': 'convolutions'},
+                             {'family': 'conv launches whose MFMA roof is the lower one', 'bound': 'mfma',
+                              'ms_per_step': round(bound['split']['mfma_bound'][0], 3), 'launches_per_step': bound['split']['mfma_bound'][3],
+                              'achieved': round(bound['split']['mfma_bound'][1] / max(bound['split']['mfma_bound'][0], 1e-9) / 1e9, 2), 'unit': 'TFLOP/s',
+                              'peak': MFMA_F32_PEAK_TFLOPS,
+                              'frac': round(bound['split']['mfma_bound'][1] / max(bound['split']['mfma_bound'][0], 1e-9) / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
+                              'work_per_step': round(bound['split']['mfma_bound'][1] / 1e9, 1), 'work_unit': 'GFLOP', 'subset_of': 'convolutions'}] + families,
             }
             line['deterministic_ms_per_step'] = deterministic_leg(args, device)
             line['dp_seam'] = dp_seam_leg(step, args, device)
