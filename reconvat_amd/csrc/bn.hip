@@ -291,10 +291,11 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
 // resident rounds of 8 per CU) paid the per-workgroup prologue (replica fold, fp64 coefficient math) twelve times per CU and left the
 // second round half empty: 3072 -> 1023 is -0.2 ms per step in situ (2046 / 1536 / 1023 / 768 within noise of each other, 510 and
 // 255 slower again: too few loads in flight).  The backward form (two input streams) likes 768 best: 1023 / 768 / 639 / 510 =
-// 22.29 / 22.19 / 22.24 / 22.30 ms per step.  RV_BN_MAXBLK / RV_BN_MAXBLK_BWD override (tuning only).
+// 22.29 / 22.19 / 22.24 / 22.30 ms per step.  Round 5, with the re-tuned conv table, the forward form likes 768 / 639 better than 1023 as well
+// (tools/knob_ab.sh, 6 interleaved runs each: 21.43 / 21.43 vs 21.52 ms; 510: 21.52) -> 768 for both.  RV_BN_MAXBLK / RV_BN_MAXBLK_BWD override (tuning only).
 static int bn_apply_blocks(long total, bool bwd = false) {
     long b = (total + 255) / 256;
-    static const long capf = getenv("RV_BN_MAXBLK") ? atol(getenv("RV_BN_MAXBLK")) : 1023;
+    static const long capf = getenv("RV_BN_MAXBLK") ? atol(getenv("RV_BN_MAXBLK")) : 768;
     static const long capb = getenv("RV_BN_MAXBLK_BWD") ? atol(getenv("RV_BN_MAXBLK_BWD")) : 768;
     const long cap = bwd ? capb : capf;
     if (b > cap) b = cap;
