@@ -805,6 +805,14 @@ def _out_hw(kind, h, w, size):
     return h, w
 
 
+# A conv layer's weight gradient is launched BEFORE its input gradient in the backward (RV_WGRAD_FIRST=0: the other way round).  The input
+# gradient is the one the next layer's backward waits for, so "input gradient first" looks right -- measured in situ it is the slower order
+# (tools/knob_ab.sh, round 5: 21.30 vs 21.48 ms/step): both kernels read dY, and the weight-gradient kernel's single pass over X and dY leaves
+# dY in the cache hierarchy for the input-gradient kernel that follows, whose output the next layer then finds warm.  Results are unaffected.
+WGRAD_FIRST = [os.environ.get('RV_WGRAD_FIRST', '1') != '0']
+_WGRAD_FIRST_UPCAT = os.environ.get('RV_WGRAD_FIRST_UPCAT', '1') != '0'      # (the decoder's up-conv + skip-conv pair follows the same order)
+
+
 class ConvFn(Function):
     """y = conv(x) for any of the five conv kinds (new contiguous NHWC tensor)."""
 
@@ -833,7 +841,11 @@ class ConvFn(Function):
         dy = dy.contiguous()
         dx = dw = db = None
         bf = BF16['bwd'] and ctx.live
-        if ctx.needs_input_grad[0]:
+
+        def input_grad():
+            nonlocal dx
+            if not ctx.needs_input_grad[0]:
+                return
             if ctx.share is not None and ctx.bn_in is None:
                 dx = ctx.share.dgrad(ctx.kind, dy, w, ctx.xshape, bf16=bf)
             else:
@@ -844,13 +856,20 @@ class ConvFn(Function):
                 conv_dgrad_into(ctx.kind, dy, w, dx, ctx.bn_in, bf16=bf, sum_ws=sum_ws)
                 if sum_ws is not None:
                     ctx.dx_colsum.sums, ctx.dx_colsum.c = sum_ws, ctx.xshape[3]
-        if ctx.needs_input_grad[1]:
+
+        def weight_grad():
+            nonlocal dw, db
+            if not ctx.needs_input_grad[1]:
+                return
             pw, pb = ctx.params
             gw, gb = _grad_buf(pw), _grad_buf(pb)
             if gw is not None and (gb is not None or not ctx.needs_input_grad[2]):
                 conv_wgrad(ctx.kind, x, dy, w, ctx.needs_input_grad[2], gw, gb, bf16=bf, colsum=ctx.dy_colsum)
             else:
                 dw, db = conv_wgrad(ctx.kind, x, dy, w, ctx.needs_input_grad[2], bf16=bf, colsum=ctx.dy_colsum)
+        # launch order: see WGRAD_FIRST
+        for part in ((weight_grad, input_grad) if WGRAD_FIRST[0] else (input_grad, weight_grad)):
+            part()
         if ctx.dy_colsum is not None:
             ctx.dy_colsum.sums = None            # drop the reference
         return dx, dw, db, None, None, None, None, None, None, None
@@ -887,30 +906,38 @@ class UpCatFn(Function):
         cu = ctx.cu
         d_up, d_sk = dcat[..., :cu], dcat[..., cu:]
         dx = ds = dwu = dbu = dws = dbs = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty(ctx.shapes[0], device=dcat.device, dtype=torch.float32)
-            conv_dgrad_into('up', d_up, w_up, dx)
-        if ctx.needs_input_grad[3]:
-            bf = BF16['bwd'] and ctx.live
-            if ctx.share is not None:
-                ds = ctx.share.dgrad('c3', d_sk, w_skip, ctx.shapes[1], bf16=bf)
-            else:
-                ds = torch.empty(ctx.shapes[1], device=dcat.device, dtype=torch.float32)
-                conv_dgrad_into('c3', d_sk, w_skip, ds, bf16=bf)
         pwu, pbu, pws, pbs = ctx.params
-        if ctx.needs_input_grad[1]:
-            gw, gb = _grad_buf(pwu), _grad_buf(pbu)
-            if gw is not None and gb is not None:
-                conv_wgrad('up', x, d_up, w_up, True, gw, gb, colsum=ctx.dy_colsum)
-            else:
-                dwu, dbu = conv_wgrad('up', x, d_up, w_up, True, colsum=ctx.dy_colsum)
-        if ctx.needs_input_grad[4]:
-            gw, gb = _grad_buf(pws), _grad_buf(pbs)
-            bfw = BF16['bwd'] and ctx.live
-            if gw is not None and gb is not None:
-                conv_wgrad('c3', s, d_sk, w_skip, True, gw, gb, bf16=bfw)
-            else:
-                dws, dbs = conv_wgrad('c3', s, d_sk, w_skip, True, bf16=bfw)
+
+        def input_grads():
+            nonlocal dx, ds
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty(ctx.shapes[0], device=dcat.device, dtype=torch.float32)
+                conv_dgrad_into('up', d_up, w_up, dx)
+            if ctx.needs_input_grad[3]:
+                bf = BF16['bwd'] and ctx.live
+                if ctx.share is not None:
+                    ds = ctx.share.dgrad('c3', d_sk, w_skip, ctx.shapes[1], bf16=bf)
+                else:
+                    ds = torch.empty(ctx.shapes[1], device=dcat.device, dtype=torch.float32)
+                    conv_dgrad_into('c3', d_sk, w_skip, ds, bf16=bf)
+
+        def weight_grads():
+            nonlocal dwu, dbu, dws, dbs
+            if ctx.needs_input_grad[1]:
+                gw, gb = _grad_buf(pwu), _grad_buf(pbu)
+                if gw is not None and gb is not None:
+                    conv_wgrad('up', x, d_up, w_up, True, gw, gb, colsum=ctx.dy_colsum)
+                else:
+                    dwu, dbu = conv_wgrad('up', x, d_up, w_up, True, colsum=ctx.dy_colsum)
+            if ctx.needs_input_grad[4]:
+                gw, gb = _grad_buf(pws), _grad_buf(pbs)
+                bfw = BF16['bwd'] and ctx.live
+                if gw is not None and gb is not None:
+                    conv_wgrad('c3', s, d_sk, w_skip, True, gw, gb, bf16=bfw)
+                else:
+                    dws, dbs = conv_wgrad('c3', s, d_sk, w_skip, True, bf16=bfw)
+        for part in ((weight_grads, input_grads) if (WGRAD_FIRST[0] and _WGRAD_FIRST_UPCAT) else (input_grads, weight_grads)):
+            part()
         if ctx.dy_colsum is not None:
             ctx.dy_colsum.sums = None
         return dx, dwu, dbu, ds, dws, dbs, None, None, None
