@@ -122,9 +122,10 @@ int rv_bn_lrelu_bwd(const float* dy, int dy_ld, const float* z, int z_ld, long P
  * 292-293,307-313,324,330): C[m*scm+n*scn] (+)= act(sum_k A[m*sam+k*sak]*B[k*sbk+n*sbn] + bias[n]);
  * splitk > 1: the reduction is split over workgroups; splitk_ws == NULL: fp32 atomic accumulation (arrival-order rounding; act 0,
  * no C2; the parameter-gradient GEMMs); splitk_ws != NULL: DETERMINISTICALLY -- every k slice parks its partial tile in splitk_ws
- * (rv_gemm_splitk_workspace_bytes, uninitialised), the last slice of a tile to arrive (splitk_tickets:
- * rv_gemm_splitk_ticket_bytes, ZERO on entry, left zero) folds them in k order and runs the epilogue, so the result does not
- * depend on arrival order and no atomics touch C; batch > 1: problem z of `batch` equal-shape problems lives at A + z*bsa,
+ * (rv_gemm_splitk_workspace_bytes, uninitialised) and a second launch on the same stream adds the slices in k order and runs the
+ * epilogue, so the result does not depend on arrival order and no atomics touch C (splitk_tickets: unused since round 5, may be
+ * NULL; rv_gemm_splitk_ticket_bytes returns 0 -- the in-kernel ticketed fold it served needed device-scope fences that cost
+ * ~30 us per slice on this multi-XCD part); batch > 1: problem z of `batch` equal-shape problems lives at A + z*bsa,
  * B + z*bsb, C + z*bsc (the per-head relative-position gradient of the attention).  a_rowsum (nullable, batch == 1):
  * a_rowsum[m] += sum_k A[m][k] (k slices folded in order): the bias gradient of a linear layer rides on its weight-gradient
  * GEMM (A = dY^T). */

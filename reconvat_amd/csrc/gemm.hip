@@ -32,10 +32,10 @@ struct GemmArgs {
     int M, N, K;
     int act;            // 0 none, 1 sigmoid
     int accumulate;     // C += (plain read-modify-write; requires splitk == 1)
-    int splitk;         // >1: K split over blockIdx.z; partial tiles go to `part`, the LAST block of a tile to arrive (ticket) folds
-                        // them in k order and runs the epilogue: deterministic, no atomics on C
+    int splitk;         // >1: K split over blockIdx.z; with `part` the partial tiles are parked there and gemm_fold_k adds them in k order and
+                        // runs the epilogue: deterministic, no atomics on C
     float* part;        // [batch][splitk][tiles][4][256] f32x4 slots (accumulator layout), uninitialised
-    int* tickets;       // [batch][tiles] zero on entry, left zero on exit
+    int* tickets;       // (unused since round 5)
     float* rs_part;     // [splitk][M] partial row sums of A (a_rowsum with splitk > 1)
     int a_vec, b_vec;   // 16-byte loads along the contiguous dimension are legal
     int batch;          // independent problems over blockIdx.z / splitk: A += z*bsa, B += z*bsb, C += z*bsc
@@ -95,6 +95,46 @@ struct TileIO {
     }
 };
 
+// Epilogue of one 64 x 64 tile: bias, activation, (accumulating / atomic / two-destination) stores.  acc[n-tile][m-tile] in the MFMA layout of
+// gemm_tile (a lane holds four consecutive n of one m).
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[2][2], const int m0, const int n0, const int wm, const int wn,
+                                              const int li, const int g, const int kz) {
+    const bool atomic_k = (a.splitk > 1 && !a.part) || a.atomic_out;     // atomic split-K (parameter gradients: order-dependent rounding is acceptable)
+    const bool vec_ok = a.scn == 1 && !a.C2 && !atomic_k;                  // (rows need not be 16-byte aligned: f32x4u)
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int m = m0 + wm + y * 16 + li;
+            const int nb = n0 + wn + x * 16 + 4 * g;
+            if (m >= a.M || nb >= a.N) continue;
+            f32x4 v = acc[x][y];
+            if (a.bias && (!(a.splitk > 1 && !a.part) || kz == 0)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (nb + r < a.N) v[r] += a.bias[nb + r];
+            }
+            if (a.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = 1.f / (1.f + __expf(-v[r]));
+            }
+            float* c = a.C + (long)m * a.scm + (long)nb * a.scn;
+            if (vec_ok && nb + 3 < a.N) {
+                if (a.accumulate) { f32x4 o = *reinterpret_cast<f32x4u*>(c); v += o; }
+                *reinterpret_cast<f32x4u*>(c) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (nb + r >= a.N) continue;
+                    float* cc = c + (long)r * a.scn;
+                    if (atomic_k) { atomicAdd(cc, v[r]); continue; }
+                    *cc = a.accumulate ? *cc + v[r] : v[r];
+                    if (a.C2) a.C2[(long)m * a.sc2m + (long)(nb + r) * a.sc2n] = v[r];
+                }
+            }
+        }
+}
+
 // One 64 x 64 output tile of one problem: (bx, by) = tile, bzi = batch index * splitk + k slice, (gdx, gdy) = tiles of the problem.
 template <bool AK, bool BK_>
 __device__ __forceinline__ void gemm_tile(GemmArgs a, const int bx, const int by, const int bzi, const int gdx, const int gdy) {
@@ -153,8 +193,9 @@ __device__ __forceinline__ void gemm_tile(GemmArgs a, const int bx, const int by
     }
 
     if (a.splitk > 1 && a.part) {
-        // deterministic split-K: park this slice's accumulators, take a ticket; the last slice of the tile to arrive folds all
-        // slices in k order (whoever it is, the summation order is the same) and runs the epilogue
+        // deterministic split-K, first half: park this slice's accumulators (and its share of the row sums); gemm_fold_k adds the slices in
+        // k order and runs the epilogue.  (Until round 5 the last slice of a tile to arrive -- a ticket -- folded them inside this kernel; the
+        // device-scope fences that needs cost ~30 us per slice on this multi-XCD part: sk = 2 was 1.7x SLOWER than sk = 1.)
         const int ntiles = gdx * gdy, tile = by * gdx + bx;
         f32x4* mine = reinterpret_cast<f32x4*>(a.part) + (((long)bz * a.splitk + kz) * ntiles + tile) * (4 * 256);
 #pragma unroll
@@ -162,77 +203,52 @@ __device__ __forceinline__ void gemm_tile(GemmArgs a, const int bx, const int by
 #pragma unroll
             for (int y = 0; y < 2; ++y) mine[(x * 2 + y) * 256 + tid] = acc[x][y];
         if (a.a_rowsum && bx == 0 && tid < GBM && m0 + tid < a.M) a.rs_part[(long)kz * a.M + m0 + tid] = rowsum;
-        __threadfence();
-        __shared__ int last;
-        __syncthreads();
-        if (tid == 0) last = (atomicAdd(&a.tickets[bz * ntiles + tile], 1) == a.splitk - 1);
-        __syncthreads();
-        if (!last) return;
-        __threadfence();
-        if (tid == 0) a.tickets[bz * ntiles + tile] = 0;                 // self-clearing: the buffer may serve the next launch
-        const f32x4* all = reinterpret_cast<const f32x4*>(a.part) + ((long)bz * a.splitk * ntiles + tile) * (4 * 256) + tid;
-        const long zs = (long)ntiles * (4 * 256);
-        // slices are added in k order; the loads of four slices x four fragments (16 independent 16-byte loads) are in flight together
-        for (int z0 = 0; z0 < a.splitk; z0 += 4) {
-            f32x4 v[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    v[j][q] = (z0 + j < a.splitk) ? __builtin_nontemporal_load(all + (long)(z0 + j) * zs + q * 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (z0 + j >= a.splitk) break;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (z0 + j == 0) acc[q >> 1][q & 1] = v[j][q];
-                    else acc[q >> 1][q & 1] += v[j][q];
-                }
-            }
-        }
-        if (a.a_rowsum && bx == 0 && tid < GBM && m0 + tid < a.M) {
-            float r = a.rs_part[m0 + tid];
-            for (int z = 1; z < a.splitk; ++z) r += a.rs_part[(long)z * a.M + m0 + tid];
-            a.a_rowsum[m0 + tid] += r;
-        }
-    } else if (a.a_rowsum && bx == 0 && tid < GBM && m0 + tid < a.M) {
+        return;
+    }
+    if (a.a_rowsum && bx == 0 && tid < GBM && m0 + tid < a.M) {
         if (a.splitk > 1 || a.atomic_out) atomicAdd(&a.a_rowsum[m0 + tid], rowsum);
         else a.a_rowsum[m0 + tid] += rowsum;                             // one workgroup per row block: plain read-modify-write
     }
-    const bool atomic_k = (a.splitk > 1 && !a.part) || a.atomic_out;     // atomic split-K (parameter gradients: order-dependent rounding is acceptable)
-    const bool vec_ok = a.scn == 1 && !a.C2 && !atomic_k;                  // (rows need not be 16-byte aligned: f32x4u)
+    gemm_epilogue(a, acc, m0, n0, wm, wn, li, g, kz);
+}
+
+// Second half of the deterministic split-K: one workgroup per output tile adds the parked slices IN k ORDER (whichever order they were
+// written in, the summation order is the same) and runs the ordinary epilogue (bias, act, accumulate, C2; the row sums of A likewise).
+__global__ __launch_bounds__(256) void gemm_fold_k(GemmArgs a) {
+    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z, gdx = gridDim.x, gdy = gridDim.y;
+    a.C += (long)bz * a.bsc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int m0 = by * GBM, n0 = bx * GBN;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int ntiles = gdx * gdy, tile = by * gdx + bx;
+    const f32x4* all = reinterpret_cast<const f32x4*>(a.part) + ((long)bz * a.splitk * ntiles + tile) * (4 * 256) + tid;
+    const long zs = (long)ntiles * (4 * 256);
+    f32x4 acc[2][2];
+    // the loads of four slices x four fragments (16 independent 16-byte loads) are in flight together
+    for (int z0 = 0; z0 < a.splitk; z0 += 4) {
+        f32x4 v[4][4];
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int y = 0; y < 2; ++y) {
-            const int m = m0 + wm + y * 16 + li;
-            const int nb = n0 + wn + x * 16 + 4 * g;
-            if (m >= a.M || nb >= a.N) continue;
-            f32x4 v = acc[x][y];
-            if (a.bias && (!(a.splitk > 1 && !a.part) || kz == 0)) {
+            for (int q = 0; q < 4; ++q)
+                v[j][q] = (z0 + j < a.splitk) ? __builtin_nontemporal_load(all + (long)(z0 + j) * zs + q * 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (nb + r < a.N) v[r] += a.bias[nb + r];
-            }
-            if (a.act == 1) {
+        for (int j = 0; j < 4; ++j) {
+            if (z0 + j >= a.splitk) break;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = 1.f / (1.f + __expf(-v[r]));
-            }
-            float* c = a.C + (long)m * a.scm + (long)nb * a.scn;
-            if (vec_ok && nb + 3 < a.N) {
-                if (a.accumulate) { f32x4 o = *reinterpret_cast<f32x4u*>(c); v += o; }
-                *reinterpret_cast<f32x4u*>(c) = v;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (nb + r >= a.N) continue;
-                    float* cc = c + (long)r * a.scn;
-                    if (atomic_k) { atomicAdd(cc, v[r]); continue; }
-                    *cc = a.accumulate ? *cc + v[r] : v[r];
-                    if (a.C2) a.C2[(long)m * a.sc2m + (long)(nb + r) * a.sc2n] = v[r];
-                }
+            for (int q = 0; q < 4; ++q) {
+                if (z0 + j == 0) acc[q >> 1][q & 1] = v[j][q];
+                else acc[q >> 1][q & 1] += v[j][q];
             }
         }
+    }
+    if (a.a_rowsum && bx == 0 && tid < GBM && m0 + tid < a.M) {
+        float r = a.rs_part[m0 + tid];
+        for (int z = 1; z < a.splitk; ++z) r += a.rs_part[(long)z * a.M + m0 + tid];
+        a.a_rowsum[m0 + tid] += r;
+    }
+    gemm_epilogue(a, acc, m0, n0, wm, wn, li, g, 0);
 }
 
 template <bool AK, bool BK_>
@@ -266,10 +282,11 @@ extern "C" {
 // C[m*scm + n*scn] (+)= act(sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] + bias[n]);  act: 0 none, 1 sigmoid.
 // splitk > 1 splits the reduction over extra workgroups.  With splitk_ws == NULL the slices accumulate by fp32 atomics (C zeroed
 // first unless accumulate; act must be 0, C2 null; rounding depends on arrival order -- used for parameter gradients).  With
-// splitk_ws the split is DETERMINISTIC: every k slice parks its partial tile in
-// `splitk_ws` (rv_gemm_splitk_workspace_bytes, uninitialised) and the last slice of a tile to arrive -- ticket in
-// `splitk_tickets` (rv_gemm_splitk_ticket_bytes, ZERO on entry, left zero) -- folds them in k order and runs the ordinary
-// epilogue (bias, act, accumulate, C2 all allowed): results do not depend on the arrival order, no atomics touch C.
+// splitk_ws the split is DETERMINISTIC: every k slice parks its partial tile in `splitk_ws` (rv_gemm_splitk_workspace_bytes,
+// uninitialised) and a second launch (gemm_fold_k, same stream) adds the slices in k order and runs the ordinary epilogue (bias, act,
+// accumulate, C2 all allowed): results do not depend on the arrival order, no atomics touch C.  `splitk_tickets` is unused since
+// round 5 (may be NULL; rv_gemm_splitk_ticket_bytes returns 0): the in-kernel ticketed fold it served needed device-scope fences
+// that cost more than the second launch.
 // C2 (nullable) receives a second copy with its own strides.
 // batch > 1: `batch` independent problems of the same shape, problem z at A + z*bsa, B + z*bsb, C + z*bsc (C2 must be null).
 // a_rowsum (nullable, batch == 1): a_rowsum[m] += sum_k A[m][k] -- the bias gradient of a linear layer for free on its
@@ -279,8 +296,8 @@ long rv_gemm_splitk_workspace_bytes(int M, int N, int splitk, int batch) {
     return ((long)batch * splitk * cdiv(M, GBM) * cdiv(N, GBN) * (4 * 256 * 16)) + (long)splitk * M * 4;
 }
 long rv_gemm_splitk_ticket_bytes(int M, int N, int splitk, int batch) {
-    if (splitk <= 1) return 0;
-    return (long)batch * cdiv(M, GBM) * cdiv(N, GBN) * 4;
+    (void)M; (void)N; (void)splitk; (void)batch;
+    return 0;
 }
 
 static int gemm_args_make(GemmArgs& a, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm, long scn,
@@ -290,7 +307,6 @@ static int gemm_args_make(GemmArgs& a, const float* A, long sam, long sak, const
     RV_CHECK_ARG(!a_rowsum || batch == 1, "rv_gemm: a_rowsum excludes batch");
     RV_CHECK_ARG(splitk >= 1, "rv_gemm: splitk must be >= 1");
     RV_CHECK_ARG(batch >= 1 && (batch == 1 || !C2) && (long)batch * splitk < 65536, "rv_gemm: bad batch %d", batch);
-    if (splitk > 1 && splitk_ws) RV_CHECK_ARG(splitk_tickets, "rv_gemm: deterministic split-K needs zeroed tickets");
     if (splitk > 1 && !splitk_ws) RV_CHECK_ARG(act == 0 && !C2, "rv_gemm: atomic split-K excludes act/C2");
     a.A = A; a.sam = sam; a.sak = sak; a.B = B; a.sbk = sbk; a.sbn = sbn; a.C = C; a.scm = scm; a.scn = scn;
     a.C2 = C2; a.sc2m = sc2m; a.sc2n = sc2n; a.bias = bias; a.M = M; a.N = N; a.K = K; a.act = act;
@@ -326,6 +342,10 @@ int rv_gemm(const float* A, long sam, long sak, const float* B, long sbk, long s
     else if (!a_kfast && b_kfast) hipLaunchKernelGGL((gemm_mfma_k<false, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((gemm_mfma_k<false, false>), grid, dim3(256), 0, st, a);
     RV_LAUNCH_CHECK("rv_gemm");
+    if (splitk > 1 && splitk_ws) {
+        hipLaunchKernelGGL(gemm_fold_k, dim3(cdiv(N, GBN), cdiv(M, GBM), batch), dim3(256), 0, st, a);
+        RV_LAUNCH_CHECK("rv_gemm(fold)");
+    }
     return RV_OK;
 }
 

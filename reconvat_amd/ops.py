@@ -24,7 +24,7 @@ _EPOCH = [0]
 # default are the folds onto the gradient bucket: the table-driven weight-gradient reductions (several passes of a step target the same
 # layer: fp32 atomics), the atomic split-K of the parameter-gradient GEMMs with the bias row sums riding on them, the column-sum bias
 # gradients.  In this mode the weight-gradient reductions run per layer in stream order (fixed tree, read-modify-write), the
-# parameter-gradient GEMMs use the ticketed in-order split-K of the data path, column sums the two-pass ordered form.  Slower (see
+# parameter-gradient GEMMs use the in-order (park + fold) split-K of the data path, column sums the two-pass ordered form.  Slower (see
 # `deterministic_ms_per_step` in bench.py's line); the default stays the atomic folds.
 DETERMINISTIC = [os.environ.get('RV_DETERMINISTIC') == '1']
 _DIRECT = [False]
@@ -1077,9 +1077,8 @@ def gemm(a, b_kn, c, bias=None, act=0, accumulate=False, splitk=None, c2=None, b
     def launch(s, pc_=pc, rs=ptr(a_rowsum), raise_=True):
         ws = tk = None
         if s > 1 and deterministic:
-            # deterministic split-K: partial tiles are parked in `ws`, the last k slice of a tile (zeroed ticket word) folds them in order
+            # deterministic split-K: partial tiles are parked in `ws`, a second launch folds them in k order and runs the epilogue
             ws = torch.empty(lib.rv_gemm_splitk_workspace_bytes(m, n, s, batch) // 4, device=c.device, dtype=torch.float32)
-            tk = ARENA.take((lib.rv_gemm_splitk_ticket_bytes(m, n, s, batch) + 7) // 8, c.device)
         call('rv_gemm', pa, sam, sak, pb, sbk, sbn, pc_, scm, scn, pc2, s2m, s2n, ptr(bias), m, n, k, act,
              1 if accumulate else 0, s, batch, bstrides[0], bstrides[1], bstrides[2], rs, ptr(ws), ptr(tk), stream())
 
@@ -1446,12 +1445,17 @@ class LocalAttnFn(Function):
 # --------------------------------------------------------------------------------------------
 # losses and VAT primitives
 # --------------------------------------------------------------------------------------------
+_LOSS_TICKET = os.environ.get('RV_LOSS_TICKET') == '1'
+
+
 def _reduce(kind, p, t):
     need_gpu(p, t)
     n = p.numel()
     out = torch.empty((), device=p.device, dtype=torch.float32)
     ws = torch.empty((n + 2047) // 2048, device=p.device, dtype=torch.float32)
-    ticket = ARENA.take(1, p.device)          # zeroed word (fp64 slot): single-launch reduction
+    # two launches (partials, then the fp64 fold): the single-launch form (RV_LOSS_TICKET=1: the last workgroup to arrive folds) needs
+    # device-scope fences, which cost more than the second launch on this multi-XCD part (21.02 vs 21.13 ms/step in situ, round 5)
+    ticket = ARENA.take(1, p.device) if _LOSS_TICKET else None
     call('rv_reduce_mean', kind, ptr(p), ptr(t), n, ptr(out), ptr(ws), ptr(ticket), stream())
     return out
 
