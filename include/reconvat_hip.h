@@ -136,13 +136,16 @@ int rv_gemm(const float* A, long sam, long sak, const float* B, long sbk, long s
             long bsa, long bsb, long bsc, float* a_rowsum, void* splitk_ws, void* splitk_tickets, void* stream);
 /* grouped launch of independent ACCUMULATING problems of one operand orientation (the parameter-gradient GEMMs of a backward
  * pass, each too small to fill the chip): fill HOST entries (returns the orientation code, <0 on error), finalize (returns the
- * total workgroup count), copy the table to the device, run.  Split-K inside a table is the atomic kind. */
+ * total workgroup count; *fold_blocks <- that of the fold launch), copy the table to the device, run.  The problems ADD into their
+ * destinations (two entries may share one): final adds are fp32 atomics.  Split-K inside a table: with a per-entry workspace
+ * (rv_gemm_splitk_workspace_bytes) the k slices are parked and a second grouped launch folds them in k order -- one atomic per
+ * output element; splitk_ws == NULL: every slice adds atomically. */
 long rv_gemm_table_entry_bytes(void);
 long rv_gemm_table_fill(void* entry_host, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm,
                         long scn, const float* bias, int M, int N, int K, int splitk, int batch, long bsa, long bsb, long bsc,
-                        float* a_rowsum);
-long rv_gemm_table_finalize(void* table_host, int count);
-int rv_gemm_table_run(const void* table_dev, int count, long total_blocks, int orientation, void* stream);
+                        float* a_rowsum, void* splitk_ws);
+long rv_gemm_table_finalize(void* table_host, int count, long* fold_blocks);
+int rv_gemm_table_run(const void* table_dev, int count, long total_blocks, long fold_blocks, int orientation, void* stream);
 int rv_sigmoid_bwd(const float* g1, int ld1, const float* g2, int ld2, const float* y, int ldy, float* dz, int ldz, long M,
                    int N, void* stream);
 int rv_colsum(const float* x, int ld, long M, int N, float* out, int accumulate, void* stream);

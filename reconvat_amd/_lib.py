@@ -45,9 +45,9 @@ SIGNATURES = {
     'rv_gemm_splitk_ticket_bytes': (L, [I, I, I, I]),
     'rv_gemm': (I, [P, L, L, P, L, L, P, L, L, P, L, L, P, I, I, I, I, I, I, I, L, L, L, P, P, P, P]),
     'rv_gemm_table_entry_bytes': (L, []),
-    'rv_gemm_table_fill': (L, [P, P, L, L, P, L, L, P, L, L, P, I, I, I, I, I, L, L, L, P]),
-    'rv_gemm_table_finalize': (L, [P, I]),
-    'rv_gemm_table_run': (I, [P, I, L, I, P]),
+    'rv_gemm_table_fill': (L, [P, P, L, L, P, L, L, P, L, L, P, I, I, I, I, I, L, L, L, P, P]),
+    'rv_gemm_table_finalize': (L, [P, I, P]),
+    'rv_gemm_table_run': (I, [P, I, L, L, I, P]),
     'rv_sigmoid_bwd': (I, [P, I, P, I, P, I, P, I, L, I, P]),
     'rv_colsum': (I, [P, I, L, I, P, I, P]),
     'rv_colsum_ordered_workspace_bytes': (L, [L, I]),

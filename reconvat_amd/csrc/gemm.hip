@@ -212,10 +212,9 @@ __device__ __forceinline__ void gemm_tile(GemmArgs a, const int bx, const int by
     gemm_epilogue(a, acc, m0, n0, wm, wn, li, g, kz);
 }
 
-// Second half of the deterministic split-K: one workgroup per output tile adds the parked slices IN k ORDER (whichever order they were
-// written in, the summation order is the same) and runs the ordinary epilogue (bias, act, accumulate, C2; the row sums of A likewise).
-__global__ __launch_bounds__(256) void gemm_fold_k(GemmArgs a) {
-    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z, gdx = gridDim.x, gdy = gridDim.y;
+// Second half of the split-K: one workgroup per output tile adds the parked slices IN k ORDER (whichever order they were written in, the
+// summation order is the same) and runs the ordinary epilogue (bias, act, accumulate, C2; the row sums of A likewise).
+__device__ __forceinline__ void gemm_fold_tile(GemmArgs a, const int bx, const int by, const int bz, const int gdx, const int gdy) {
     a.C += (long)bz * a.bsc;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
@@ -246,9 +245,14 @@ __global__ __launch_bounds__(256) void gemm_fold_k(GemmArgs a) {
     if (a.a_rowsum && bx == 0 && tid < GBM && m0 + tid < a.M) {
         float r = a.rs_part[m0 + tid];
         for (int z = 1; z < a.splitk; ++z) r += a.rs_part[(long)z * a.M + m0 + tid];
-        a.a_rowsum[m0 + tid] += r;
+        if (a.atomic_out) atomicAdd(&a.a_rowsum[m0 + tid], r);
+        else a.a_rowsum[m0 + tid] += r;
     }
     gemm_epilogue(a, acc, m0, n0, wm, wn, li, g, 0);
+}
+
+__global__ __launch_bounds__(256) void gemm_fold_k(GemmArgs a) {
+    gemm_fold_tile(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
 }
 
 template <bool AK, bool BK_>
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a) {
 // Grouped launch: a device table of independent problems (all of the same operand orientation), one 1-D grid over the tiles of
 // all of them.  The parameter-gradient GEMMs of a backward pass (M or N of 31 .. 229, K = B*T = 5120: a few dozen workgroups
 // each, latency-bound alone) then run side by side in ONE launch instead of one under-filled launch each.
-struct GemmEntry { GemmArgs a; int block0, gx, gy, pad; };
+struct GemmEntry { GemmArgs a; int block0, gx, gy, fold0; };     // fold0: prefix of the fold workgroups (tiles x batch of the entries that park)
 template <bool AK, bool BK_>
 __global__ __launch_bounds__(256) void gemm_table_k(const GemmEntry* tab, int count) {
     int e = 0;
@@ -268,6 +272,16 @@ __global__ __launch_bounds__(256) void gemm_table_k(const GemmEntry* tab, int co
     const int local = blockIdx.x - t.block0;
     const int bx = local % t.gx, rest = local / t.gx;
     gemm_tile<AK, BK_>(t.a, bx, rest % t.gy, rest / t.gy, t.gx, t.gy);
+}
+
+// The folds of a grouped launch's parked entries, as one more 1-D grid (entries that do not park own no workgroups here).
+__global__ __launch_bounds__(256) void gemm_table_fold_k(const GemmEntry* tab, int count) {
+    int e = 0;
+    while (e + 1 < count && (int)blockIdx.x >= tab[e + 1].fold0) ++e;
+    const GemmEntry& t = tab[e];
+    const int local = blockIdx.x - t.fold0;
+    const int bx = local % t.gx, rest = local / t.gx;
+    gemm_fold_tile(t.a, bx, rest % t.gy, rest / t.gy, t.gx, t.gy);
 }
 
 __global__ void zero_strided_k(float* c, long scm, long scn, int M, int N) {
@@ -349,34 +363,45 @@ int rv_gemm(const float* A, long sam, long sak, const float* B, long sbk, long s
     return RV_OK;
 }
 
-// Grouped form (see gemm_table_k): fill HOST entries one by one with the arguments of rv_gemm -- accumulate must be 1 and split-K
-// is the atomic kind (the problems ADD into their destinations: gradient accumulation), all entries of one table must have the
-// same operand orientation (rv_gemm_table_fill returns it: bit 0 = A k-fast, bit 1 = B k-fast; negative = error) --, finalize
-// (prefix sums of the workgroup counts; returns the total), copy the table to the device and run it.
+// Grouped form (see gemm_table_k): fill HOST entries one by one with the arguments of rv_gemm -- accumulate must be 1; the problems ADD
+// into their destinations (gradient accumulation; two entries may share one), so the final adds are fp32 atomics.  splitk > 1 with a
+// workspace (rv_gemm_splitk_workspace_bytes, one per entry): the k slices are PARKED and a second grouped launch folds them in k order --
+// one atomic per output element instead of one per slice (the far atomics of a multi-XCD part are the slow half of an atomic split-K);
+// without a workspace every slice adds atomically.  All entries of one table must have the same operand orientation
+// (rv_gemm_table_fill returns it: bit 0 = A k-fast, bit 1 = B k-fast; negative = error) --, finalize (prefix sums of the workgroup
+// counts of both launches), copy the table to the device and run it.
 long rv_gemm_table_entry_bytes(void) { return (long)sizeof(GemmEntry); }
 
 long rv_gemm_table_fill(void* entry_host, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm,
                         long scn, const float* bias, int M, int N, int K, int splitk, int batch, long bsa, long bsb, long bsc,
-                        float* a_rowsum) {
+                        float* a_rowsum, void* splitk_ws) {
     if (!entry_host) { rv_set_error("rv_gemm_table_fill: null entry"); return RV_EINVAL; }
     GemmEntry* e = (GemmEntry*)entry_host;
     const int rc = gemm_args_make(e->a, A, sam, sak, B, sbk, sbn, C, scm, scn, nullptr, 0, 0, bias, M, N, K, 0, 1, splitk, batch, bsa, bsb,
-                                  bsc, a_rowsum, nullptr, nullptr);
+                                  bsc, a_rowsum, splitk > 1 ? splitk_ws : nullptr, nullptr);
     if (rc != RV_OK) return rc;
     e->a.atomic_out = 1;
-    e->gx = cdiv(N, GBN); e->gy = cdiv(M, GBM); e->block0 = e->gx * e->gy * splitk * batch; e->pad = 0;     // block0: count until finalize
+    e->gx = cdiv(N, GBN); e->gy = cdiv(M, GBM);
+    e->block0 = e->gx * e->gy * splitk * batch;                           // block0 / fold0: counts until finalize
+    e->fold0 = (splitk > 1 && splitk_ws) ? e->gx * e->gy * batch : 0;
     return ((sak <= sam) ? 1 : 0) | ((sbk <= sbn) ? 2 : 0);
 }
 
-long rv_gemm_table_finalize(void* table_host, int count) {
+// -> the workgroups of the grouped launch; *fold_blocks (nullable) <- the workgroups of its fold launch (0: no entry parks)
+long rv_gemm_table_finalize(void* table_host, int count, long* fold_blocks) {
     GemmEntry* t = (GemmEntry*)table_host;
-    long total = 0;
-    for (int i = 0; i < count; ++i) { const int n = t[i].block0; t[i].block0 = (int)total; total += n; }
+    long total = 0, ftotal = 0;
+    for (int i = 0; i < count; ++i) {
+        const int n = t[i].block0; t[i].block0 = (int)total; total += n;
+        const int f = t[i].fold0; t[i].fold0 = (int)ftotal; ftotal += f;
+    }
+    if (fold_blocks) *fold_blocks = ftotal;
     return total;
 }
 
-int rv_gemm_table_run(const void* table_dev, int count, long total_blocks, int orientation, void* stream) {
+int rv_gemm_table_run(const void* table_dev, int count, long total_blocks, long fold_blocks, int orientation, void* stream) {
     RV_CHECK_ARG(count > 0 && count <= 64 && total_blocks > 0 && total_blocks < (1L << 31), "rv_gemm_table_run: empty or oversized table");
+    RV_CHECK_ARG(fold_blocks >= 0 && fold_blocks < (1L << 31), "rv_gemm_table_run: bad fold grid");
     hipStream_t st = (hipStream_t)stream;
     const GemmEntry* t = (const GemmEntry*)table_dev;
     dim3 grid((unsigned)total_blocks);
@@ -387,6 +412,10 @@ int rv_gemm_table_run(const void* table_dev, int count, long total_blocks, int o
         default: hipLaunchKernelGGL((gemm_table_k<false, false>), grid, dim3(256), 0, st, t, count); break;
     }
     RV_LAUNCH_CHECK("rv_gemm_table_run");
+    if (fold_blocks > 0) {
+        hipLaunchKernelGGL(gemm_table_fold_k, dim3((unsigned)fold_blocks), dim3(256), 0, st, t, count);
+        RV_LAUNCH_CHECK("rv_gemm_table_run(fold)");
+    }
     return RV_OK;
 }
 

@@ -5,6 +5,7 @@ numeric kernel is a hand-written HIP kernel (reconvat_amd/csrc).  There is no CP
 Internal activation layout is NHWC ([B, H=time, W=bins, C]); a tensor handed to a conv may be a channel
 slice (view) of a wider buffer -- the pixel stride is taken from ``stride(2)``.
 """
+import ctypes
 import os
 import sys
 
@@ -1142,12 +1143,13 @@ class _GemmTable:
     def flush(self):
         if self.n == 0:
             return
-        total = _lib.load().rv_gemm_table_finalize(self.host.data_ptr(), self.n)
+        fold = ctypes.c_long(0)
+        total = _lib.load().rv_gemm_table_finalize(self.host.data_ptr(), self.n, ctypes.addressof(fold))
         used = self.host[:self.n * self.eb]
         with torch.cuda.stream(self.stream):
             src = used if self.pinned else used.pin_memory()
             table = src.to(self.device, non_blocking=True)
-            call('rv_gemm_table_run', ptr(table), self.n, total, self.orientation, self.stream.cuda_stream)
+            call('rv_gemm_table_run', ptr(table), self.n, total, fold.value, self.orientation, self.stream.cuda_stream)
             table.record_stream(self.stream)
             if self.pinned:
                 _keep(table, _GEMM_KEEP)       # captured: keep the device copy's memory out of the graph pool's reuse
@@ -1177,6 +1179,9 @@ class deferred_param_gemms:
             t.flush()
 
 
+_TABLE_PARK = os.environ.get('RV_GEMM_TABLE_PARK', '1') != '0'      # (0: every k slice of a grouped GEMM adds atomically, the form until round 5)
+
+
 def _defer_gemm(a, b_kn, c, splitk, batch, bstrides, a_rowsum):
     """Register c += a @ b_kn (atomic split-K) with the active deferred_param_gemms context; False if none is active."""
     tables = _GEMM_DEFER[0]
@@ -1193,15 +1198,19 @@ def _defer_gemm(a, b_kn, c, splitk, batch, bstrides, a_rowsum):
         tab = tables[key] = _GemmTable(c.device, cur, orient)
     if tab.n >= _GEMM_MAX:
         return False
-    rc = _lib.load().rv_gemm_table_fill(tab.host.data_ptr() + tab.n * tab.eb, pa, sam, sak, pb, sbk, sbn, pc, scm, scn, None, m, n, k,
-                                        splitk, batch, bstrides[0], bstrides[1], bstrides[2], ptr(a_rowsum))
+    lib = _lib.load()
+    # split-K inside the grouped launch: slices parked in a per-entry workspace, folded by the table's second launch (one atomic per element)
+    ws = torch.empty(lib.rv_gemm_splitk_workspace_bytes(m, n, splitk, batch) // 4, device=c.device, dtype=torch.float32) \
+        if (splitk > 1 and _TABLE_PARK) else None
+    rc = lib.rv_gemm_table_fill(tab.host.data_ptr() + tab.n * tab.eb, pa, sam, sak, pb, sbk, sbn, pc, scm, scn, None, m, n, k,
+                                splitk, batch, bstrides[0], bstrides[1], bstrides[2], ptr(a_rowsum), ptr(ws))
     if rc < 0:
         raise RuntimeError(f'rv_gemm_table_fill failed ({rc}): {_lib.last_error()}')
     assert rc == orient
     tab.n += 1
     tab.flops += 2.0 * m * n * k * batch
     tab.bytes += 4.0 * batch * (m * k + k * n + m * n)
-    tab.keep += [a, b_kn, c, a_rowsum]          # operands stay alive (and their memory un-reused) until the grouped launch
+    tab.keep += [a, b_kn, c, a_rowsum, ws]      # operands stay alive (and their memory un-reused) until the grouped launch
     return True
 
 

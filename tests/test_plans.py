@@ -52,4 +52,4 @@ def test_shipped_table_digest_is_pinned():
     assert 'MI355X' in meta.get('device', '') and meta.get('git'), meta.get('device')
 
 
-PINNED_DIGEST = '71c223e27290d219'
+PINNED_DIGEST = '644fe159bb9eb70e'

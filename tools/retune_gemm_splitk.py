@@ -1,5 +1,5 @@
-"""Re-tune the split-K factors of the DETERMINISTIC GEMM entries of a plan table (the data-path GEMMs and, in RV_DETERMINISTIC mode, the
-parameter-gradient ones) with the on-line tuner (ops._tune_gemm: isolated launches, a larger factor must win by 3 %), leaving everything
+"""Re-tune the split-K factors of the GEMM entries of a plan table whose slices are parked and folded (the data-path GEMMs; the parameter-gradient
+GEMMs of the grouped launch) with the on-line tuner (ops._tune_gemm: isolated launches, a larger factor must win by 3 %), leaving everything
 else of the table alone.  Round 5: the deterministic split-K became park + fold (two launches) and, unlike the ticketed in-kernel fold it
 replaces, pays off -- the shipped factors of these entries were all 1.
 
@@ -18,6 +18,7 @@ from reconvat_amd import ops  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument('--table', default=os.path.join(ROOT, 'reconvat_amd', 'tuned_plans.json'))
 ap.add_argument('--out', required=True)
+ap.add_argument('--only', default='all', choices=('all', 'det', 'grouped'), help='det: the data-path entries; grouped: the parameter-gradient entries of the grouped launch')
 args = ap.parse_args()
 doc = json.load(open(args.table))
 dev = torch.device('cuda:0')
@@ -25,16 +26,25 @@ ops.AUTOTUNE = True
 changed = 0
 for key, old in sorted(doc['gemm'].items()):
     m, n, k, batch, ak, bk, act, flags = (int(v) for v in key.split(','))
-    if not flags & 2 or batch != 1:
+    if args.only == 'det' and not flags & 2:
         continue
-    a = torch.randn(m, k, device=dev) if ak else torch.randn(k, m, device=dev).t()
-    b = torch.randn(n, k, device=dev).t() if bk else torch.randn(k, n, device=dev)
-    c = torch.zeros(m, n, device=dev)
+    if args.only == 'grouped' and (flags & 2 or not flags & 1):
+        continue
+    if not flags & 3:
+        continue                                          # (plain single-pass GEMMs: nothing to fold)
+    # `batch` problems side by side in one allocation (the per-head relative-position gradient): problem z at +z*m / +z*n / +z*m*n
+    a_all = torch.randn(batch * m, k, device=dev) if ak else torch.randn(k, batch * m, device=dev).t()
+    b_all = torch.randn(batch * n, k, device=dev).t() if bk else torch.randn(k, batch * n, device=dev)
+    a, b = a_all[:m], b_all[:, :n]
+    bstr = (m * a_all.stride(0), n * b_all.stride(1), m * n) if batch > 1 else (0, 0, 0)
+    c = torch.zeros(batch * m, n, device=dev)[:m]
     best = {}
     for rnd in range(3):                                  # three tuner runs: the factor most often chosen (ties: the smaller)
         ops._gemm_splitk.clear()
         ops.ARENA.begin_step(dev, 64 << 20)
-        ops.gemm(a, b, c, act=act, accumulate=bool(flags & 1), deterministic=True)
+        # grouped entries (flags 1) are timed through the same park + fold path as a single launch: what differs in the grouped launch is
+        # only the atomic final add
+        ops.gemm(a, b, c, act=act, accumulate=bool(flags & 1), deterministic=True, batch=batch, bstrides=bstr)
         ops.ARENA.end_step()
         torch.cuda.synchronize()
         (s,) = ops._gemm_splitk.values()
