@@ -93,6 +93,17 @@ int rv_conv_wgrad(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, co
 long rv_conv_wgrad_deferred(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, const float* V, int v_ld, int Hv, int Wv,
                             int Cb, int B, float* dw, long s_a, long s_b, int flip, float* dbias, void* workspace,
                             long workspace_bytes, void* entry_host, void* stream);
+/* Segmented forms: the pixel reduction runs over nseg (1..4) runs of Bseg images, run s at U[s] / V[s] (identical geometry and strides):
+ * the (input, dY) pairs of ONE layer from several backward passes of a training step (model/UNet_onset.py:383,117-146: the transcriber
+ * is back-propagated three times per step on one stream) folded by ONE launch instead of one per pass -- the fixed cost of a
+ * weight-gradient launch (prologue, accumulator fold, partial sums, reduction entry) is paid once.  Plan and workspace: those of
+ * B = nseg * Bseg images.  RV_EUNSUPPORTED for the small-channel layers (launch those per pass). */
+int rv_conv_wgrad_seg(int mode, int nseg, const float* const* U, const float* const* V, int u_ld, int Hu, int Wu, int Ca, int v_ld, int Hv,
+                      int Wv, int Cb, int Bseg, float* dw, long s_a, long s_b, int flip, float* dbias, int accumulate, void* workspace,
+                      long workspace_bytes, void* stream);
+long rv_conv_wgrad_deferred_seg(int mode, int nseg, const float* const* U, const float* const* V, int u_ld, int Hu, int Wu, int Ca, int v_ld,
+                                int Hv, int Wv, int Cb, int Bseg, float* dw, long s_a, long s_b, int flip, float* dbias, void* workspace,
+                                long workspace_bytes, void* entry_host, void* stream);
 long rv_wgrad_table_entry_bytes(void);
 long rv_wgrad_table_finalize(void* table_host, int count);
 int rv_wgrad_reduce_table(const void* table_dev, int count, long total_blocks, void* stream);

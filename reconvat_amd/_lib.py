@@ -33,6 +33,8 @@ SIGNATURES = {
     'rv_conv_wgrad_set_plan': (I, [I, I, I, I, I, I, I]),
     'rv_conv_wgrad': (I, [I, P, I, I, I, I, P, I, I, I, I, I, P, L, L, I, P, I, P, L, P]),
     'rv_conv_wgrad_deferred': (L, [I, P, I, I, I, I, P, I, I, I, I, I, P, L, L, I, P, P, L, P, P]),
+    'rv_conv_wgrad_seg': (I, [I, I, P, P, I, I, I, I, I, I, I, I, I, P, L, L, I, P, I, P, L, P]),
+    'rv_conv_wgrad_deferred_seg': (L, [I, I, P, P, I, I, I, I, I, I, I, I, I, P, L, L, I, P, P, L, P, P]),
     'rv_wgrad_table_entry_bytes': (L, []),
     'rv_wgrad_table_finalize': (L, [P, I]),
     'rv_wgrad_reduce_table': (I, [P, I, L, P]),

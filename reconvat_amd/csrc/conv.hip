@@ -1475,8 +1475,19 @@ struct WgradArgs {
                                              // 2 no fragment reads, 4 stage the first row only, 8 no row barriers
     unsigned long long* dbg;                 // -DRV_ABLATION: s_memtime stamps of workgroup (0,0) / wave 0 (RV_DBG_PTR)
     FastDiv fd_vplane, fd_wv;                // divide by Hv*Wv, by Wv (small-channel kernel)
-    unsigned u_bytes, v_bytes;               // wgrad_wino_k: bytes of the U / V views (buffer-resource ranges of its staging loads; < 0x3f000000)
+    unsigned u_bytes, v_bytes;               // wgrad_wino_k: bytes of ONE SEGMENT's U / V view (buffer-resource ranges of its staging loads; < 0x3f000000)
+    // Segments (rv_conv_wgrad_seg): the B images are nseg runs of Bseg images, run s at Useg[s] / Vseg[s] (same geometry and strides) --
+    // the same layer's (input, dY) pairs of several backward passes of one step reduced by ONE launch.  nseg == 1: Useg[0] = U, Bseg = B.
+    const float* Useg[4]; const float* Vseg[4];
+    int nseg, Bseg;
 };
+
+// image b -> (segment, image inside it); b is wave-uniform
+__device__ __forceinline__ int wgrad_seg_of(const WgradArgs& a, int b, int& bl) {
+    const int sg = (b >= a.Bseg ? 1 : 0) + (b >= 2 * a.Bseg ? 1 : 0) + (b >= 3 * a.Bseg ? 1 : 0);
+    bl = b - sg * a.Bseg;
+    return sg;
+}
 
 // LDS-staged pixel-reduction GEMM.  One workgroup owns a run of V rows (b, y) and one (a-group, b-group)
 // of up to 32x32 channels.  Per V row it stages that row (CB channels) and the KH input rows it touches
@@ -1557,7 +1568,9 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
         constexpr int PPI = 64 / C4A;
         float* dst0 = ubuf + slot * UP * CA + P * CA;
         const bool inside = r >= 0 && r < a.Hu;
-        const float* src = a.U + ((long)b * a.Hu + (inside ? r : 0)) * a.Wu * a.u_ld + a0;
+        int bl;
+        const int sg = wgrad_seg_of(a, b, bl);
+        const float* src = a.Useg[sg] + ((long)bl * a.Hu + (inside ? r : 0)) * a.Wu * a.u_ld + a0;
         const int px_l = lane / C4A, c4 = (lane - px_l * C4A) * 4;
         for (int k = wave; k * PPI < npxu; k += NW) {
             const int px = k * PPI + px_l;
@@ -1571,7 +1584,9 @@ __global__ __launch_bounds__(NW * 64) void wgrad_mfma_k(WgradArgs a) {
     auto dma_vrow = [&](int b, int y, int vb) {
         constexpr int PPI = 64 / C4B;
         float* dst0 = vbuf + vb * Wv4 * CB;
-        const float* src = a.V + ((long)b * a.Hv + y) * a.Wv * a.v_ld + b0;
+        int bl;
+        const int sg = wgrad_seg_of(a, b, bl);
+        const float* src = a.Vseg[sg] + ((long)bl * a.Hv + y) * a.Wv * a.v_ld + b0;
         const int px_l = lane / C4B, c4 = (lane - px_l * C4B) * 4;
         for (int k = wave; k * PPI < a.Wv; k += NW) {
             const int px = k * PPI + px_l;
@@ -1927,7 +1942,6 @@ __global__ __launch_bounds__(NW * 64) void wgrad_wino_k(WgradArgs a) {
     // (k = wave, wave + NW, ...) do not depend on the row: computed once. ----
     constexpr unsigned OOB = 0x40000000u;
     constexpr int MAXP = 4;                                  // pieces per row and wave planned in registers (any further: generic loop)
-    const rv_rsrc_t rs_u = rv_make_rsrc(a.U, a.u_bytes), rs_v = rv_make_rsrc(a.V, a.v_bytes);
     const int upl = lane / C4A, uql = lane - upl * C4A;      // slot pixel inside the piece, quad position
     const int vpl = lane / C4B, vql = lane - vpl * C4B;
     auto u_off = [&](int k) -> unsigned {
@@ -1948,7 +1962,10 @@ __global__ __launch_bounds__(NW * 64) void wgrad_wino_k(WgradArgs a) {
     for (int j = 0; j < MAXP; ++j) { u_goff[j] = u_off(wave + NW * j); v_goff[j] = v_off(wave + NW * j); }
     auto dma_urow = [&](int b, int r, int slot) {            // input row r of image b -> ring slot
         float* dst0 = ubuf + slot * UPp * CA;
-        const unsigned base = (unsigned)r < (unsigned)a.Hu ? (unsigned)(((b * a.Hu + r) * a.Wu) * a.u_ld + a0) * 4u : OOB;
+        int bl;
+        const int sg = wgrad_seg_of(a, b, bl);
+        const rv_rsrc_t rs_u = rv_make_rsrc(a.Useg[sg], a.u_bytes);       // (the resource covers the image's own segment)
+        const unsigned base = (unsigned)r < (unsigned)a.Hu ? (unsigned)(((bl * a.Hu + r) * a.Wu) * a.u_ld + a0) * 4u : OOB;
 #pragma unroll
         for (int j = 0; j < MAXP; ++j) {
             const int k = wave + NW * j;
@@ -1959,7 +1976,10 @@ __global__ __launch_bounds__(NW * 64) void wgrad_wino_k(WgradArgs a) {
     };
     auto dma_vrow = [&](int b, int y, int vslot) {           // dY row y of image b -> vbuf row slot (0..3)
         float* dst0 = vbuf + vslot * VPp * CB;
-        const unsigned base = (unsigned)(((b * a.Hv + y) * a.Wv) * a.v_ld + b0) * 4u;
+        int bl;
+        const int sg = wgrad_seg_of(a, b, bl);
+        const rv_rsrc_t rs_v = rv_make_rsrc(a.Vseg[sg], a.v_bytes);
+        const unsigned base = (unsigned)(((bl * a.Hv + y) * a.Wv) * a.v_ld + b0) * 4u;
 #pragma unroll
         for (int j = 0; j < MAXP; ++j) {
             const int k = wave + NW * j;
@@ -3224,7 +3244,8 @@ long rv_conv_wgrad_workspace_bytes(int taps, int B, int Hv, int Ca, int Cb) {
 // mode: 0 = 3x3 s1 p1 (U = conv input, V = dY), 1 = 1x1, 2 = 2x2 s2 (U gathered at 2p+tap)
 static int conv_wgrad_impl(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, const float* V, int v_ld, int Hv, int Wv,
                            int Cb, int B, float* dw, long s_a, long s_b, int flip, float* dbias, int accumulate, void* workspace,
-                           long workspace_bytes, void* stream, WreduceEntry* defer);
+                           long workspace_bytes, void* stream, WreduceEntry* defer, int nseg = 1, const float* const* Useg = nullptr,
+                           const float* const* Vseg = nullptr);
 
 int rv_conv_wgrad(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, const float* V, int v_ld, int Hv, int Wv,
                   int Cb, int B, float* dw, long s_a, long s_b, int flip, float* dbias, int accumulate, void* workspace,
@@ -3243,6 +3264,27 @@ long rv_conv_wgrad_deferred(int mode, const float* U, int u_ld, int Hu, int Wu, 
     WreduceEntry* e = (WreduceEntry*)entry_host;
     const int rc = conv_wgrad_impl(mode, U, u_ld, Hu, Wu, Ca, V, v_ld, Hv, Wv, Cb, B, dw, s_a, s_b, flip, dbias, 1, workspace,
                                    workspace_bytes, stream, e);
+    return rc != RV_OK ? (long)rc : e->block0;
+}
+
+// Segmented forms: the reduction runs over nseg (1..4) runs of Bseg images, run s at U[s] / V[s] (identical geometry and strides) -- the
+// (input, dY) pairs of the same layer from several backward passes in ONE launch (plan / workspace: those of B = nseg * Bseg images).
+// Only the MFMA kernels take segments (wgrad_mfma_k, wgrad_wino_k); RV_EUNSUPPORTED for the small-channel layers: launch those per pass.
+int rv_conv_wgrad_seg(int mode, int nseg, const float* const* U, const float* const* V, int u_ld, int Hu, int Wu, int Ca, int v_ld, int Hv,
+                      int Wv, int Cb, int Bseg, float* dw, long s_a, long s_b, int flip, float* dbias, int accumulate, void* workspace,
+                      long workspace_bytes, void* stream) {
+    RV_CHECK_ARG(nseg >= 1 && nseg <= 4 && U && V && Bseg > 0, "rv_conv_wgrad_seg: 1..4 segments");
+    return conv_wgrad_impl(mode, U[0], u_ld, Hu, Wu, Ca, V[0], v_ld, Hv, Wv, Cb, nseg * Bseg, dw, s_a, s_b, flip, dbias, accumulate,
+                           workspace, workspace_bytes, stream, nullptr, nseg, U, V);
+}
+long rv_conv_wgrad_deferred_seg(int mode, int nseg, const float* const* U, const float* const* V, int u_ld, int Hu, int Wu, int Ca, int v_ld,
+                                int Hv, int Wv, int Cb, int Bseg, float* dw, long s_a, long s_b, int flip, float* dbias, void* workspace,
+                                long workspace_bytes, void* entry_host, void* stream) {
+    if (!entry_host) { rv_set_error("rv_conv_wgrad_deferred_seg: null entry"); return RV_EINVAL; }
+    if (!(nseg >= 1 && nseg <= 4 && U && V && Bseg > 0)) { rv_set_error("rv_conv_wgrad_deferred_seg: 1..4 segments"); return RV_EINVAL; }
+    WreduceEntry* e = (WreduceEntry*)entry_host;
+    const int rc = conv_wgrad_impl(mode, U[0], u_ld, Hu, Wu, Ca, V[0], v_ld, Hv, Wv, Cb, nseg * Bseg, dw, s_a, s_b, flip, dbias, 1,
+                                   workspace, workspace_bytes, stream, e, nseg, U, V);
     return rc != RV_OK ? (long)rc : e->block0;
 }
 
@@ -3269,13 +3311,18 @@ int rv_wgrad_reduce_table(const void* table_dev, int count, long total_blocks, v
 
 static int conv_wgrad_impl(int mode, const float* U, int u_ld, int Hu, int Wu, int Ca, const float* V, int v_ld, int Hv, int Wv,
                            int Cb, int B, float* dw, long s_a, long s_b, int flip, float* dbias, int accumulate, void* workspace,
-                           long workspace_bytes, void* stream, WreduceEntry* defer) {
+                           long workspace_bytes, void* stream, WreduceEntry* defer, int nseg, const float* const* Useg,
+                           const float* const* Vseg) {
     // mode bit 8 (RV_WGRAD_BF16): bf16 operands on the matrix pipe for the 3x3 MFMA kernel (opt-in experiment; ignored elsewhere)
     const bool want_bf = (mode & 0x100) != 0;
     mode &= 0xff;
     hipStream_t st = (hipStream_t)stream;
     RV_CHECK_ARG(mode >= 0 && mode <= 2, "rv_conv_wgrad: bad mode %d", mode);
     const int taps = mode == 0 ? 9 : (mode == 1 ? 1 : 4);
+    if (nseg > 1 && (wgrad_sliced(taps, Ca, Cb) || B % nseg)) {
+        rv_set_error("rv_conv_wgrad_seg: no segmented form for this layer (taps %d, %d -> %d channels)", taps, Ca, Cb);
+        return RV_EUNSUPPORTED;
+    }
     if (wgrad_sliced(taps, Ca, Cb)) {
         if (defer) { rv_set_error("rv_conv_wgrad_deferred: the sliced 1 -> %d channel case has no deferred form", Cb); return RV_EUNSUPPORTED; }
         for (int c0 = 0; c0 < Cb; c0 += 16) {
@@ -3288,6 +3335,8 @@ static int conv_wgrad_impl(int mode, const float* U, int u_ld, int Hu, int Wu, i
     WgradArgs a;
     a.U = U; a.u_ld = u_ld; a.Hu = Hu; a.Wu = Wu; a.Ca = Ca; a.V = V; a.v_ld = v_ld; a.Hv = Hv; a.Wv = Wv; a.Cb = Cb;
     a.B = B; a.want_bias = dbias != nullptr;
+    a.nseg = nseg; a.Bseg = B / nseg;
+    for (int i = 0; i < 4; ++i) { a.Useg[i] = nseg > 1 ? Useg[i < nseg ? i : 0] : U; a.Vseg[i] = nseg > 1 ? Vseg[i < nseg ? i : 0] : V; }
     a.ablate = getenv("RV_ABLATE") ? atoi(getenv("RV_ABLATE")) : 0;
     a.dbg = getenv("RV_DBG_PTR") ? (unsigned long long*)strtoull(getenv("RV_DBG_PTR"), nullptr, 10) : nullptr;
     a.pstride = (long)taps * Ca * Cb + Cb;
@@ -3303,7 +3352,7 @@ static int conv_wgrad_impl(int mode, const float* U, int u_ld, int Hu, int Wu, i
         const int nh_ = (plan.TA == 2 && plan.TB == 2) ? 2 : 1, nxg_ = 8 / nh_;
         const size_t fold = (size_t)nh_ * (nxg_ / 2) * (9 * (plan.TA / nh_) * plan.TB + plan.TB) * 4 * 64 * sizeof(float);
         if (wino_lds < fold) wino_lds = fold;
-        const long ub = (((long)B * Hu * Wu - 1) * u_ld + Ca) * 4, vb = (((long)B * Hv * Wv - 1) * v_ld + Cb) * 4;
+        const long ub = (((long)a.Bseg * Hu * Wu - 1) * u_ld + Ca) * 4, vb = (((long)a.Bseg * Hv * Wv - 1) * v_ld + Cb) * 4;   // per segment
         a.u_bytes = (unsigned)ub; a.v_bytes = (unsigned)vb;   // (the staging loads address the views with 30-bit offsets: see the kernel)
         if (want_bf || mode != 0 || Hu != Hv || Wu != Wv || wino_lds > 160 * 1024 || ub >= 0x3f000000L || vb >= 0x3f000000L) {
             plan.wino = false;                             // this launch runs the direct form on the same partition, in ROWS
@@ -3314,6 +3363,10 @@ static int conv_wgrad_impl(int mode, const float* U, int u_ld, int Hu, int Wu, i
     RV_CHECK_ARG(workspace_bytes >= (long)plan.nparts * a.pstride * 4, "rv_conv_wgrad: workspace too small");
     a.part = (float*)workspace;
     a.nparts = plan.nparts; a.rows_per_wave = plan.rows_per_wave; a.ngb = plan.ngb;
+    if (plan.small && nseg > 1) {
+        rv_set_error("rv_conv_wgrad_seg: the small-channel kernels take one segment");
+        return RV_EUNSUPPORTED;
+    }
     if (plan.small) {
         dim3 grid(cdiv(a.nparts, 4)), blk(256);
 #define RV_WS(ca, cb, kh, kw, ss, pp)                                                             \

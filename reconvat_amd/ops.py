@@ -671,24 +671,16 @@ def _tune_wgrad(lib, mode, taps, u, uld, hu, wu, ca, v, vld, hv, wv, cb, bb, w, 
         print(f'[tune] wgrad taps={taps} {ca}->{cb} {hv}x{wv} B={bb}: nw={choice[0]} wgs={choice[1]} {best / 3 * 1e3:.1f} us', file=sys.stderr)
 
 
-def conv_wgrad(kind, x, dy, w, want_bias=True, dw_acc=None, db_acc=None, bf16=False, colsum=None):
-    """(dw, db) in the PyTorch layouts of `w` / bias; with dw_acc/db_acc the results are ADDED into those buffers."""
+def _wgrad_geom(kind, x, dy, w, bf16):
+    """The pixel-reduction GEMM behind a conv layer's weight gradient: (mode, taps, u, uld, hu, wu, ca, v, vld, hv, wv, cb, bb, s_a, s_b, flip)."""
     bb, h, wd, cin, xld = _geom(x)
     _, ho, wo, cout, yld = _geom(dy)
-    acc = 1 if dw_acc is not None else 0
-    dw = dw_acc if acc else torch.empty_like(w)
-    if not want_bias:
-        db = None
-    else:
-        db = db_acc if acc else torch.empty(cout, device=w.device, dtype=torch.float32)
-    lib = _lib.load()
     if kind == 'up':
         # G[tap][a=co][b=ci] = sum_p dY[2p+tap][co] * X[p][ci]  -> dWt[ci][co][tap]
         taps, mode = 4, 2
         u, uld, hu, wu, ca = dy, yld, ho, wo, cout
         v, vld, hv, wv, cb = x, xld, h, wd, cin
         s_a, s_b, flip = 4, cout * 4, 0
-        bias_ptr = None
     else:
         mode = {'c3': 0, 't3': 0, 'c1': 1, 'down': 2}[kind]
         taps = {'c3': 9, 't3': 9, 'c1': 1, 'down': 4}[kind]
@@ -698,34 +690,194 @@ def conv_wgrad(kind, x, dy, w, want_bias=True, dw_acc=None, db_acc=None, bf16=Fa
             s_a, s_b, flip = cout * 9, 9, 1
         else:
             s_a, s_b, flip = taps, cin * taps, 0
-        bias_ptr = ptr(db)
         if bf16 and taps == 9:
             mode |= 0x100                       # bf16 operands on the matrix pipe (opt-in experiment, see BF16)
-    _tune_wgrad(lib, mode & 0xff, taps, u, uld, hu, wu, ca, v, vld, hv, wv, cb, bb, w, s_a, s_b, flip)
-    nbytes = lib.rv_conv_wgrad_workspace_bytes(taps, bb, hv, ca, cb)
-    ws = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
-    tables = _WGRAD_DEFER[0]
-    if tables is not None and acc and not DETERMINISTIC[0] and not (taps == 9 and ca == 1 and cb > 16):
-        cur = torch.cuda.current_stream(w.device)
-        tab = tables.get(cur.cuda_stream)
-        if tab is None:
-            tab = tables[cur.cuda_stream] = _WgradTable(w.device, cur)
-        rc = invoke('rv_conv_wgrad_deferred', mode, ptr(u), uld, hu, wu, ca, ptr(v), vld, hv, wv, cb, bb, ptr(dw), s_a, s_b, flip,
-                    bias_ptr, ptr(ws), nbytes, tab.slot(), cur.cuda_stream)
-        if rc <= 0:
-            raise RuntimeError(f'rv_conv_wgrad_deferred failed ({rc}): {_lib.last_error()}')
-        tab.n += 1
-        tab.keep.append(ws)
+    return mode, taps, u, uld, hu, wu, ca, v, vld, hv, wv, cb, bb, s_a, s_b, flip
+
+
+def conv_wgrad(kind, x, dy, w, want_bias=True, dw_acc=None, db_acc=None, bf16=False, colsum=None):
+    """(dw, db) in the PyTorch layouts of `w` / bias; with dw_acc/db_acc the results are ADDED into those buffers."""
+    mode, taps, u, uld, hu, wu, ca, v, vld, hv, wv, cb, bb, s_a, s_b, flip = _wgrad_geom(kind, x, dy, w, bf16)
+    cout = dy.shape[3]
+    acc = 1 if dw_acc is not None else 0
+    dw = dw_acc if acc else torch.empty_like(w)
+    if not want_bias:
+        db = None
     else:
-        call('rv_conv_wgrad', mode, ptr(u), uld, hu, wu, ca, ptr(v), vld, hv, wv, cb, bb, ptr(dw), s_a, s_b, flip,
-             bias_ptr, acc, ptr(ws), nbytes, stream())
+        db = db_acc if acc else torch.empty(cout, device=w.device, dtype=torch.float32)
+    bias_ptr = None if kind == 'up' else ptr(db)
+    lib = _lib.load()
+    merger = _WGRAD_MERGE[0]
+    if merger is not None and acc and not DETERMINISTIC[0] and ca > 2 and cb > 2 and \
+            merger.submit((dw.data_ptr(), mode), (kind, x, dy, w, dw, None if kind == 'up' else db, bf16)):
+        pass                                       # (launched with the same layer's other passes of this step: WgradMerger)
+    else:
+        _tune_wgrad(lib, mode & 0xff, taps, u, uld, hu, wu, ca, v, vld, hv, wv, cb, bb, w, s_a, s_b, flip)
+        nbytes = lib.rv_conv_wgrad_workspace_bytes(taps, bb, hv, ca, cb)
+        ws = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+        tables = _WGRAD_DEFER[0]
+        if tables is not None and acc and not DETERMINISTIC[0] and not (taps == 9 and ca == 1 and cb > 16):
+            cur = torch.cuda.current_stream(w.device)
+            tab = tables.get(cur.cuda_stream)
+            if tab is None:
+                tab = tables[cur.cuda_stream] = _WgradTable(w.device, cur)
+            rc = invoke('rv_conv_wgrad_deferred', mode, ptr(u), uld, hu, wu, ca, ptr(v), vld, hv, wv, cb, bb, ptr(dw), s_a, s_b, flip,
+                        bias_ptr, ptr(ws), nbytes, tab.slot(), cur.cuda_stream)
+            if rc <= 0:
+                raise RuntimeError(f'rv_conv_wgrad_deferred failed ({rc}): {_lib.last_error()}')
+            tab.n += 1
+            tab.keep.append(ws)
+        else:
+            call('rv_conv_wgrad', mode, ptr(u), uld, hu, wu, ca, ptr(v), vld, hv, wv, cb, bb, ptr(dw), s_a, s_b, flip,
+                 bias_ptr, acc, ptr(ws), nbytes, stream())
     if kind == 'up' and want_bias:
         if colsum is not None and colsum.sums is not None:
             # dY's column sums came with the kernel that produced dY (ColsumLink): fold the replicas, no pass over dY
             call('rv_sums_fold', ptr(colsum.sums), colsum.c, 0, cout, ptr(db), acc, stream())
         else:
-            _colsum_into(dy, yld, bb * ho * wo, cout, db, acc)
+            _colsum_into(dy, dy.stride(2), bb * dy.shape[1] * dy.shape[2], cout, db, acc)
     return (None, None) if acc else (dw, db)
+
+
+def conv_wgrad_merged(items):
+    """ONE weight-gradient launch for the same layer's (x, dY) pairs of several backward passes (rv_conv_wgrad_seg: up to four segments of
+    identical geometry).  items: [(kind, x, dy, w, dw_acc, db_acc_or_None), ...], all of one layer and one gradient buffer."""
+    kind, x0, dy0, w, dw, db, bf16 = items[0]
+    geo = [_wgrad_geom(it[0], it[1], it[2], w, bf16) for it in items]
+    mode, taps, u0, uld, hu, wu, ca, v0, vld, hv, wv, cb, bb, s_a, s_b, flip = geo[0]
+    same = all(g[0] == mode and g[3:7] == geo[0][3:7] and g[8:] == geo[0][8:] for g in geo)
+    lib = _lib.load()
+    n = len(items)
+    if n == 1 or not same:
+        return False
+    tkey = (taps, n * bb, hv, ca, cb)
+    if AUTOTUNE and tkey not in _wgrad_tuned:
+        # the partition of n * bb images: the table's entry (or the nearest batch's), else the one this process tuned for one pass -- never the
+        # on-line tuner's timing launches (they read n * bb CONTIGUOUS images from the first segment)
+        _wgrad_tuned.add(tkey)
+        plan = (plans.lookup_wgrad((taps, n * bb, hv, wv, ca, cb)) if AUTOTUNE == 'table' else None) or _wgrad_plans.get((taps, bb, hv, wv, ca, cb))
+        if plan is not None and lib.rv_conv_wgrad_set_plan(taps, n * bb, hv, ca, cb, *plan) == 0:
+            _wgrad_plans[(taps, n * bb, hv, wv, ca, cb)] = tuple(plan)
+    nbytes = lib.rv_conv_wgrad_workspace_bytes(taps, n * bb, hv, ca, cb)
+    ws = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+    us = (ctypes.c_void_p * n)(*[g[2].data_ptr() for g in geo])
+    vs = (ctypes.c_void_p * n)(*[g[7].data_ptr() for g in geo])
+    tables = _WGRAD_DEFER[0]
+    if tables is not None:
+        cur = torch.cuda.current_stream(w.device)
+        tab = tables.get(cur.cuda_stream)
+        if tab is None:
+            tab = tables[cur.cuda_stream] = _WgradTable(w.device, cur)
+        rc = invoke('rv_conv_wgrad_deferred_seg', mode, n, ctypes.addressof(us), ctypes.addressof(vs), uld, hu, wu, ca, vld, hv, wv, cb, bb,
+                    ptr(dw), s_a, s_b, flip, ptr(db), ptr(ws), nbytes, tab.slot(), cur.cuda_stream)
+        if rc <= 0:
+            return False                           # (no segmented form for this layer: the caller launches per pass)
+        tab.n += 1
+        tab.keep.append(ws)
+    else:
+        rc = invoke('rv_conv_wgrad_seg', mode, n, ctypes.addressof(us), ctypes.addressof(vs), uld, hu, wu, ca, vld, hv, wv, cb, bb,
+                    ptr(dw), s_a, s_b, flip, ptr(db), 1, ptr(ws), nbytes, stream())
+        if rc != 0:
+            return False
+    return True
+
+
+# --------------------------------------------------------------------------------------------
+# one weight-gradient launch per layer and STEP (per gradient bucket), not per backward pass
+# --------------------------------------------------------------------------------------------
+_WGRAD_MERGE = [None]
+_WGRAD_MERGE_HELPER = os.environ.get('RV_WGRAD_MERGE_HELPER', '1') != '0'      # the main chain's merged launches run on the (then idle) side stream
+_WGRAD_MERGE_MAX = min(4, max(2, int(os.environ.get('RV_WGRAD_MERGE_MAX', '4'))))      # passes per launch (rv_conv_wgrad_seg takes up to four)
+
+
+class WgradMerger:
+    """The transcriber is back-propagated several times per training step (model/UNet_onset.py:383,117-146: main forward, the two VAT final
+    passes, the reconstruction branch) and every pass launched its own weight-gradient kernel per layer.  A weight gradient is a sum over
+    pixels, so the passes of one layer that add into the SAME gradient buffer (= run on the same stream) can be one launch over the
+    concatenation of their (x, dY) pairs -- the fixed cost of such a launch (prologue, accumulator fold, partial sums, reduction entry:
+    ~10 us of 35-60) is paid once: 3 x 49.9 -> 117 us for 64 -> 64 @160x57 at B = 8 per pass.
+    How many passes a buffer sees per step is LEARNED from a step that runs unmerged (per mode: one chain or two); afterwards a pass only
+    registers its operands and the last one launches.  `finish()` launches whatever is still pending (a step that took another path)."""
+
+    def __init__(self):
+        self.learned = {}          # (mode, key) -> launches per step
+        self.mode = None
+        self.counts, self.pending = {}, {}
+
+    def begin(self, mode):
+        self.mode, self.counts, self.pending = mode, {}, {}
+
+    def submit(self, key, item):
+        self.counts[key] = self.counts.get(key, 0) + 1
+        want = self.learned.get((self.mode, key))
+        if want is None or want < 2:
+            return False                           # learning step / single pass: the caller launches now
+        q = self.pending.setdefault(key, [])
+        q.append(item)
+        if len(q) >= min(want, _WGRAD_MERGE_MAX):
+            self._launch(key)
+        return True
+
+    def _launch(self, key):
+        q = self.pending.pop(key, [])
+        if not q:
+            return
+        helper = self._helper_for(q)
+        if helper is not None:
+            # the last pass of the main chain (the main forward's backward) runs while the side chain is idle: its input-gradient chain stays
+            # here, the merged weight gradients go next door (they ADD into the same bucket through the reduction table's atomics)
+            cur = torch.cuda.current_stream(q[0][3].device)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            with torch.cuda.stream(helper):
+                helper.wait_event(ev)
+                for it in q:
+                    it[1].record_stream(helper)
+                    it[2].record_stream(helper)
+                self._launch_here(q)
+            return
+        self._launch_here(q)
+
+    def _helper_for(self, q):
+        if not _WGRAD_MERGE_HELPER or len(q) < 2 or not DUAL_STREAM[0] or SIDE_GRADS[0] is None or _WGRAD_DEFER[0] is None:
+            return None
+        main, twins = SIDE_GRADS[0]
+        p_ = q[0][4].data_ptr()
+        if not (main.data_ptr() <= p_ < main.data_ptr() + main.numel() * 4) or not twins:
+            return None
+        dev = q[0][3].device
+        helper = side_stream(dev, 0)
+        return None if helper.cuda_stream == torch.cuda.current_stream(dev).cuda_stream else helper
+
+    def _launch_here(self, q):
+        if not conv_wgrad_merged(q):
+            merger, _WGRAD_MERGE[0] = _WGRAD_MERGE[0], None
+            try:
+                for kind, x, dy, w, dw, db, bf16 in q:   # no segmented form: per pass after all
+                    conv_wgrad(kind, x, dy, w, db is not None, dw, db, bf16=bf16)
+            finally:
+                _WGRAD_MERGE[0] = merger
+
+    def finish(self):
+        for key in list(self.pending):
+            self._launch(key)
+        for key, n in self.counts.items():
+            self.learned[(self.mode, key)] = n
+
+
+class wgrad_merging:
+    def __init__(self, merger, mode):
+        self.merger, self.mode = merger, mode
+
+    def __enter__(self):
+        self.prev = _WGRAD_MERGE[0]
+        _WGRAD_MERGE[0] = self.merger
+        if self.merger is not None:
+            self.merger.begin(self.mode)
+        return self.merger
+
+    def __exit__(self, *exc):
+        _WGRAD_MERGE[0] = self.prev
 
 
 # --------------------------------------------------------------------------------------------

@@ -287,6 +287,7 @@ class TrainStep:
             import sys
             print('[bf16] backward convs of the final graphs use bf16 operands', file=sys.stderr)
         self.dual_stream = dual_stream        # the two VAT chains on two HIP streams (model._vat_two_streams)
+        self._merger = ops.WgradMerger()       # one weight-gradient launch per layer and gradient bucket, not per backward pass
         self._dual_ready = False              # ... from the second step on: the first one packs weights and autotunes
         if getattr(model, 'has_recurrence', False):
             opt.sync_error_word = True
@@ -321,14 +322,18 @@ class TrainStep:
             # (RV_DETERMINISTIC=1: per-layer reductions in stream order instead of the table launch with its fp32 atomics, ops.DETERMINISTIC)
             defer = os.environ.get('RV_DEFER_WGRAD', '1') != '0' and getattr(self.model, 'defer_wgrad_reductions', True) and not ops.DETERMINISTIC[0]
             defer_g = os.environ.get('RV_DEFER_GEMM', '1') != '0' and getattr(self.model, 'defer_param_gemms', True)
+            merge = self._merger if (defer and os.environ.get('RV_WGRAD_MERGE', '1') != '0') else None
             with ops.bf16_final_graphs(fwd=False, bwd=self.bf16_backward), ops.direct_param_grads(), \
                     (ops.deferred_wgrad_reductions() if defer else contextlib.nullcontext()) as pending, \
-                    (ops.deferred_param_gemms() if defer_g else contextlib.nullcontext()) as pending_g:
+                    (ops.deferred_param_gemms() if defer_g else contextlib.nullcontext()) as pending_g, \
+                    ops.wgrad_merging(merge, bool(dual)):
                 # conv grads accumulate straight into the flat bucket; their partial sums are folded by ONE launch per stream, and the
                 # linear / attention parameter-gradient GEMMs run as ONE grouped launch per stream
                 _, losses, _ = self.model.run_on_batch(self.batch, self.batch_ul, self.VAT)
                 loss = weighted_loss(losses, self.alpha)
                 loss.backward()
+                if merge is not None:
+                    merge.finish()                 # (a layer whose passes did not all arrive: launched now, merged as far as they came)
                 if pending is not None:
                     pending.flush()
                 if pending_g is not None:

@@ -795,3 +795,105 @@ def test_deterministic_mode_parameter_gradients(dev, monkeypatch):
         assert torch.equal(p, q)
     for p, q in zip(d1, a1):
         assert rel_err(p, q) < 1e-5
+
+
+WGRAD_SEG_CASES = [('c3', 32, 32, 12, 57, 24), ('c3', 64, 64, 8, 28, 8), ('t3', 96, 48, 10, 57, 24), ('c3', 16, 16, 6, 229, 24), ('c1', 32, 64, 9, 57, 8),
+                   ('down', 32, 32, 10, 57, 8), ('up', 32, 32, 5, 29, 8), ('c3', 48, 24, 7, 114, 8)]
+
+
+@pytest.mark.parametrize('kind,cin,cout,H,W,nw', WGRAD_SEG_CASES)
+@pytest.mark.parametrize('nseg', [2, 3, 4])
+def test_wgrad_segments_equal_the_sum_of_per_pass_launches(dev, kind, cin, cout, H, W, nw, nseg):
+    """rv_conv_wgrad_seg / rv_conv_wgrad_deferred_seg (ops.conv_wgrad_merged): ONE launch over the (x, dY) pairs of `nseg` backward passes of a
+    layer adds the same dW / db into the gradient buffers as `nseg` separate launches (both against torch in fp64) -- Winograd and direct
+    kernels, every conv kind with an MFMA weight-gradient kernel, odd heights, segments that live in unrelated allocations."""
+    import torch.nn.functional as F
+    from reconvat_amd import ops, _lib
+    lib = _lib.load()
+    B = 2
+    ho, wo = ops._out_hw(kind, H, W, (2 * H + 1, 2 * W + 1) if kind == 'up' else None)
+    wshape = {'c3': (cout, cin, 3, 3), 't3': (cin, cout, 3, 3), 'c1': (cout, cin, 1, 1), 'down': (cout, cin, 2, 2), 'up': (cin, cout, 2, 2)}[kind]
+    w = rnd(*wshape, seed=3).to(dev)
+    pairs, junk = [], []
+    for sgi in range(nseg):
+        junk.append(torch.empty(1000 + 4096 * sgi, device=dev))                   # (scatter the segments over the heap)
+        pairs.append((rnd(B, H, W, cin, seed=10 + sgi).to(dev), rnd(B, ho, wo, cout, seed=20 + sgi).to(dev)))
+    # torch: the sum over the passes of the layer's parameter gradients, fp64
+    wt = w.cpu().double().requires_grad_(True)
+    bt = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    for x, dy in pairs:
+        xt = x.cpu().permute(0, 3, 1, 2).double()
+        if kind == 'c3':
+            yt = F.conv2d(xt, wt, bt, padding=1)
+        elif kind == 't3':
+            yt = F.conv_transpose2d(xt, wt, bt, padding=1)
+        elif kind == 'c1':
+            yt = F.conv2d(xt, wt, bt)
+        elif kind == 'down':
+            yt = F.conv2d(xt, wt, bt, stride=2)
+        else:
+            yt = F.conv_transpose2d(xt, wt, bt, stride=2, output_padding=(ho - 2 * H, wo - 2 * W))
+        yt.backward(dy.cpu().permute(0, 3, 1, 2).double())
+    taps = {'c3': 9, 't3': 9, 'c1': 1, 'down': 4, 'up': 4}[kind]
+    hv, ca, cb = (H, cout, cin) if kind == 'up' else (ho, cin, cout)
+    old = ops.AUTOTUNE
+    ops.AUTOTUNE = False
+    try:
+        for bb in (B, nseg * B):
+            assert lib.rv_conv_wgrad_set_plan(taps, bb, hv, ca, cb, nw, 256) == 0
+        want_bias = kind != 'up'                                 # (the up-conv's bias gradient is a column sum of dY, taken per pass)
+        for deferred in (False, True):
+            gw, gb = torch.full_like(w, 0.5), torch.full((cout,), -0.25, device=dev)
+            gw2, gb2 = gw.clone(), gb.clone()
+            items = [(kind, x, dy, w, gw, gb if want_bias else None, False) for x, dy in pairs]
+            if deferred:
+                with ops.deferred_wgrad_reductions() as pend:
+                    assert ops.conv_wgrad_merged(items)
+                    for x, dy in pairs:
+                        ops.conv_wgrad(kind, x, dy, w, want_bias, gw2, gb2 if want_bias else None)
+                    pend.flush()
+            else:
+                assert ops.conv_wgrad_merged(items)
+                for x, dy in pairs:
+                    ops.conv_wgrad(kind, x, dy, w, want_bias, gw2, gb2 if want_bias else None)
+            torch.cuda.synchronize()
+            assert rel_err(gw - 0.5, wt.grad.float()) < 3e-5, (deferred, rel_err(gw - 0.5, wt.grad.float()))
+            assert rel_err(gw - 0.5, gw2 - 0.5) < 1e-5
+            if want_bias:
+                assert rel_err(gb + 0.25, bt.grad.float()) < 3e-5 and rel_err(gb + 0.25, gb2 + 0.25) < 1e-5
+    finally:
+        for bb in (B, nseg * B):
+            lib.rv_conv_wgrad_set_plan(taps, bb, hv, ca, cb, 0, 0)
+        ops.AUTOTUNE = old
+
+
+def test_wgrad_merger_learns_then_merges(dev):
+    """ops.WgradMerger: a step that runs unmerged teaches it how many passes add into a gradient buffer; from then on the passes only register
+    and the last one launches -- same gradients, a third of the launches; a step that takes another path is finished by finish()."""
+    from reconvat_amd import ops
+    w = rnd(32, 32, 3, 3, seed=3).to(dev)
+    pairs = [(rnd(2, 12, 57, 32, seed=10 + i).to(dev), rnd(2, 12, 57, 32, seed=20 + i).to(dev)) for i in range(3)]
+    merger = ops.WgradMerger()
+    launches = []
+    hook_prev = ops._lib.HOOK[0]
+    ops._lib.HOOK[0] = lambda name, args, fn: (launches.append(name), fn(*args))[1]
+    try:
+        results = []
+        gw, gb = torch.zeros_like(w), torch.zeros(32, device=dev)           # (the merger knows a layer by its gradient buffer)
+        for step, npass in enumerate((3, 3, 2, 3)):
+            gw.zero_(), gb.zero_()
+            launches.clear()
+            with ops.wgrad_merging(merger, False):
+                for x, dy in pairs[:npass]:
+                    ops.conv_wgrad('c3', x, dy, w, True, gw, gb)
+                merger.finish()
+            torch.cuda.synchronize()
+            results.append((gw.clone(), gb.clone(), [n for n in launches if n.startswith('rv_conv_wgrad')]))
+    finally:
+        ops._lib.HOOK[0] = hook_prev
+    assert results[0][2] == ['rv_conv_wgrad'] * 3                                     # learning step: per pass
+    assert results[1][2] == ['rv_conv_wgrad_seg']                                     # merged: one launch
+    assert results[2][2] == ['rv_conv_wgrad_seg']                                     # a pass short: finish() launches the two that came
+    assert results[3][2] == ['rv_conv_wgrad_seg', 'rv_conv_wgrad']                    # (learned 2 in the short step: the third pass arrives alone)
+    assert rel_err(results[1][0], results[0][0]) < 1e-5 and rel_err(results[1][1], results[0][1]) < 1e-5
+    assert rel_err(results[3][0], results[0][0]) < 1e-5

@@ -11,7 +11,7 @@ from reconvat_amd import ops
 
 what, kind, cin, cout, h, w = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
 reps = int(sys.argv[7]) if len(sys.argv) > 7 else 20
-B = 8
+B = int(os.environ.get('RV_BENCH_B', '8'))
 dev = torch.device('cuda:0')
 x = torch.rand(B, h, w, cin, device=dev) - 0.5
 wshape = {'c3': (cout, cin, 3, 3), 't3': (cin, cout, 3, 3), 'c1': (cout, cin, 1, 1), 'down': (cout, cin, 2, 2), 'up': (cin, cout, 2, 2)}[kind]
