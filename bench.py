@@ -71,14 +71,26 @@ CONV_ENTRY_POINTS = ('rv_conv_fwd', 'rv_conv_wgrad', 'rv_conv_wgrad_deferred', '
 ROTATE_BYTES = 320 << 20              # operand sets of one timed launch are rotated until they total more than the 256 MiB Infinity Cache
 
 
+def plain_wgrad(name, a):
+    """Book-keeping form of a SEGMENTED weight-gradient launch (rv_conv_wgrad_seg / _deferred_seg: the (x, dY) pairs of several backward
+    passes of one layer in one launch): the argument list of the plain entry point over nseg * Bseg images -- same kernel, same work, same
+    time; the segment pointer arrays (host memory of the caller) are not kept."""
+    if name == 'rv_conv_wgrad_seg':
+        return 'rv_conv_wgrad', (a[0], 0, a[4], a[5], a[6], a[7], 0, a[8], a[9], a[10], a[11], a[1] * a[12]) + tuple(a[13:])
+    if name == 'rv_conv_wgrad_deferred_seg':
+        return 'rv_conv_wgrad_deferred', (a[0], 0, a[4], a[5], a[6], a[7], 0, a[8], a[9], a[10], a[11], a[1] * a[12]) + tuple(a[13:])
+    return name, a
+
+
 def record_launches(step_fn, names):
     """Run step_fn once with the library's launch hook installed; returns [(entry point, args)] of the launches in `names`."""
     from reconvat_amd import _lib
     records = []
 
     def hook(name, args, fn):
-        if name in names:
-            records.append((name, args))
+        pname, pargs = plain_wgrad(name, args)
+        if pname in names:
+            records.append((pname, pargs))
         return fn(*args)
     prev = _lib.HOOK[0]
     _lib.HOOK[0] = hook
@@ -104,7 +116,9 @@ def measure_conv_phase(step_fn, device):
     prev_defer = os.environ.get('RV_DEFER_WGRAD')
     os.environ['RV_DEFER_WGRAD'] = '0'
     try:
-        records = record_launches(step_fn, ('rv_conv_fwd', 'rv_conv_wgrad'))
+        step_fn()                  # (two steps first: the weight-gradient merger learns the pass counts of this step object's two modes ...
+        step_fn()
+        records = record_launches(step_fn, ('rv_conv_fwd', 'rv_conv_wgrad'))      # ... so the recorded step launches what the timed step launches)
     finally:
         if prev_defer is None:
             del os.environ['RV_DEFER_WGRAD']
@@ -257,14 +271,15 @@ def measure_in_situ(step_fn, device):
     brackets = []
 
     def hook(name, args, fn):
-        f = fam_of.get(name)
+        pname, pargs = plain_wgrad(name, args)
+        f = fam_of.get(pname)
         if f is None:
             return fn(*args)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = fn(*args)
         e1.record()
-        brackets.append((f, name, args, e0, e1))
+        brackets.append((f, pname, pargs, e0, e1))
         return rc
     prev = _lib.HOOK[0]
     _lib.HOOK[0] = hook

@@ -709,7 +709,7 @@ def conv_wgrad(kind, x, dy, w, want_bias=True, dw_acc=None, db_acc=None, bf16=Fa
     lib = _lib.load()
     merger = _WGRAD_MERGE[0]
     if merger is not None and acc and not DETERMINISTIC[0] and ca > 2 and cb > 2 and \
-            merger.submit((dw.data_ptr(), mode), (kind, x, dy, w, dw, None if kind == 'up' else db, bf16)):
+            merger.submit((_bucket_offset(dw.data_ptr()), mode), (kind, x, dy, w, dw, None if kind == 'up' else db, bf16, torch.cuda.current_stream(w.device))):
         pass                                       # (launched with the same layer's other passes of this step: WgradMerger)
     else:
         _tune_wgrad(lib, mode & 0xff, taps, u, uld, hu, wu, ca, v, vld, hv, wv, cb, bb, w, s_a, s_b, flip)
@@ -739,10 +739,28 @@ def conv_wgrad(kind, x, dy, w, want_bias=True, dw_acc=None, db_acc=None, bf16=Fa
     return (None, None) if acc else (dw, db)
 
 
+def _bucket_offset(p_):
+    """A gradient buffer's identity across the chains' gradient buckets (the side chains add into twins of the flat bucket, SIDE_GRADS): its
+    offset inside whichever bucket holds it (no buckets: the pointer itself)."""
+    sg = SIDE_GRADS[0] if (_WGRAD_MERGE_ACROSS and _WGRAD_MERGE_HELPER) else None
+    if sg is None:
+        return p_
+    main, twins = sg
+    for t in (main, *twins.values()):
+        if t.data_ptr() <= p_ < t.data_ptr() + t.numel() * 4:
+            return p_ - t.data_ptr()
+    return p_
+
+
+def _in_main_bucket(p_):
+    sg = SIDE_GRADS[0]
+    return sg is not None and sg[0].data_ptr() <= p_ < sg[0].data_ptr() + sg[0].numel() * 4
+
+
 def conv_wgrad_merged(items):
     """ONE weight-gradient launch for the same layer's (x, dY) pairs of several backward passes (rv_conv_wgrad_seg: up to four segments of
     identical geometry).  items: [(kind, x, dy, w, dw_acc, db_acc_or_None), ...], all of one layer and one gradient buffer."""
-    kind, x0, dy0, w, dw, db, bf16 = items[0]
+    kind, x0, dy0, w, dw, db, bf16 = items[0][:7]
     geo = [_wgrad_geom(it[0], it[1], it[2], w, bf16) for it in items]
     mode, taps, u0, uld, hu, wu, ca, v0, vld, hv, wv, cb, bb, s_a, s_b, flip = geo[0]
     same = all(g[0] == mode and g[3:7] == geo[0][3:7] and g[8:] == geo[0][8:] for g in geo)
@@ -787,6 +805,7 @@ def conv_wgrad_merged(items):
 # --------------------------------------------------------------------------------------------
 _WGRAD_MERGE = [None]
 _WGRAD_MERGE_HELPER = os.environ.get('RV_WGRAD_MERGE_HELPER', '1') != '0'      # the main chain's merged launches run on the (then idle) side stream
+_WGRAD_MERGE_ACROSS = os.environ.get('RV_WGRAD_MERGE_ACROSS', '1') != '0'      # the side chain's pass of a shared layer joins the main chain's launch
 _WGRAD_MERGE_MAX = min(4, max(2, int(os.environ.get('RV_WGRAD_MERGE_MAX', '4'))))      # passes per launch (rv_conv_wgrad_seg takes up to four)
 
 
@@ -822,21 +841,25 @@ class WgradMerger:
         q = self.pending.pop(key, [])
         if not q:
             return
-        helper = self._helper_for(q)
-        if helper is not None:
-            # the last pass of the main chain (the main forward's backward) runs while the side chain is idle: its input-gradient chain stays
-            # here, the merged weight gradients go next door (they ADD into the same bucket through the reduction table's atomics)
-            cur = torch.cuda.current_stream(q[0][3].device)
-            ev = torch.cuda.Event()
-            ev.record(cur)
-            with torch.cuda.stream(helper):
-                helper.wait_event(ev)
-                for it in q:
-                    it[1].record_stream(helper)
-                    it[2].record_stream(helper)
-                self._launch_here(q)
-            return
-        self._launch_here(q)
+        q.sort(key=lambda it: not _in_main_bucket(it[4].data_ptr()))       # the sum goes to the main chain's bucket when one of the passes is its
+        dev = q[0][3].device
+        cur = torch.cuda.current_stream(dev)
+        where = self._helper_for(q) or cur
+        # the last pass of the main chain (the main forward's backward) runs while the side chain is idle: its input-gradient chain stays
+        # there, the merged weight gradients go next door (they ADD into the main bucket through the reduction table's atomics).  Whatever
+        # stream launches: it first waits for every OTHER stream a pass of the group was produced on.
+        origins = {it[7].cuda_stream: it[7] for it in q}
+        with torch.cuda.stream(where):
+            for sp, st in origins.items():
+                if sp != where.cuda_stream:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    where.wait_event(ev)
+            for it in q:
+                if it[7].cuda_stream != where.cuda_stream:
+                    it[1].record_stream(where)
+                    it[2].record_stream(where)
+            self._launch_here(q)
 
     def _helper_for(self, q):
         if not _WGRAD_MERGE_HELPER or len(q) < 2 or not DUAL_STREAM[0] or SIDE_GRADS[0] is None or _WGRAD_DEFER[0] is None:
@@ -847,13 +870,15 @@ class WgradMerger:
             return None
         dev = q[0][3].device
         helper = side_stream(dev, 0)
-        return None if helper.cuda_stream == torch.cuda.current_stream(dev).cuda_stream else helper
+        if helper.cuda_stream == torch.cuda.current_stream(dev).cuda_stream:
+            return None
+        return helper
 
     def _launch_here(self, q):
         if not conv_wgrad_merged(q):
             merger, _WGRAD_MERGE[0] = _WGRAD_MERGE[0], None
             try:
-                for kind, x, dy, w, dw, db, bf16 in q:   # no segmented form: per pass after all
+                for kind, x, dy, w, dw, db, bf16, _st in q:   # no segmented form: per pass after all
                     conv_wgrad(kind, x, dy, w, db is not None, dw, db, bf16=bf16)
             finally:
                 _WGRAD_MERGE[0] = merger

@@ -845,7 +845,7 @@ def test_wgrad_segments_equal_the_sum_of_per_pass_launches(dev, kind, cin, cout,
         for deferred in (False, True):
             gw, gb = torch.full_like(w, 0.5), torch.full((cout,), -0.25, device=dev)
             gw2, gb2 = gw.clone(), gb.clone()
-            items = [(kind, x, dy, w, gw, gb if want_bias else None, False) for x, dy in pairs]
+            items = [(kind, x, dy, w, gw, gb if want_bias else None, False, torch.cuda.current_stream()) for x, dy in pairs]
             if deferred:
                 with ops.deferred_wgrad_reductions() as pend:
                     assert ops.conv_wgrad_merged(items)
