@@ -875,10 +875,18 @@ class WgradMerger:
         return helper
 
     def _launch_here(self, q):
-        if not conv_wgrad_merged(q):
+        # passes of different geometry (the labelled and the unlabelled batch may differ in size) merge among their likes
+        groups = {}
+        for it in q:
+            groups.setdefault((tuple(it[1].shape), it[1].stride(), tuple(it[2].shape), it[2].stride()), []).append(it)
+        dw0, db0 = q[0][4], q[0][5]                # (every launch of the group adds into the first item's buffers: the main chain's when it has a pass)
+        for g in groups.values():
+            g = [(it[0], it[1], it[2], it[3], dw0, db0 if it[5] is not None else None) + tuple(it[6:]) for it in g]
+            if len(g) >= 2 and conv_wgrad_merged(g):
+                continue
             merger, _WGRAD_MERGE[0] = _WGRAD_MERGE[0], None
             try:
-                for kind, x, dy, w, dw, db, bf16, _st in q:   # no segmented form: per pass after all
+                for kind, x, dy, w, dw, db, bf16, _st in g:   # a single pass, or no segmented form for this layer: per pass after all
                     conv_wgrad(kind, x, dy, w, db is not None, dw, db, bf16=bf16)
             finally:
                 _WGRAD_MERGE[0] = merger

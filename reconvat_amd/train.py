@@ -324,7 +324,7 @@ class TrainStep:
             defer_g = os.environ.get('RV_DEFER_GEMM', '1') != '0' and getattr(self.model, 'defer_param_gemms', True)
             # (the merged launches do not need the reduction table; without it they stay on the launching chain)
             merge = self._merger if (os.environ.get('RV_WGRAD_MERGE', '1') != '0' and getattr(self.model, 'defer_wgrad_reductions', True)
-                                     and not ops.DETERMINISTIC[0]) else None
+                                     and not ops.DETERMINISTIC[0] and not self.bf16_backward) else None
             with ops.bf16_final_graphs(fwd=False, bwd=self.bf16_backward), ops.direct_param_grads(), \
                     (ops.deferred_wgrad_reductions() if defer else contextlib.nullcontext()) as pending, \
                     (ops.deferred_param_gemms() if defer_g else contextlib.nullcontext()) as pending_g, \
