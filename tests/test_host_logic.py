@@ -322,3 +322,43 @@ def test_numerics_emulation_helpers():
     e3 = float((eb.emulated(op, xi, w, 'bf16x3').double() - ref).abs().max() / ref.abs().max())
     e1 = float((eb.emulated(op, xi, w, 'bf16').double() - ref).abs().max() / ref.abs().max())
     assert e6 < 2e-6 and e6 < e3 < e1 and e1 > 1e-3
+
+
+def test_wgrad_merger_bookkeeping(monkeypatch):
+    """ops.WgradMerger without a device: what it launches when (the launch itself is stubbed).  A step that runs unmerged teaches it the number of passes per
+    gradient buffer and mode; afterwards passes register and the LAST one launches; finish() launches what is left; counts are re-learned every step."""
+    from reconvat_amd import ops
+    m = ops.WgradMerger()
+    launched = []
+    monkeypatch.setattr(m, '_launch', lambda key: launched.append((key, len(m.pending.pop(key)))))
+    # step 1 (mode two-chain): nothing known -> every pass is launched by the caller (submit returns False)
+    m.begin(True)
+    assert [m.submit('a', 1), m.submit('a', 2), m.submit('b', 1), m.submit('a', 3)] == [False] * 4
+    m.finish()
+    assert launched == [] and m.learned == {(True, 'a'): 3, (True, 'b'): 1}
+    # step 2: 'a' merges at its third pass, 'b' (a single pass) stays with the caller
+    m.begin(True)
+    assert m.submit('a', 1) and m.submit('a', 2) and launched == []
+    assert m.submit('b', 1) is False
+    assert m.submit('a', 3) and launched == [('a', 3)]
+    m.finish()
+    # another mode (one chain) has its own counts: learning again
+    m.begin(False)
+    assert m.submit('a', 1) is False
+    m.finish()
+    assert m.learned[(False, 'a')] == 1 and m.learned[(True, 'a')] == 3
+    # a step that comes up one pass short: finish() launches the two that arrived, and the count is re-learned
+    launched.clear()
+    m.begin(True)
+    assert m.submit('a', 1) and m.submit('a', 2) and launched == []
+    m.finish()
+    assert launched == [('a', 2)] and m.learned[(True, 'a')] == 2
+    # more passes than one launch takes (rv_conv_wgrad_seg: four segments): a launch every fourth pass, the rest at finish()
+    m.learned[(True, 'c')] = 6
+    launched.clear()
+    m.begin(True)
+    for i in range(6):
+        assert m.submit('c', i)
+    assert launched == [('c', 4)]
+    m.finish()
+    assert launched == [('c', 4), ('c', 2)]
