@@ -855,6 +855,14 @@ def main():
                     break
             # the committed trace describes the tile table (and library) it ran: with another table the kernel times are not this build's
             two_stream_ok = bool(two_stream) and two_stream.get('kernel_plan_table') == plans.digest()
+            # the same table of `bench.py --single-stream` (no co-running kernels stretching each other): the rocprofv3 figure the isolated
+            # HIP-event figure above has to agree with
+            single_stream = None
+            spath1 = os.path.join(ROOT, 'profiles', 'r05_single_stream_conv.json')
+            if os.path.exists(spath1):
+                with open(spath1) as fh:
+                    single_stream = json.load(fh)
+            single_stream_ok = bool(single_stream) and single_stream.get('kernel_plan_table') == plans.digest()
             if two_stream:
                 two_stream['kernel_plan_table_matches'] = two_stream_ok
             families = measure_families(eager, device)
@@ -881,6 +889,13 @@ def main():
                 'frac_two_stream': (round(conv_flops_total / (two_stream['conv_ms_per_step'] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
                                     if two_stream_ok else None),
                 'two_stream': two_stream,
+                'frac_single_stream_rocprof': (round(conv_flops_total / (single_stream['conv_ms_per_step'] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
+                                               if single_stream_ok else None),
+                'single_stream_rocprof': ({'conv_ms_per_step': single_stream['conv_ms_per_step'], 'conv_launches_per_step': single_stream['conv_launches_per_step'],
+                                           'kernel_ms_per_step': single_stream['kernel_ms_per_step'], 'kernel_plan_table': single_stream.get('kernel_plan_table'),
+                                           'git': single_stream.get('git'),
+                                           'source': 'profiles/r05_single_stream_conv.json (tools/profile_step.sh <tag> --single-stream; table: profiles/r05_step_kernel_stats_single_stream.txt)'}
+                                          if single_stream else None),
                 'kernel': 'conv3x3_lds_k / conv_mfma_k / wgrad_mfma_k family (all conv launches of one step)',
                 'conv_ms_source': 'isolated re-launch of every distinct conv launch of one step, HIP events on the launch stream, after the '
                                   f'timed loop, operands ROTATED through >= {min_sets} scratch sets totalling > 256 MiB per launch shape (no launch finds '
@@ -889,7 +904,7 @@ def main():
                 # the same family inside ONE eager single-stream step: every conv launch bracketed by two HIP events on the launch
                 # stream, operands as warm / cold as the step leaves them.  A bracket includes the dispatch gap behind the previous
                 # launch (`event_bracket_floor_us`: the same bracket around a one-workgroup kernel), so this is an upper bound of the
-                # rocprofv3 kernel-duration sum of the same step (profiles/r03_step_kernel_stats_single_stream.txt)
+                # rocprofv3 kernel-duration sum of the same step (profiles/r05_step_kernel_stats_single_stream.txt; `frac_single_stream_rocprof`)
                 'frac_in_situ': round(achieved_situ / MFMA_F32_PEAK_TFLOPS, 4), 'achieved_in_situ': round(achieved_situ, 2),
                 'conv_ms_in_situ': round(conv_situ_ms, 3), 'conv_launches_in_situ': conv_situ_n,
                 'event_bracket_floor_us': round(floor_us, 2),
