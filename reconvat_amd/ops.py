@@ -810,13 +810,19 @@ _WGRAD_MERGE_MAX = min(4, max(2, int(os.environ.get('RV_WGRAD_MERGE_MAX', '4')))
 
 
 class WgradMerger:
-    """The transcriber is back-propagated several times per training step (model/UNet_onset.py:383,117-146: main forward, the two VAT final
-    passes, the reconstruction branch) and every pass launched its own weight-gradient kernel per layer.  A weight gradient is a sum over
-    pixels, so the passes of one layer that add into the SAME gradient buffer (= run on the same stream) can be one launch over the
-    concatenation of their (x, dY) pairs -- the fixed cost of such a launch (prologue, accumulator fold, partial sums, reduction entry:
-    ~10 us of 35-60) is paid once: 3 x 49.9 -> 117 us for 64 -> 64 @160x57 at B = 8 per pass.
-    How many passes a buffer sees per step is LEARNED from a step that runs unmerged (per mode: one chain or two); afterwards a pass only
-    registers its operands and the last one launches.  `finish()` launches whatever is still pending (a step that took another path)."""
+    """The transcriber is back-propagated four times per training step (model/UNet_onset.py:383,117-146: the two VAT final passes, the
+    reconstruction branch's second transcription, the main forward) and every pass launched its own weight-gradient kernel per layer.  A
+    weight gradient is a sum over pixels, so the passes of one layer can be ONE launch over their (x, dY) pairs as segments
+    (rv_conv_wgrad_seg) -- the fixed cost of such a launch (prologue, accumulator fold, partial sums, reduction entry: ~10 us of 35-60)
+    is paid once: 4 x 49.9 -> 155 us for 64 -> 64 @160x57 at B = 8 per pass.
+    * A layer is known by the OFFSET of its gradient in the gradient bucket, so the side chain's pass (which adds into a twin of the
+      bucket) joins the main chain's; the sum goes to the main bucket.
+    * How many passes a layer sees per step is LEARNED from a step that runs unmerged (per mode: one chain or two); afterwards a pass
+      only registers its operands and the last one launches.  `finish()` launches whatever is still pending (a step that took another
+      path) and re-learns the counts.
+    * WHERE it launches decides whether it pays (profiles/r05_wgrad_merge_ab.txt): on the side stream, which is idle while the main chain
+      runs the main forward's backward -- merged on the main chain the same launches LOSE 0.14 ms/step, next door they win 0.5.  The
+      launching stream first waits for every other stream a segment was produced on."""
 
     def __init__(self):
         self.learned = {}          # (mode, key) -> launches per step
