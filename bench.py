@@ -432,10 +432,11 @@ def _cpu_steps(threads, budget_s, min_timed=3, max_timed=3, batch=1):
 
 
 def cpu_baseline():
-    """The oracle (CPU restatement pinned to the reference by tests/golden) timed on this host's cores: one labelled + one
-    unlabelled full-length segment per step (B = 1 + 1: a bounded sample of the B = 8 + 8 workload, same step definition:
-    front-end, 2 x VAT, forward, backward, Adam) at 8 threads, and the workload's own B = 8 + 8 at 8 / 32 / 64 threads (capped at
-    the physical core count); `value` is the fastest B = 8 + 8 run (the headline's own batch), every run is listed."""
+    """The oracle (CPU restatement pinned to the reference by tests/golden) timed on this host's cores at the workload's OWN batch
+    (B_l = B_ul = 8 full-length segments per step; same step definition: front-end, 2 x VAT, forward, backward, Adam), SURVEY 8(d):
+    1 warm-up + 3 timed steps at 8 threads and at 32 threads (the best count on every box of rounds 1-5), plus ONE run at all physical
+    cores -- listed even where it is slower; that run stops after its first timed step once it has used its 75 s budget.  `value` is
+    the fastest run, every run is listed."""
     try:
         import psutil
         physical = psutil.cpu_count(logical=False) or os.cpu_count()
@@ -443,23 +444,21 @@ def cpu_baseline():
         physical = os.cpu_count()
     prev = torch.get_num_threads()
     runs = []
-    per_step, timed = _cpu_steps(min(8, physical), budget_s=30.0)
-    runs.append({'threads': min(8, physical), 'batch': '1+1', 's_per_step': round(per_step, 3), 'timed_steps': timed,
-                 'audio_s_per_s': round(2 * SEG_SECONDS / per_step, 3)})
-    # the workload's own batch (B_l = B_ul = 8, SURVEY 8(d): "same synthetic inputs, same step definition") at 8, 32 and 64 threads
-    # (never more than the physical cores; all 128+ logical CPUs at once is an oversubscription artefact, 7x slower than 8 threads
-    # in rounds 1-3): 1 warm-up + 2 timed steps each
-    for n in sorted({min(8, physical), min(32, physical), min(64, physical)}):
-        per_step, timed = _cpu_steps(n, budget_s=20.0, min_timed=2, max_timed=2, batch=8)
+    for n in sorted({min(8, physical), min(32, physical)}):
+        per_step, timed = _cpu_steps(n, budget_s=1e9, min_timed=3, max_timed=3, batch=8)
         runs.append({'threads': n, 'batch': '8+8', 's_per_step': round(per_step, 3), 'timed_steps': timed,
                      'audio_s_per_s': round(16 * SEG_SECONDS / per_step, 3)})
+    if physical not in {r['threads'] for r in runs}:
+        per_step, timed = _cpu_steps(physical, budget_s=75.0, min_timed=1, max_timed=3, batch=8)
+        runs.append({'threads': physical, 'batch': '8+8', 's_per_step': round(per_step, 3), 'timed_steps': timed,
+                     'audio_s_per_s': round(16 * SEG_SECONDS / per_step, 3), 'note': 'all physical cores'})
     torch.set_num_threads(prev)
-    best = max((r for r in runs if r['batch'] == '8+8'), key=lambda r: r['audio_s_per_s'])     # `value`: the workload's own batch
+    best = max(runs, key=lambda r: r['audio_s_per_s'])
     return {'value': best['audio_s_per_s'], 'unit': 'audio-s/s', 'cores': best['threads'], 'kind': 'port',
             'physical_cores': physical, 'logical_cpus': os.cpu_count(), 'runs': runs,
             'sample': f'B_l + B_ul = {best["batch"]} full 327680-sample segments per step, UNet_Onset VAT+recon fp32 (oracle = CPU port pinned '
                       f'to the reference), median of {best["timed_steps"]} timed steps after 1 warm-up at torch.set_num_threads('
-                      f'{best["threads"]}) ({best["s_per_step"]:.2f} s/step); every (threads, batch) combination tried is in `runs`'}
+                      f'{best["threads"]}) ({best["s_per_step"]:.2f} s/step); every thread count tried (8, 32, all physical cores) is in `runs`'}
 
 
 def parity_leg(device):
@@ -529,7 +528,7 @@ def _time_steps(step, n):
 
 def deterministic_leg(args, device):
     """The same step with RV_DETERMINISTIC=1 (ops.DETERMINISTIC): parameter gradients folded in a fixed order instead of by fp32 atomics
-    (per-layer weight-gradient reductions, ticketed in-order split-K of the parameter-gradient GEMMs) -- what bit-exact replica / solo-run
+    (per-layer weight-gradient reductions, park + in-order fold split-K of the parameter-gradient GEMMs) -- what bit-exact replica / solo-run
     comparisons cost (tests/test_stress_gpu.py, tests/test_dp_gpu.py run in this mode).  A fresh model and capture; ms per step."""
     from reconvat_amd import ops as ops_
     prev = ops_.DETERMINISTIC[0]
@@ -702,9 +701,11 @@ def main():
         return self_launch(args)
     if args.gpus != world:
         raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE={world}')
+    from reconvat_amd import dp
+    # one slice of the host cores per rank, set before anything touches the GPU (next to the launcher's OMP_NUM_THREADS split)
+    rank_cpus = dp.pin_rank_cpus() if world > 1 else None
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
-    from reconvat_amd import dp
     device = dp.local_device() if world > 1 else torch.device('cuda', local)
     torch.cuda.set_device(device)
     if world > 1 or os.environ.get('RV_DP_FORCE_ALLREDUCE') == '1':
@@ -713,7 +714,7 @@ def main():
         dp.init(device)
 
     import reconvat_amd as ra
-    from reconvat_amd import plans, ops as ops_mod
+    from reconvat_amd import plans, ops as ops_mod, _lib as _lib_mod
     cls = ra.UNet_Onset if args.model == 'onset' else ra.UNet
     batch_l = args.batch if args.batch_l is None else args.batch_l
     model, opt, batch, batch_ul, step = make_rank_step(args.model, batch_l, args.batch, rank, device, graph=not args.no_graph,
@@ -738,7 +739,8 @@ def main():
         # parameters that step produced (written below, after the warm-up steps have been issued and synchronised)
         dump = {'rank': rank, 'world': world, 'audio_checksum_l': float(batch['audio'].double().sum()),
                 'audio_checksum_ul': float(batch_ul['audio'].double().sum()), 'cuda_seed': int(torch.cuda.initial_seed()),
-                'omp_num_threads': os.environ.get('OMP_NUM_THREADS'), 'device': str(device), 'pid': os.getpid()}
+                'omp_num_threads': os.environ.get('OMP_NUM_THREADS'), 'device': str(device), 'pid': os.getpid(),
+                'cpu_affinity': sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None, 'rank_cpus': rank_cpus}
 
         def dp_hook(when, o):
             if when + '_bucket' not in dump:
@@ -755,7 +757,10 @@ def main():
         if dump is not None and i == 0:
             grab_params()
     barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # K + 1 HIP events on the launch stream: event i sits behind step i, so consecutive differences are the per-step device times
+    # (`ms_per_step` = their median; the barrier-to-barrier wall clock of the same K steps stays the basis of `value`)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    ev0, ev1 = evs[0], evs[-1]
     ev0.record()
     t0 = time.perf_counter()
     # test instrumentation (tests/test_dp_gpu.py): this rank dies in the middle of the timed loop -- its peers are then blocked in the
@@ -766,16 +771,18 @@ def main():
             torch.cuda.synchronize()
             os._exit(17)
         step()
+        evs[i + 1].record()
         if dump is not None and i == 0:
             grab_params()
-    ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
     device_ms = ev0.elapsed_time(ev1)             # the same K steps on the device's own clock (HIP events on the launch stream)
+    per_step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+    median_ms = per_step_ms[len(per_step_ms) // 2] if len(per_step_ms) % 2 else 0.5 * (per_step_ms[len(per_step_ms) // 2 - 1] + per_step_ms[len(per_step_ms) // 2])
     if dp.active():
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed, median_ms], device=device, dtype=torch.float64)
         dp.all_reduce(t, dist.ReduceOp.MAX)
-        elapsed = t.item()
+        elapsed, median_ms = t[0].item(), t[1].item()
     loss = float(step.loss.item())
     nan_flag = int(model.vat_loss.nan_flag.item())
     loss_terms = {k: round(float(v), 6) for k, v in step.losses.items()}      # the 11 loss values of the last timed step
@@ -796,11 +803,15 @@ def main():
         os.makedirs(args.dp_dump, exist_ok=True)
         torch.save(dump, os.path.join(args.dp_dump, f'rank{rank}.pt'))
     ms = elapsed / args.steps * 1e3
+    assert _lib_mod.load().rv_source_digest().decode() == _lib_mod.source_digest(), 'stale libreconvat_hip.so'
     audio_s = world * (batch_l + args.batch) * SEG_SECONDS * args.steps / elapsed
 
     line = {
         'metric': 'training audio-sec/sec (node)', 'value': round(audio_s, 2), 'unit': 'audio-s/s', 'n_gpus': world,
-        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True,
+        # ms_per_step: MEDIAN of the K per-step device times (HIP events on the launch stream, MAX over ranks);
+        # mean_ms_per_step: barrier-to-barrier wall clock of the same K steps / K (MAX over ranks) -- what `value` is computed from
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(median_ms, 3), 'mean_ms_per_step': round(ms, 3),
+        'min_ms_per_step': round(per_step_ms[0], 3), 'max_ms_per_step': round(per_step_ms[-1], 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32' if not args.bf16_backward else 'f32 forward + power iteration, bf16-operand / f32-accumulate backward 3x3 convs (opt-in experiment)',
         'data': 'synthetic',
@@ -808,6 +819,9 @@ def main():
                                f'B_ul={args.batch} segments of 327680 samples (640 frames x 229 mel), Adam+StepLR, fp32',
                    'parallelism': f'dp{world}', 'hipgraph': used_graph, 'two_stream_schedule': not args.single_stream, 'labelled_only_audio_s_per_s': round(audio_s * batch_l / (batch_l + args.batch), 2),
                    'kernel_plan_table': plans.digest(), 'kernel_plan_mode': str(ops_mod.AUTOTUNE),
+                   # the library's own record of the sources it was built from; _lib.load() has already refused a library whose digest
+                   # differs from the sources next to it, the assertion repeats that for the record
+                   'source_digest': _lib_mod.load().rv_source_digest().decode(), 'source_digest_of_tree': _lib_mod.source_digest(),
                    'final_loss': round(loss, 5), 'vat_nan_flag': nan_flag, 'losses_last_step': loss_terms},
         # the same K steps timed by two HIP events on the launch stream (the record carries its own evidence that the device worked)
         'device_ms_per_step': round(device_ms / args.steps, 3),
@@ -835,7 +849,7 @@ def main():
             # tools/pmc_traffic.py over separate FETCH_SIZE / WRITE_SIZE runs of `bench.py --no-graph`, gfx950-corrected
             traffic, traffic_src, traffic_digest, two_stream = None, None, None, None
             traffic_fam = None
-            for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
+            for rnd in ('r06', 'r05', 'r04', 'r03', 'r02', 'r01'):
                 tpath = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_traffic.json')
                 if os.path.exists(tpath):
                     with open(tpath) as fh:
@@ -846,7 +860,7 @@ def main():
                     break
             # the conv fraction INSIDE the shipped two-stream schedule: rocprofv3 kernel-trace of the timed command, summed by
             # tools/rocpd_stats.py (committed table; a profiler cannot run inside this process)
-            for rnd in ('r05', 'r04'):
+            for rnd in ('r06', 'r05', 'r04'):
                 spath = os.path.join(ROOT, 'profiles', f'{rnd}_two_stream_conv.json')
                 if os.path.exists(spath):
                     with open(spath) as fh:
@@ -854,17 +868,22 @@ def main():
                     two_stream['source'] = f'profiles/{rnd}_two_stream_conv.json (tools/rocpd_stats.py --json over profiles/{rnd}_step_kernel_stats.txt\'s trace)'
                     break
             # the committed trace describes the tile table (and library) it ran: with another table the kernel times are not this build's
-            two_stream_ok = bool(two_stream) and two_stream.get('kernel_plan_table') == plans.digest()
+            # (and the SOURCES it was built from: rv_source_digest(), round 6)
+            src_digest = _lib_mod.load().rv_source_digest().decode()
+            two_stream_ok = bool(two_stream) and two_stream.get('kernel_plan_table') == plans.digest() and two_stream.get('source_digest') == src_digest
             # the same table of `bench.py --single-stream` (no co-running kernels stretching each other): the rocprofv3 figure the isolated
             # HIP-event figure above has to agree with
-            single_stream = None
-            spath1 = os.path.join(ROOT, 'profiles', 'r05_single_stream_conv.json')
-            if os.path.exists(spath1):
-                with open(spath1) as fh:
-                    single_stream = json.load(fh)
-            single_stream_ok = bool(single_stream) and single_stream.get('kernel_plan_table') == plans.digest()
+            single_stream, single_src = None, None
+            for rnd in ('r06', 'r05'):
+                spath1 = os.path.join(ROOT, 'profiles', f'{rnd}_single_stream_conv.json')
+                if os.path.exists(spath1):
+                    with open(spath1) as fh:
+                        single_stream = json.load(fh)
+                    single_src = f'profiles/{rnd}_single_stream_conv.json (tools/profile_step.sh <tag> --single-stream; table: profiles/{rnd}_step_kernel_stats_single_stream.txt)'
+                    break
+            single_stream_ok = bool(single_stream) and single_stream.get('kernel_plan_table') == plans.digest() and single_stream.get('source_digest') == src_digest
             if two_stream:
-                two_stream['kernel_plan_table_matches'] = two_stream_ok
+                two_stream['kernel_plan_table_matches'] = two_stream_ok      # (plan table AND source digest)
             families = measure_families(eager, device)
             if traffic_fam:
                 # measured HBM bytes (committed PMC passes) next to the algorithmic bytes each HBM-bound family is graded on
@@ -876,9 +895,20 @@ def main():
                         f['measured_gb'] = round(t['traffic_bytes'] / 1e9, 2)
                         if f['bound'] == 'hbm' and f['work_per_step']:
                             f['measured_over_algorithmic'] = round(t['traffic_bytes'] / 1e9 / f['work_per_step'], 3)
+            # `frac` / `achieved` describe the SHIPPED two-stream schedule: executed conv flops / the conv kernel time of
+            # the committed rocprofv3 trace of this very command when that trace ran this build's plan table; otherwise the live
+            # event-bracketed in-situ figure of this run (an upper bound of the kernel time).  The isolated re-launch figure measured live
+            # by this run is `frac_isolated` / `achieved_isolated`.
+            if two_stream_ok:
+                achieved_shipped = conv_flops_total / (two_stream['conv_ms_per_step'] * 1e-3) / 1e12
+                frac_src = 'frac_two_stream (committed rocprofv3 kernel trace of the shipped schedule, same plan table)'
+            else:
+                achieved_shipped = achieved_situ
+                frac_src = 'frac_in_situ (live HIP-event brackets inside one eager single-stream step; no committed trace of this plan table)'
             line['roofline'] = {
-                'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,
+                'bound': 'mfma', 'achieved': round(achieved_shipped, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(achieved_shipped / MFMA_F32_PEAK_TFLOPS, 4), 'frac_source': frac_src,
+                'frac_isolated': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'achieved_isolated': round(achieved, 2), 'traffic': traffic,
                 'traffic_scope': 'HBM bytes (FETCH_SIZE x2 + WRITE_SIZE) of all conv launches of one step; NOT measured by this run: '
                                  + str(traffic_src),
                 # the PMC pass ran the tile table with this digest; a mismatch means the committed traffic figure describes other tiles
@@ -894,7 +924,7 @@ def main():
                 'single_stream_rocprof': ({'conv_ms_per_step': single_stream['conv_ms_per_step'], 'conv_launches_per_step': single_stream['conv_launches_per_step'],
                                            'kernel_ms_per_step': single_stream['kernel_ms_per_step'], 'kernel_plan_table': single_stream.get('kernel_plan_table'),
                                            'git': single_stream.get('git'),
-                                           'source': 'profiles/r05_single_stream_conv.json (tools/profile_step.sh <tag> --single-stream; table: profiles/r05_step_kernel_stats_single_stream.txt)'}
+                                           'source': single_src}
                                           if single_stream else None),
                 'kernel': 'conv3x3_lds_k / conv_mfma_k / wgrad_mfma_k family (all conv launches of one step)',
                 'conv_ms_source': 'isolated re-launch of every distinct conv launch of one step, HIP events on the launch stream, after the '

@@ -26,6 +26,8 @@ extern "C" {
 
 int rv_abi_version(void);
 const char* rv_last_error(void);
+/* first 16 hex digits of the sha256 over the sources (reconvat_amd/csrc: *.hip, *.h, *.cpp) this library was built from */
+const char* rv_source_digest(void);
 
 /* ---- log-Mel front-end ------------------------------------------------------------------------
  * replaces nnAudio MelSpectrogram.forward / STFT.forward (model/Spectrogram.py:187-231, :443-461),

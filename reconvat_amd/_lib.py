@@ -22,6 +22,7 @@ F = ctypes.c_float
 SIGNATURES = {
     'rv_abi_version': (I, []),
     'rv_last_error': (ctypes.c_char_p, []),
+    'rv_source_digest': (ctypes.c_char_p, []),
     'rv_melspec_lognorm_fwd': (I, [P, L, I, I, P, P, P, P, P, I, I, I, I, I, P, I, P, P]),
     'rv_packed_weight_floats': (L, [I, I, I]),
     'rv_pack_weights': (I, [P, P, I, I, I, L, L, I, I, I, P]),
@@ -92,8 +93,21 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    # the library is git-ignored and ships prebuilt next to its sources: refuse one that was built from OTHER sources
+    # (an explicitly named experiment library -- RECONVAT_HIP_LIB: ablation / A-B builds of the tools -- or RV_SKIP_DIGEST_CHECK=1 is
+    # exempt; the in-tree default, i.e. everything the product, the tests, smoke() and bench.py load, never is)
+    built_from, tree = lib.rv_source_digest().decode(), source_digest()
+    if built_from != tree and not os.environ.get('RECONVAT_HIP_LIB') and os.environ.get('RV_SKIP_DIGEST_CHECK') != '1':
+        raise RuntimeError(f'{LIB_PATH} was built from sources with digest {built_from}, the sources in reconvat_amd/csrc have {tree}: '
+                           'rebuild it (`python reconvat_amd/build.py`)')
     _lib = lib
     return lib
+
+
+def source_digest():
+    """Digest of the kernel sources in the tree (reconvat_amd/build.py::source_digest); load() compares it with rv_source_digest()."""
+    from . import build
+    return build.source_digest()
 
 
 def last_error():

@@ -1,5 +1,6 @@
 """Build libreconvat_hip.so (gfx950 only) in-tree with hipcc.  No JIT cache: the .so lives next to the
 sources so it travels with the repo snapshot to the GPU box."""
+import hashlib
 import os
 import subprocess
 import sys
@@ -13,6 +14,19 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
 
+def source_digest():
+    """sha256 (first 16 hex digits) over every kernel / ABI source in csrc/ (names and contents, sorted): baked into the library as
+    rv_source_digest() and compared by reconvat_amd._lib.load() with the sources that travelled next to the .so."""
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith(('.hip', '.h', '.cpp')):
+            h.update(name.encode() + b'\0')
+            with open(os.path.join(CSRC, name), 'rb') as fh:
+                h.update(fh.read())
+            h.update(b'\0')
+    return h.hexdigest()[:16]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -24,13 +38,22 @@ def _compile(src):
     obj = os.path.join(CSRC, os.path.splitext(src)[0] + '.o')
     path = os.path.join(CSRC, src)
     deps = [path, os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_shared.h')]
-    if _stale(obj, deps):
-        cmd = [HIPCC] + FLAGS + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', path, '-o', obj]
+    extra, stale = [], _stale(obj, deps)
+    if src == 'api.cpp':                       # carries the digest of ALL sources: rebuilt whenever any of them changed
+        dig = source_digest()
+        extra = [f'-DRV_SOURCE_DIGEST="{dig}"']
+        side = obj + '.digest'
+        stale = stale or not os.path.exists(side) or open(side).read().strip() != dig
+    if stale:
+        cmd = [HIPCC] + FLAGS + extra + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', path, '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed for {src}:\n{r.stderr}')
         if r.stderr.strip():
             sys.stderr.write(r.stderr)
+        if src == 'api.cpp':
+            with open(obj + '.digest', 'w') as fh:
+                fh.write(extra[0].split('"')[1])
     return obj
 
 

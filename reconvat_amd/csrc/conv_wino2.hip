@@ -17,6 +17,7 @@
 // stage, so they never share the band's double buffer: either all chunks are resident, or they travel through a ring of three.
 // Tile geometry is per kernel, not per band (the tile -> LDS offsets do not depend on the band; only the validity of a row pair does).
 #include "conv_shared.h"
+#include <mutex>
 
 #ifndef RV_W2_SIDE
 #define RV_W2_SIDE 2
@@ -457,14 +458,14 @@ static size_t wino2_bytes(int NT, int TH, int W, int wslots) {
 
 template <int NT, int MTW, int NW, bool HALF>
 static int launch_wino2(const ConvLdsArgs& aa, dim3 grid, size_t lds, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    // (launches come from the autograd thread as well as from the main thread: once_flag, not a plain static bool)
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
         if (hipFuncSetAttribute((const void*)conv3x3_wino2_k<NT, MTW, NW, HALF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
             (void)hipGetLastError();
         if (hipFuncSetAttribute((const void*)conv3x3_wino2_k<NT, MTW, NW, HALF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
             (void)hipGetLastError();
-        attr_done = true;
-    }
+    });
     if (aa.c.bn_z) hipLaunchKernelGGL((conv3x3_wino2_k<NT, MTW, NW, HALF, true>), grid, dim3(NW * 64), lds, st, aa);
     else hipLaunchKernelGGL((conv3x3_wino2_k<NT, MTW, NW, HALF, false>), grid, dim3(NW * 64), lds, st, aa);
     return RV_OK;
@@ -536,8 +537,8 @@ int rv_launch_conv3x3_wino2(const ConvArgs& a0, int NT, int MTW, int nw, int hal
     RV_W2(1, 2, 4, false) RV_W2(2, 1, 4, false)
     if (nw == 12 && a0.bn_z) return RV_EUNSUPPORTED;       // (three waves per SIMD: no room for the fused BatchNorm-backward epilogue)
     if (NT == 1 && MTW == 1 && nw == 12 && half) {
-        static bool attr12 = false;
-        if (!attr12) { (void)hipFuncSetAttribute((const void*)conv3x3_wino2_k<1, 1, 12, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); attr12 = true; }
+        static std::once_flag attr12;
+        std::call_once(attr12, [] { (void)hipFuncSetAttribute((const void*)conv3x3_wino2_k<1, 1, 12, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); });
         hipLaunchKernelGGL((conv3x3_wino2_k<1, 1, 12, true, false>), grid, dim3(768), lds, st, aa);
         return RV_OK;
     }

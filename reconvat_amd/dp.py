@@ -38,6 +38,25 @@ def local_device():
     return torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
 
 
+def pin_rank_cpus(local_rank=None, local_world=None):
+    """Give this rank its own slice of the host cores (`os.sched_setaffinity`): rank r of n gets CPUs [r*k, (r+1)*k) of the process's
+    current affinity set, k = len // n -- next to the OMP_NUM_THREADS split of the launcher, so eight launch threads (and their
+    torch intra-op pools) do not migrate over each other.  Call it BEFORE anything touches the GPU (it is plain host state, but the
+    HIP runtime's helper threads inherit the mask of the thread that creates them).  Returns the sorted CPU list (or None when the
+    platform has no affinity API / the set is smaller than the rank count)."""
+    if not hasattr(os, 'sched_setaffinity'):
+        return None
+    r = int(os.environ.get('LOCAL_RANK', '0')) if local_rank is None else local_rank
+    n = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1'))) if local_world is None else local_world
+    cpus = sorted(os.sched_getaffinity(0))
+    k = len(cpus) // max(n, 1)
+    if n <= 1 or k < 1:
+        return cpus
+    mine = cpus[r * k:(r + 1) * k]
+    os.sched_setaffinity(0, mine)
+    return mine
+
+
 def init(device, long_wait_group=False):
     """Join the process group the launcher described (RANK / WORLD_SIZE / MASTER_*; rendezvous on 127.0.0.1 by default).  The
     training group keeps the DEFAULT collective timeout, so a rank that dies leaves its peers blocked for minutes, not hours;

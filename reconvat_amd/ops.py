@@ -272,6 +272,17 @@ def _channels(kind, w):
 
 
 _pack_cache = {}
+# Entries die with their OWNER (drop_packs_of / drop_packs_of_params).  Weights packed through the functional API or by modules that
+# are not _Base models have no owner: a bounded LRU is the fallback for those (re-inserting a key moves it to the young end; a live
+# model's entries are re-inserted by PackPlan.run() every step and by every lazy repack, so they are never the old end for long).
+_PACK_CACHE_MAX = int(os.environ.get('RV_PACK_CACHE_MAX', '2048'))
+
+
+def _pack_put(key, val):
+    _pack_cache.pop(key, None)
+    _pack_cache[key] = val
+    while len(_pack_cache) > _PACK_CACHE_MAX:
+        del _pack_cache[next(iter(_pack_cache))]
 
 
 def _pack(kind, w, which):
@@ -307,7 +318,7 @@ def _pack(kind, w, which):
     n = lib.rv_packed_weight_floats(taps, kdim, ndim)
     out = torch.empty(n, device=w.device, dtype=torch.float32)
     call('rv_pack_weights', ptr(w), ptr(out), taps, kdim, ndim, s_k, s_n, flip, scatter, plain, stream())
-    _pack_cache[key] = (tag, out, w, (taps, kdim, ndim, s_k, s_n, flip, scatter, plain))
+    _pack_put(key, (tag, out, w, (taps, kdim, ndim, s_k, s_n, flip, scatter, plain)))
     return out
 
 
@@ -321,7 +332,7 @@ def _pack_rel(rel, f):
     args = (1, 31, f, 1, 31, 0, 0, 1)            # out[w*F + c] = rel[c*31 + w]
     out = torch.empty(31 * f, device=rel.device, dtype=torch.float32)
     call('rv_pack_weights', ptr(rel), ptr(out), *args, stream())
-    _pack_cache[key] = (tag, out, rel, args)
+    _pack_put(key, (tag, out, rel, args))
     return out
 
 
@@ -339,7 +350,7 @@ def _lin_t(w2d):
     args = (1, k, n, 1, k, 0, 0, 1)              # out[kk*n + nn] = w[kk + nn*k]
     out = torch.empty(k * n, device=w2d.device, dtype=torch.float32)
     call('rv_pack_weights', ptr(w2d), ptr(out), *args, stream())
-    _pack_cache[key] = (tag, out, w2d, args)
+    _pack_put(key, (tag, out, w2d, args))
     return out.view(k, n)
 
 
@@ -372,7 +383,7 @@ class PackPlan:
             return
         call('rv_pack_table_run', ptr(self.table), self.count, self.total_blocks, stream())
         for key, (_, out, w, a) in self.entries:
-            _pack_cache[key] = ((_EPOCH[0], w._version, tuple(w.shape)), out, w, a)
+            _pack_put(key, ((_EPOCH[0], w._version, tuple(w.shape)), out, w, a))
 
 
 _FWD_MODE = {'c3': 0, 't3': 0, 'c1': 1, 'down': 2, 'up': 3}
@@ -397,6 +408,9 @@ AUTOTUNE = plans.default_mode()
 # loss term and posteriorgram bit-identical and moves the gradients by 0.6 % -- so only 'bwd' is meant to be used.
 BF16 = {'fwd': False, 'bwd': False}
 ALGO_BF16 = 1 << 20
+# algo families (bits 8..11) that are fp32 Winograd tiles -- conv3x3_wino_k (0x6 / 0xA / 0xC) and the software-pipelined conv3x3_wino2_k
+# (0x8 / 0x9 / 0xB / 0xD): no bf16-operand form, a bf16 launch of such a shape runs the library-default direct tile instead
+WINOGRAD_FAMILIES = (6, 8, 9, 10, 11, 12, 13)
 
 
 class bf16_final_graphs:
@@ -437,7 +451,7 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
         if algo < 0 and AUTOTUNE == 'table':
             hit = plans.lookup_conv(base_key)
             algo = hit[0] if hit is not None else 0
-            if bf16 and (algo >> 8) & 15 in (6, 10, 12):
+            if bf16 and (algo >> 8) & 15 in WINOGRAD_FAMILIES:
                 algo = 0                        # fp32 Winograd tile: the bf16 launch of this shape runs the library-default direct tile
             _algo_cache[key] = algo
             if hit is not None and not hit[1] and algo != 0:
@@ -538,7 +552,7 @@ def _conv_call(mode, x, ild, bb, h, wd, cin, out, old, ho, wo, cout, wpack, bias
             if invoke('rv_conv_fwd', *args, algo | (ALGO_BF16 if bf16 else 0), ptr(stats), *tail, stream()) == 0:
                 return
             algo = _algo_cache[key] = 0         # the borrowed tile does not fit this batch size: library default
-    if bf16 and (algo >> 8) & 15 in (6, 10, 12):
+    if bf16 and (algo >> 8) & 15 in WINOGRAD_FAMILIES:
         algo = 0                                # (forced / on-line tuned Winograd tile: no bf16 form -> library-default direct tile)
     if bf16 and algo not in (1,) and (algo >> 8) & 15 != 1:
         algo |= ALGO_BF16                       # (the library ignores the bit outside the persistent 3x3 kernel / 16-channel chunks)
@@ -828,9 +842,19 @@ class WgradMerger:
         self.learned = {}          # (mode, key) -> launches per step
         self.mode = None
         self.counts, self.pending = {}, {}
+        self.merged_launches = 0   # segmented launches of the current step (0 in a learning step)
+        self.seen = set()          # modes whose pass counts have been learned (a finished step of that mode)
 
     def begin(self, mode):
-        self.mode, self.counts, self.pending = mode, {}, {}
+        self.mode, self.counts, self.pending, self.merged_launches = mode, {}, {}, 0
+
+    def knows(self, mode):
+        """True once a step of this mode (one chain / two chains) has run unmerged, i.e. the next step of that mode merges."""
+        return mode in self.seen
+
+    def abort(self):
+        """An exception left the step: drop the parked (x, dY) references instead of pinning them until the next step."""
+        self.pending, self.counts = {}, {}
 
     def submit(self, key, item):
         self.counts[key] = self.counts.get(key, 0) + 1
@@ -889,6 +913,7 @@ class WgradMerger:
         for g in groups.values():
             g = [(it[0], it[1], it[2], it[3], dw0, db0 if it[5] is not None else None) + tuple(it[6:]) for it in g]
             if len(g) >= 2 and conv_wgrad_merged(g):
+                self.merged_launches += 1
                 continue
             merger, _WGRAD_MERGE[0] = _WGRAD_MERGE[0], None
             try:
@@ -902,6 +927,7 @@ class WgradMerger:
             self._launch(key)
         for key, n in self.counts.items():
             self.learned[(self.mode, key)] = n
+        self.seen.add(self.mode)
 
 
 class wgrad_merging:
@@ -915,8 +941,10 @@ class wgrad_merging:
             self.merger.begin(self.mode)
         return self.merger
 
-    def __exit__(self, *exc):
+    def __exit__(self, exc_type, *exc):
         _WGRAD_MERGE[0] = self.prev
+        if exc_type is not None and self.merger is not None:
+            self.merger.abort()
 
 
 # --------------------------------------------------------------------------------------------

@@ -306,12 +306,21 @@ class TrainStep:
             ops.prepare_wgrad_tables(max(4, streams))          # one table per stream
             ops.prepare_gemm_tables(max(8, 2 * streams))       # one per stream and operand orientation
 
+    def _dual_now(self):
+        """Whether the next _fwd_bwd() runs the two-chain schedule."""
+        return bool(self.dual_stream and self._dual_ready and self.batch_ul is not None and self.VAT)
+
+    def _merging(self):
+        """Whether the next _fwd_bwd() hands its weight gradients to the merger (one launch per layer and step)."""
+        return bool(os.environ.get('RV_WGRAD_MERGE', '1') != '0' and getattr(self.model, 'defer_wgrad_reductions', True)
+                    and not ops.DETERMINISTIC[0] and not self.bf16_backward)
+
     def _fwd_bwd(self):
         self.opt.zero_grad()
         ops.ARENA.begin_step(self.opt.flat_grad.device)
         ops.bump_drop_epoch(self.opt.flat_grad.device)
         prev_dual, prev_side = ops.DUAL_STREAM[0], ops.SIDE_GRADS[0]
-        dual = self.dual_stream and self._dual_ready and self.batch_ul is not None and self.VAT
+        dual = self._dual_now()
         ops.DUAL_STREAM[0] = dual
         if dual:
             dev = self.opt.flat_grad.device
@@ -323,8 +332,7 @@ class TrainStep:
             defer = os.environ.get('RV_DEFER_WGRAD', '1') != '0' and getattr(self.model, 'defer_wgrad_reductions', True) and not ops.DETERMINISTIC[0]
             defer_g = os.environ.get('RV_DEFER_GEMM', '1') != '0' and getattr(self.model, 'defer_param_gemms', True)
             # (the merged launches do not need the reduction table; without it they stay on the launching chain)
-            merge = self._merger if (os.environ.get('RV_WGRAD_MERGE', '1') != '0' and getattr(self.model, 'defer_wgrad_reductions', True)
-                                     and not ops.DETERMINISTIC[0] and not self.bf16_backward) else None
+            merge = self._merger if self._merging() else None
             with ops.bf16_final_graphs(fwd=False, bwd=self.bf16_backward), ops.direct_param_grads(), \
                     (ops.deferred_wgrad_reductions() if defer else contextlib.nullcontext()) as pending, \
                     (ops.deferred_param_gemms() if defer_g else contextlib.nullcontext()) as pending_g, \
@@ -381,6 +389,10 @@ class TrainStep:
                 # after the first step every weight is packed (nothing changes them here) and every conv shape is
                 # tuned: from now on the step may use the second stream
                 self._dual_ready = True
+            # the weight-gradient merger learns the pass counts of a mode (one chain / two chains) from one unmerged step of that mode:
+            # keep warming up until the mode about to be captured has been seen, or the graph would replay unmerged forever
+            while self._merging() and not self._merger.knows(self._dual_now()):
+                self._fwd_bwd()
         torch.cuda.current_stream().wait_stream(s)
         for b, v in zip(state, saved):
             b.copy_(v)

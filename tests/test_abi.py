@@ -43,10 +43,24 @@ def test_ctypes_signatures_match_header(built):
         assert len(_lib.SIGNATURES[name][1]) == n, name
     lib = _lib.load()
     assert lib.rv_abi_version() == 1
+    # the library records the sources it was built from; load() refuses a library built from other sources (next test)
+    assert lib.rv_source_digest().decode() == _lib.source_digest() and len(_lib.source_digest()) == 16
     assert lib.rv_packed_weight_floats(9, 16, 16) == (9 + 16) * 1 * 1 * 64 * 4      # nine tap fragments + the 16 Winograd fragments
     assert lib.rv_packed_weight_floats(9, 8, 16) == 9 * 1 * 1 * 64 * 2
     assert lib.rv_packed_weight_floats(9, 1, 16) == 9 * 16
     assert lib.rv_reduce_workspace_bytes(4096) == 8
+
+
+def test_stale_library_is_refused(built, monkeypatch):
+    """A prebuilt .so whose baked-in source digest differs from the sources next to it must not load (the library is
+    git-ignored and ships prebuilt; nothing else ties it to the sources)."""
+    from reconvat_amd import _lib, build
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(build, 'source_digest', lambda: '0123456789abcdef')
+    monkeypatch.delenv('RECONVAT_HIP_LIB', raising=False)
+    monkeypatch.delenv('RV_SKIP_DIGEST_CHECK', raising=False)
+    with pytest.raises(RuntimeError, match='rebuild it'):
+        _lib.load()
 
 
 def test_no_cpu_fallback():

@@ -50,7 +50,7 @@ def test_two_replicas_line(dev, two_ranks):
         assert r['allreduce_calls'] == STEPS + WARMUP == r['optimizer_steps'] and r['world'] == 2
     assert line['config']['vat_nan_flag'] == 0
     # whole-job aggregate over both ranks: 2 ranks x (2 + 2) segments x 20.48 s per step
-    assert abs(line['value'] - 2 * 2 * BATCH * 20.48 / (line['ms_per_step'] * 1e-3)) <= 1e-3 * line['value']
+    assert abs(line['value'] - 2 * 2 * BATCH * 20.48 / (line['mean_ms_per_step'] * 1e-3)) <= 1e-3 * line['value']
 
 
 def test_ranks_differ_before_and_agree_after_the_collective(dev, two_ranks):
@@ -120,7 +120,7 @@ def test_eight_rank_rehearsal_on_one_gpu(dev, tmp_path):
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 8 and line['dp_ranks'] == 8 and line['dp_backend'] == 'gloo' and line['replicas_equal'] is True
     assert line['dp_allreduce_calls'] == 3 == line['optimizer_steps']
-    assert abs(line['value'] - 8 * 2 * 20.48 / (line['ms_per_step'] * 1e-3)) <= 1e-3 * line['value']        # whole-job aggregate over 8 ranks
+    assert abs(line['value'] - 8 * 2 * 20.48 / (line['mean_ms_per_step'] * 1e-3)) <= 1e-3 * line['value']        # whole-job aggregate over 8 ranks
     ranks = [torch.load(os.path.join(out, f'rank{r}.pt'), map_location='cpu') for r in range(8)]
     assert [r['rank'] for r in ranks] == list(range(8)) and all(r['world'] == 8 for r in ranks)
     assert len({r['pid'] for r in ranks}) == 8                                                # eight processes
@@ -128,6 +128,14 @@ def test_eight_rank_rehearsal_on_one_gpu(dev, tmp_path):
     assert len({r['cuda_seed'] for r in ranks}) == 8                                          # eight VAT noise streams
     want_threads = str(max(1, (os.cpu_count() or 8) // 8))
     assert all(r['omp_num_threads'] == want_threads for r in ranks), [r['omp_num_threads'] for r in ranks]
+    # per-rank CPU affinity (reconvat_amd.dp.pin_rank_cpus, set before the rank touches the GPU): eight disjoint, equally sized slices
+    # of the launcher's own CPU set
+    have = sorted(os.sched_getaffinity(0))
+    k = len(have) // 8
+    if k >= 1:
+        for r in ranks:
+            assert r['cpu_affinity'] == have[r['rank'] * k:(r['rank'] + 1) * k] == r['rank_cpus'], (r['rank'], r['cpu_affinity'])
+        assert len({c for r in ranks for c in r['cpu_affinity']}) == 8 * k
     total = sum(r['pre_bucket'].double() for r in ranks)
     for r in ranks:
         assert r['allreduce_calls'] == 3 and r['optimizer_steps'] == 3

@@ -656,6 +656,41 @@ def test_conv3x3_bf16_operands_vs_torch(dev, cin, cout, h, w, algo):
     assert 2e-4 < d32 < 2e-2, d32
 
 
+@pytest.mark.parametrize('algo', [0x811, 0x911, 0xb12, 0x611, 0xa11])
+def test_bf16_launch_of_a_winograd_plan_runs_a_bf16_kernel(dev, algo, monkeypatch):
+    """a shape whose plan entry is an fp32 Winograd tile (conv3x3_wino_k 0x6 / 0xA / 0xC, conv3x3_wino2_k 0x8 / 0x9 / 0xB / 0xD)
+    has no bf16 form; a bf16 launch through the host wrapper must fall back to the library-default direct tile WITH the bf16 bit --
+    not keep the Winograd algo, whose launcher strips the bit and runs fp32 (a silent no-op that bench.py would grade as bf16)."""
+    from reconvat_amd import ops
+    monkeypatch.setenv('RV_FORCE_ALGO', hex(algo))
+    assert (algo >> 8) & 15 in ops.WINOGRAD_FAMILIES
+    B, h, w, cin, cout = 2, 24, 57, 64, 64
+    x = rnd(B, h, w, cin, seed=1).to(dev)
+    wt = (rnd(cout, cin, 3, 3, seed=2) * (1.0 / (9 * cin) ** 0.5)).to(dev)
+    bias = rnd(cout, seed=3).to(dev)
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    ref_bf = F.conv2d(rb(x).cpu().permute(0, 3, 1, 2), rb(wt).cpu(), bias.cpu(), padding=1).permute(0, 2, 3, 1)
+    ref_32 = F.conv2d(x.cpu().permute(0, 3, 1, 2), wt.cpu(), bias.cpu(), padding=1).permute(0, 2, 3, 1)
+    seen = []
+    from reconvat_amd import _lib
+
+    def hook(name, args, fn):
+        if name == 'rv_conv_fwd':
+            seen.append(args[15])
+        return fn(*args)
+    monkeypatch.setattr(_lib, 'HOOK', [hook])
+    out = torch.empty(B, h, w, cout, device=dev)
+    ops.conv_forward_into('c3', x, wt, bias, out, bf16=True)
+    out32 = torch.empty(B, h, w, cout, device=dev)
+    ops.conv_forward_into('c3', x, wt, bias, out32, bf16=False)
+    torch.cuda.synchronize()
+    assert len(seen) == 2 and seen[0] & ops.ALGO_BF16 and (seen[0] >> 8) & 15 not in ops.WINOGRAD_FAMILIES, [hex(a) for a in seen]
+    assert seen[1] == algo                                     # the fp32 launch keeps its Winograd tile
+    assert rel_err(out, ref_bf) < 2e-5                         # bf16-rounded operands, fp32 accumulate: the bf16 matrix instructions ran
+    assert 2e-4 < rel_err(out, ref_32) < 2e-2
+    assert rel_err(out32, ref_32) < 1e-5
+
+
 @pytest.mark.parametrize('kind,cin,cout,h,w', [('c3', 16, 16, 24, 229), ('c3', 32, 32, 20, 114), ('t3', 96, 48, 12, 57), ('c3', 64, 128, 10, 28),
                                               ('t3', 192, 96, 10, 28), ('c3', 48, 24, 9, 114), ('c3', 16, 32, 7, 33)])
 def test_wgrad3x3_bf16_operands_vs_torch(dev, kind, cin, cout, h, w):

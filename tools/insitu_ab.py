@@ -32,7 +32,7 @@ def measure(variants, reps=3, verbose=True):
                                capture_output=True, text=True, env=env, cwd=ROOT)
             if r.returncode != 0:
                 raise SystemExit(f'{name}: bench.py failed\n{r.stderr[-2000:]}')
-            ms = json.loads(r.stdout.strip().split('\n')[-1])['ms_per_step']
+            ms = json.loads(r.stdout.strip().split('\n')[-1])['mean_ms_per_step']
             times[name].append(ms)
             if verbose:
                 print(f'{name:24s} {ms:.3f} ms', flush=True)

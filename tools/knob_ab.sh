@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 for rep in $(seq 1 ${REPS:-4}); do
   for cfg in "$@"; do
     if [ "$cfg" = "-" ]; then envs=""; else envs="$cfg"; fi
-    ms=$(env $envs python bench.py --no-cpu-baseline --no-roofline --no-parity 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])")
+    ms=$(env $envs python bench.py --no-cpu-baseline --no-roofline --no-parity 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['mean_ms_per_step'])")
     echo "[${cfg// /,}] $ms"
   done
 done | sort | awk '{k=$1; a[k]=a[k]" "$2} END {for (k in a) print k, a[k]}' | sort

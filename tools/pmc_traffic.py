@@ -12,6 +12,14 @@ import os
 import sys
 from collections import defaultdict
 
+def _src_digest():
+    """Digest of the kernel sources the profiled library was built from (reconvat_amd/build.py::source_digest)."""
+    import os as _os
+    sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+    from reconvat_amd import build as _b
+    return _b.source_digest()
+
+
 CONV = ('conv3x3_lds_k', 'conv3x3_wino_k', 'conv3x3_wino2_k', 'conv_mfma_k', 'conv_small_k', 'conv_narrow_out_k', 'conv_cin12_k', 'wgrad_mfma_k', 'wgrad_wino_k', 'wgrad_small_k', 'wgrad_small_sw_k', 'wgrad_cin1_k', 'wgrad_reduce_k',
         'wgrad_reduce_table_k')
 
@@ -103,7 +111,7 @@ def main():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from reconvat_amd import plans
     res = {'scope': 'all conv-family launches of one optimiser step (eager launches, B_l=B_ul=8)', 'git': git,
-           'kernel_plan_table': plans.digest(),         # the tile table these launches ran (bench.py flags a mismatch with its own)
+           'kernel_plan_table': plans.digest(), 'source_digest': _src_digest(),         # the tile table these launches ran (bench.py flags a mismatch with its own)
            'fetch_bytes': fetch, 'write_bytes': write, 'traffic_bytes': fetch + write,
            'launches': out['FETCH_SIZE']['launches'],
            'families': families,          # every family of the step (eager single-stream launches), gfx950-corrected like the conv total

@@ -15,6 +15,14 @@ import re
 import sqlite3
 import sys
 
+def _src_digest():
+    """Digest of the kernel sources the profiled library was built from (reconvat_amd/build.py::source_digest)."""
+    import os as _os
+    sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+    from reconvat_amd import build as _b
+    return _b.source_digest()
+
+
 FAMILIES = [
     ('conv3x3 fwd+dgrad (MFMA)', ('conv3x3_lds_k', 'conv3x3_wino_k', 'conv3x3_wino2_k')),
     ('conv direct 3x3/1x1/2x2 (MFMA / HBM)', ('conv_mfma_k',)),
@@ -74,7 +82,7 @@ def main():
         from reconvat_amd import plans
         doc = {'steps': steps, 'wall_ms_per_step': (hi - lo) / 1e6 / steps, 'kernel_ms_per_step': total / 1e6 / steps,
                # the tile table (and commit) the traced command ran: bench.py only uses the conv time of a trace whose table is its own
-               'kernel_plan_table': plans.digest(), 'git': os.environ.get('RV_GIT_SHA', 'not recorded'),
+               'kernel_plan_table': plans.digest(), 'source_digest': _src_digest(), 'git': os.environ.get('RV_GIT_SHA', 'not recorded'),
                'launches_per_step': sum(r[1] for r in rows) / steps,
                'conv_ms_per_step': sum(fam[f][1] for f in conv_fams) / 1e6 / steps,
                'conv_launches_per_step': sum(fam[f][0] for f in conv_fams) / steps,
