@@ -206,3 +206,23 @@ def fixture_labels(b, t, tag='lab'):
 def fixture_noise(shape, tag='d0'):
     """Bell-shaped stand-in for torch.randn_like (std 1, bounded)."""
     return hashed_normalish(tag, shape, 1.0)
+
+
+# ---- the multi-step trajectory fixture (tests/golden/trajectory.npz, generator g_trajectory of tests/golden/make_golden.py) ----------
+# K iterations of the reference's train_VAT_model (model/helper_functions.py:570-615): Adam(lr), StepLR(step_size, gamma), post-step
+# clip, `n_l` labelled / `n_ul` unlabelled batches cycled out of phase, one injected VAT noise pair per iteration (mode `radv`).
+TRAJ = dict(K=6, B=2, T=64, N=128, lr=1e-3, step_size=2, gamma=0.7, clip=3.0, n_l=3, n_ul=2)
+
+
+def trajectory_inputs(mode=None):
+    """The closed-form inputs of the trajectory fixture (shared by the generator, the CPU oracle test and the GPU test)."""
+    c = TRAJ
+
+    def batch(tag):
+        onset, frame = fixture_labels(c['B'], c['T'], tag)
+        return {'audio': fixture_audio(c['B'], c['T'] * 512, tag), 'onset': onset, 'frame': frame}
+    lbs = [batch(f'traj_L{i}') for i in range(c['n_l'])]
+    ubs = [batch(f'traj_UL{i}') for i in range(c['n_ul'])]
+    noises = [(fixture_noise((c['B'], 1, c['T'], 229), f'traj_ul_{i}'), fixture_noise((c['B'], 1, c['T'], 229), f'traj_l_{i}'))
+              for i in range(c['K'])]
+    return lbs, ubs, noises

@@ -311,13 +311,18 @@ def g_lds_spread():
             bl, bul = _batch(2, T, 'L'), _batch(2, T, 'UL')
         noises = [fx.fixture_noise((2, 1, T, 229), n) for n in ntags]
         runs = {}
-        for name, dtype, threads in (('f32_8t', torch.float32, 8), ('f32_1t', torch.float32, 1), ('f64', torch.float64, 8)):
+        # round 6: the 2- and 4-thread fp32 runs as well -- a FOUR-sample estimate of the reference's own noise
+        # (1, 2, 4 threads and fp64 against the 8-thread golden) instead of a two-sample one; `_spread2` keeps the two-sample figure
+        for name, dtype, threads in (('f32_8t', torch.float32, 8), ('f32_1t', torch.float32, 1), ('f64', torch.float64, 8),
+                                     ('f32_2t', torch.float32, 2), ('f32_4t', torch.float32, 4)):
             pr, lr, sr = _ref_losses(kind, True, True, bl, bul, noises, dtype=dtype, threads=threads)
             runs[name] = (pr, lr)
             out[f'{tag}_{name}'] = np.array([float(v) for v in lr.values()], dtype=np.float64)
         out[f'{tag}_keys'] = np.array(list(runs['f32_8t'][1].keys()))
         base = out[f'{tag}_f32_8t']
-        spread = np.maximum(np.abs(out[f'{tag}_f32_1t'] - base), np.abs(out[f'{tag}_f64'] - base)) / np.maximum(np.abs(base), 1e-12)
+        den = np.maximum(np.abs(base), 1e-12)
+        out[f'{tag}_spread2'] = np.maximum(np.abs(out[f'{tag}_f32_1t'] - base), np.abs(out[f'{tag}_f64'] - base)) / den
+        spread = np.max([np.abs(out[f'{tag}_{n}'] - base) for n in ('f32_1t', 'f32_2t', 'f32_4t', 'f64')], axis=0) / den
         out[f'{tag}_spread'] = spread
         print(tag, {k: f'{s_:.1e}' for k, s_ in zip(out[f'{tag}_keys'], spread)})
         if T == 640:
@@ -336,7 +341,8 @@ def g_lds_spread():
         x = fx.fixture_spec(2, 64, 'spec_vat')
         d0 = fx.fixture_noise(x.shape, 'd0_' + kind)
         vals = {}
-        for name, dtype, threads in (('f32_8t', torch.float32, 8), ('f32_1t', torch.float32, 1), ('f64', torch.float64, 8)):
+        for name, dtype, threads in (('f32_8t', torch.float32, 8), ('f32_1t', torch.float32, 1), ('f64', torch.float64, 8),
+                                     ('f32_2t', torch.float32, 2), ('f32_4t', torch.float32, 4)):
             torch.set_num_threads(threads)
             net, _ = build_ref(kind, False, xi=1e-6, eps=2.0)
             if dtype == torch.float64:
@@ -351,7 +357,8 @@ def g_lds_spread():
             vals[name] = np.array([float(lds['frame']), float(lds['onset'])] if kind == 'onset' else [float(lds)])
         base = vals['f32_8t']
         out[f'vat_{kind}_f32_8t'] = base
-        out[f'vat_{kind}_spread'] = np.maximum(np.abs(vals['f32_1t'] - base), np.abs(vals['f64'] - base)) / np.abs(base)
+        out[f'vat_{kind}_spread2'] = np.maximum(np.abs(vals['f32_1t'] - base), np.abs(vals['f64'] - base)) / np.abs(base)
+        out[f'vat_{kind}_spread'] = np.max([np.abs(vals[n] - base) for n in ('f32_1t', 'f32_2t', 'f32_4t', 'f64')], axis=0) / np.abs(base)
         print('vat', kind, out[f'vat_{kind}_spread'])
     save('lds_spread', **out)
 
@@ -551,6 +558,114 @@ def g_train_step():
         out[f'{kind}_lr'] = opt.param_groups[0]['lr']
         out[f'{kind}_nograd'] = np.array([k for k, p in named.items() if p.grad is None])
     save('train_step', **out)
+
+
+TRAJ = fx.TRAJ
+trajectory_inputs = fx.trajectory_inputs
+
+
+def g_trajectory():
+    """K = 6 iterations of the REFERENCE's own train_VAT_model (model/helper_functions.py:570-615) -- torch Adam, StepLR(step_size = 2:
+    two decay boundaries are crossed), post-step clip_grad_norm_, `cycle`d loaders -- at B = 2, T = 64, reconstruction on, both models,
+    in the two modes in which the reference's step is deterministic: `novat` (VAT=False: run_on_batch(batch, None, False)) and `radv`
+    (VAT on with n_power = 0: the injected noise goes straight into r_adv, all eleven loss terms incl. both LDS branches).  Each at 8
+    threads fp32 (the reference as shipped) and in fp64 (the yardstick: a product trajectory is held to e <= 2 x the reference's own
+    fp32-vs-fp64 drift + 1e-3).  Stored: the loss terms and the learning rate of every iteration, and after the sixth step (norm,
+    strided sample) of every parameter and of Adam's exp_avg / exp_avg_sq, every BatchNorm running_mean / running_var in full and
+    num_batches_tracked.  The oracle is run through the same six steps and must meet the product's bar."""
+    c = TRAJ
+    out = {}
+    real_randn_like = torch.randn_like
+    K, N = c['K'], c['N']
+
+    class Loader(list):
+        batch_size = c['B']
+    for kind in ('onset', 'frame'):
+        for mode in ('novat', 'radv'):
+            lbs, ubs, noises = trajectory_inputs(mode)
+            tag = f'{kind}_{mode}'
+            for name, dtype in (('f32', torch.float32), ('f64', torch.float64)):
+                torch.set_num_threads(8)
+                net, _ = build_ref(kind, True)
+                if dtype == torch.float64:
+                    net = net.double()
+                cast = lambda d: {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()}
+                opt = torch.optim.Adam(net.parameters(), c['lr'])
+                sched = torch.optim.lr_scheduler.StepLR(opt, step_size=c['step_size'], gamma=c['gamma'])
+                rec = {'losses': [], 'lr': []}
+                orig = net.run_on_batch
+
+                def wrapped(b, bu, vat, _orig=orig, _rec=rec, _opt=opt):
+                    _rec['lr'].append(_opt.param_groups[0]['lr'])            # the rate this iteration's optimizer.step() will use
+                    pr, lr_, sp = _orig(b, bu, vat)
+                    _rec['losses'].append([float(v.detach()) for v in lr_.values()])
+                    _rec['keys'] = list(lr_.keys())
+                    return pr, lr_, sp
+                net.run_on_batch = wrapped
+                seq = [n.to(dtype) for pair in noises for n in pair]           # per iteration: unlabelled first, labelled second
+
+                def fake(t, **kw):
+                    d = seq.pop(0).clone()
+                    return d.requires_grad_(True) if kw.get('requires_grad') else d
+                torch.randn_like = fake
+                try:
+                    if mode == 'radv':
+                        net.vat_loss.n_power = 0
+                    ref.train_VAT_model(net, K, 1, Loader([cast(b) for b in lbs]), Loader([cast(b) for b in ubs]), opt, sched,
+                                        c['clip'], 1, mode == 'radv', 0)
+                finally:
+                    torch.randn_like = real_randn_like
+                assert len(rec['losses']) == K and (mode == 'novat' or not seq)
+                out[f'{tag}_{name}_losses'] = np.array(rec['losses'], dtype=np.float64)
+                named = dict(net.named_parameters())
+                if name == 'f32':
+                    out[f'{tag}_keys'] = np.array(rec['keys'])
+                    out[f'{tag}_lr'] = np.array(rec['lr'] + [opt.param_groups[0]['lr']], dtype=np.float64)      # K rates used + the rate after step K
+                    out[f'{tag}_nograd'] = np.array([k for k, p in named.items() if p.grad is None])
+                small = (lambda d: d.astype(np.float32)) if name == 'f32' else (lambda d: d)      # (the fp32 run's digests as float32: exact)
+                for k, p in named.items():
+                    out[f'{tag}_{name}_p:' + k] = small(digest(p, N))
+                    st = opt.state.get(p)
+                    if st:
+                        out[f'{tag}_{name}_m:' + k] = small(digest(st['exp_avg'], N // 2))
+                        out[f'{tag}_{name}_v:' + k] = small(digest(st['exp_avg_sq'], N // 4))
+                for k, b in net.state_dict().items():
+                    if k.endswith(('running_mean', 'running_var')):
+                        out[f'{tag}_{name}_s:' + k] = b.detach().double().numpy().copy()
+                    elif k.endswith('num_batches_tracked'):
+                        out[f'{tag}_{name}_s:' + k] = np.array(int(b))
+                del net, opt, sched
+            # ---- the oracle through the same six steps (fp32), held to the product's bar against the reference's fp64 run ----
+            fn = om.run_on_batch_onset if kind == 'onset' else om.run_on_batch_frame
+            params, state = fx.clone_params(fx.fixture_params(kind, True)), {}
+            worst, lworst, spreads = 0.0, 0.0, []
+            for i in range(K):
+                kw = dict(VAT=True, d0_ul=noises[i][0], d0_l=noises[i][1], n_power=0) if mode == 'radv' else dict(VAT=False)
+                _, lo, _ = om.train_step(params, state, i, lbs[i % c['n_l']], ubs[i % c['n_ul']] if mode == 'radv' else None, fn, alpha=1.0,
+                                         lr0=c['lr'], decay_steps=c['step_size'], decay_rate=c['gamma'], clip=c['clip'], reconstruction=True, **kw)
+                # bar of a loss term at iteration i: against the fp64 run, 2 x the reference's own worst fp32-vs-fp64 movement of that
+                # iteration + 1e-3 (the trajectory amplifies rounding noise: Adam's first updates are lr * sign(g))
+                l32, l64 = out[f'{tag}_f32_losses'][i], out[f'{tag}_f64_losses'][i]
+                spread = float(np.max(np.abs(l32 - l64) / np.maximum(np.abs(l64), 1e-6)))
+                for j, k in enumerate(lo):
+                    e = abs(float(lo[k]) - l64[j]) / max(abs(l64[j]), 1e-6)
+                    assert e <= 2 * spread + 1e-3, ('oracle trajectory loss', tag, i, k, float(lo[k]), l64[j], spread)
+                    lworst = max(lworst, e / (2 * spread + 1e-3))
+                spreads.append(spread)
+            errs = []
+            for k in om.trainable_keys(params):
+                d64, d32 = out[f'{tag}_f64_p:' + k], out[f'{tag}_f32_p:' + k].astype(np.float64)
+                do = digest(params[k], N)
+                den = max(np.linalg.norm(d64[1:]), 1e-30)
+                e_or, e_ref = np.linalg.norm(do[1:] - d64[1:]) / den, np.linalg.norm(d32[1:] - d64[1:]) / den
+                errs.append((e_or, e_ref))
+                assert e_or <= 2 * e_ref + 1e-3, ('oracle trajectory parameter', tag, k, e_or, e_ref)
+                worst = max(worst, e_or / (2 * e_ref + 1e-3))
+            print(tag, f'final lr {out[tag + "_lr"][-1]:.3e}; reference fp32 vs fp64 parameter drift after {K} steps: median '
+                  f'{np.median([e[1] for e in errs]):.2e}, max {np.max([e[1] for e in errs]):.2e}; oracle vs fp64: median '
+                  f'{np.median([e[0] for e in errs]):.2e}, max {np.max([e[0] for e in errs]):.2e}, worst share of its bar {worst:.2f}; reference fp32-vs-fp64 loss movement per iteration '
+                  + ' '.join(f'{x:.1e}' for x in spreads) + f'; oracle losses: worst share of their bar {lworst:.2f}')
+    save('trajectory', **out)
 
 
 def g_lds_backward():
@@ -888,7 +1003,7 @@ def g_onset_frames():
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['frontend', 'unet', 'attention', 'networks', 'vat', 'run_on_batch', 'train_step', 'dataset',
-                             'decoding', 'onset_frames', 'ingest', 'lds_spread', 'application', 'lds_backward', 'anchor_b8', 'anchor_grads']
+                             'decoding', 'onset_frames', 'ingest', 'lds_spread', 'application', 'lds_backward', 'anchor_b8', 'anchor_grads', 'trajectory']
     for w in which:
         print('==', w)
         globals()['g_' + w]()

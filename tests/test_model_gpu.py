@@ -633,3 +633,69 @@ def test_two_stream_graph_replays_keep_running_statistics(dev):
                 assert abs(le[k] - lg[k]) <= 2e-3 * max(abs(le[k]), 1e-6), (k, le[k], lg[k])
         for k in se:
             assert rel_err(sg[k], se[k]) < 5e-2, k      # the adversarial passes (eps = 2 along an ill-conditioned direction) move the deep layers' batch means by a percent or two; stale or garbage tables would be O(1) off
+
+
+@pytest.mark.parametrize('deterministic', [False, True])
+@pytest.mark.parametrize('tag', ['onset_novat', 'onset_radv', 'frame_novat', 'frame_radv'])
+def test_six_step_trajectory_vs_reference(dev, tag, deterministic, monkeypatch):
+    """K = 6 optimiser steps of the PRODUCT -- hipGraph TrainStep (two-chain schedule in `radv`), FlatAdam with
+    StepLR(step_size = 2: two decay boundaries), weights repacked by the one-launch PackPlan after every step, 8-9 BatchNorm
+    running-statistic updates per step, new batches loaded into the static buffers every step, post-step clip -- against K iterations of
+    the REFERENCE's own train_VAT_model (model/helper_functions.py:570-615; tests/golden/trajectory.npz) in its two deterministic modes
+    (`novat`: VAT=False; `radv`: VAT with n_power = 0 and injected noise), in the default mode and in RV_DETERMINISTIC=1.  Checked:
+    every loss term of every iteration, the learning rate of every iteration, and after step 6 every parameter, Adam's exp_avg /
+    exp_avg_sq, every BatchNorm running_mean / running_var, num_batches_tracked, never-touched parameters; bars in
+    tests/trajectory_check.py (the reference's own fp32-vs-fp64 drift is the yardstick: the trajectory amplifies rounding noise)."""
+    import reconvat_amd as ra
+    import trajectory_check as tc
+    from oracle import fixture as fx
+    from reconvat_amd import ops
+    monkeypatch.setattr(ops, 'DETERMINISTIC', [deterministic])
+    kind, mode = tag.split('_')
+    c = fx.TRAJ
+    lbs, ubs, noises = fx.trajectory_inputs()
+    todev = lambda b: {k: v.to(dev) for k, v in b.items()}
+    lbs, ubs = [todev(b) for b in lbs], [todev(b) for b in ubs]
+    m = build(kind, True, dev)
+    opt = ra.FlatAdam(m.parameters(), lr=c['lr'], step_size=c['step_size'], gamma=c['gamma'])
+    if mode == 'radv':
+        m.vat_loss.n_power = 0
+        # injected noise in STATIC buffers (the captured graph reads them; they are overwritten before every replay)
+        nbuf = [noises[0][0].to(dev).clone(), noises[0][1].to(dev).clone()]
+        state = {'i': 0}
+
+        def draw(t):
+            state['i'] += 1
+            return nbuf[(state['i'] - 1) % 2].clone()            # unlabelled first, labelled second (model/UNet_onset.py:425,445)
+        m.vat_loss.noise = draw
+        step = ra.TrainStep(m, opt, lbs[0], ubs[0], alpha=1.0, VAT=True, clip=c['clip'], graph=True, dual_stream=True)
+    else:
+        step = ra.TrainStep(m, opt, lbs[0], None, alpha=1.0, VAT=False, clip=c['clip'], graph=True)
+    losses, lrs = [], []
+    for i in range(c['K']):
+        step.load(lbs[i % c['n_l']], ubs[i % c['n_ul']] if mode == 'radv' else None)
+        if mode == 'radv':
+            nbuf[0].copy_(noises[i][0].to(dev))
+            nbuf[1].copy_(noises[i][1].to(dev))
+        lrs.append(opt.current_lr())
+        step()
+        torch.cuda.synchronize()
+        step.check()
+        assert list(step.losses.keys()) == [str(k) for k in tc.gold()[tag + '_keys']]
+        losses.append([float(v) for v in step.losses.values()])
+    lrs.append(opt.current_lr())
+    assert int(opt.step_count.item()) == c['K']
+    names = [n for n, p in m.named_parameters() if p.requires_grad]
+    assert len(names) == len(opt.params)
+    p = dict(m.named_parameters())
+    mm = {n: opt.exp_avg[o:o + q.numel()].view_as(q) for n, q, o in zip(names, opt.params, opt.offsets)}
+    vv = {n: opt.exp_avg_sq[o:o + q.numel()].view_as(q) for n, q, o in zip(names, opt.params, opt.offsets)}
+    bufs = {k: t for k, t in m.state_dict().items() if k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', f'trajectory_{tag}_{"det" if deterministic else "default"}.json')
+    rows = tc.check(tag, losses, lrs, p, mm, vv, bufs, c['N'], f'hipGraph TrainStep + FlatAdam ({"RV_DETERMINISTIC" if deterministic else "default"})', log=out)
+    s = tc.summary(rows)
+    print(tag, 'deterministic' if deterministic else 'default', s)
+    # the never-touched parameters have no Adam state in the reference; here their moments stay exactly zero
+    nograd = set(str(k) for k in tc.gold()[tag + '_nograd'])
+    for n in nograd:
+        assert float(mm[n].abs().max()) == 0.0 and float(vv[n].abs().max()) == 0.0, n

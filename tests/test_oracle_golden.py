@@ -172,3 +172,34 @@ def test_oracle_fullsize_gradients_match_the_reference_golden():
         assert e_oracle <= 0.5 * e_ref + 1e-4, (k, e_oracle, e_ref)
         checked += 1
     assert checked > 90
+
+
+@pytest.mark.parametrize('tag', ['onset_novat', 'onset_radv', 'frame_novat', 'frame_radv'])
+def test_oracle_six_step_trajectory_vs_reference(tag):
+    """K = 6 iterations of the oracle's train_step (Adam + StepLR(step_size = 2) + post-step clip, cycled batches, BatchNorm running
+    statistics) against the REFERENCE's own train_VAT_model run (tests/golden/trajectory.npz; model/helper_functions.py:570-615) in the
+    two deterministic modes -- the CPU side of the GPU test test_six_step_trajectory_vs_reference; bars in tests/trajectory_check.py."""
+    import trajectory_check as tc
+    kind, mode = tag.split('_')
+    c = fx.TRAJ
+    lbs, ubs, noises = fx.trajectory_inputs()
+    fn = om.run_on_batch_onset if kind == 'onset' else om.run_on_batch_frame
+    params, state = fx.clone_params(fx.fixture_params(kind, True)), {}
+    losses, lrs = [], []
+    for i in range(c['K']):
+        kw = dict(VAT=True, d0_ul=noises[i][0], d0_l=noises[i][1], n_power=0) if mode == 'radv' else dict(VAT=False)
+        lrs.append(c['lr'] * c['gamma'] ** (i // c['step_size']))
+        _, lo, _ = om.train_step(params, state, i, lbs[i % c['n_l']], ubs[i % c['n_ul']] if mode == 'radv' else None, fn, alpha=1.0,
+                                 lr0=c['lr'], decay_steps=c['step_size'], decay_rate=c['gamma'], clip=c['clip'], reconstruction=True, **kw)
+        assert list(lo.keys()) == [str(k) for k in tc.gold()[tag + '_keys']]
+        losses.append([float(v.detach()) for v in lo.values()])
+    lrs.append(c['lr'] * c['gamma'] ** (c['K'] // c['step_size']))
+    keys = om.trainable_keys(params)
+    p = {k: params[k] for k in keys}
+    m = {k: state[k][0] for k in keys if k in state}
+    v = {k: state[k][1] for k in keys if k in state}
+    bufs = {k: t for k, t in params.items() if k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))}
+    rows = tc.check(tag, losses, lrs, p, m, v, bufs, c['N'], 'oracle (CPU)')
+    s = tc.summary(rows)
+    # the oracle is the reference's own op sequence in fp32: it sits where the reference's fp32 run sits (half of the 2 x bar)
+    assert s['p']['worst_share_of_bar'] < 0.8 and s['loss']['worst_share_of_bar'] < 0.8, s

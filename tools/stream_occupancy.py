@@ -37,3 +37,41 @@ for t, d in ev:
 hist[0] = hist.get(0, 0) + (hi - last)
 for k in sorted(hist):
     print(f'{k} kernels in flight: {hist[k] / 1e6 / n:.3f} ms/step ({100 * hist[k] / (hi - lo):.1f} %)')
+
+# ---- round 6: WHICH kernels co-run.  Per kernel name: its total time and the part of it during which at least one other kernel was in
+# flight; and the heaviest co-running (name, name) pairs.  (the second chain only co-runs 9-14 % of the time; this
+# table shows with whom -- a persistent conv workgroup takes a CU's LDS and most of its VGPRs, so what can share a CU with it is decided
+# by the registers it leaves free.)
+if '--pairs' in sys.argv:
+    import re
+
+    def short(nm):
+        nm = re.sub(r'\(.*\)$', '', nm).replace('void ', '')
+        return nm[:72]
+    evs = []
+    for i, (s, e, _, nm) in enumerate(rows):
+        evs.append((s, 1, i)); evs.append((e, 0, i))
+    evs.sort()
+    live, last = set(), lo
+    tot, shared, pairs = {}, {}, {}
+    for t, kind, i in evs:
+        dt = t - last
+        if dt > 0 and live:
+            names = sorted(short(rows[j][3]) for j in live)
+            for nm in names:
+                tot[nm] = tot.get(nm, 0) + dt
+                if len(live) > 1:
+                    shared[nm] = shared.get(nm, 0) + dt
+            if len(live) == 2:
+                pairs[tuple(names)] = pairs.get(tuple(names), 0) + dt
+        last = t
+        if kind:
+            live.add(i)
+        else:
+            live.discard(i)
+    print('\n# per kernel: ms/step in flight, of which co-running with another kernel')
+    for nm, v in sorted(tot.items(), key=lambda kv: -kv[1])[:40]:
+        print(f'{v / 1e6 / n:8.3f} ms/step  co-running {shared.get(nm, 0) / 1e6 / n:7.3f} ms ({100 * shared.get(nm, 0) / v:5.1f} %)  {nm}')
+    print('\n# heaviest co-running pairs (exactly two kernels in flight)')
+    for (a, b), v in sorted(pairs.items(), key=lambda kv: -kv[1])[:30]:
+        print(f'{v / 1e6 / n:8.3f} ms/step  {a}  ||  {b}')
