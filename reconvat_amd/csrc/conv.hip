@@ -712,7 +712,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_lds_k(ConvLdsArgs aa) {
 // BNZ: the launch carries the fused BatchNorm-backward reduction (a.bn_z != NULL); its epilogue needs ~30 more registers, so the plain
 // launches get their own instance
 template <int NT, int MTW, int NW, bool HALF = false, int LAY = 1, bool BNZ = false>
-__global__ __launch_bounds__(NW * 64) void conv3x3_wino_k(ConvLdsArgs aa) {
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv3x3_wino_k(ConvLdsArgs aa) {     // (four waves: the half-CU experiment family 0xE, two workgroups per CU -> <= 256 registers)
     constexpr int NTHR = NW * 64;
     constexpr int KC = 16;                       // channels per chunk
     constexpr int WFLOATS = 16 * NT * 256;       // 16 xi x NT fragments x 64 lanes x 4 floats
@@ -2797,8 +2797,10 @@ static size_t conv3x3_wino_bytes(int NT, int TH, int W, int wbufs) {
     return (size_t)2 * (TH + 2) * NP * 1024 + (size_t)wbufs * 16 * NT * 1024;
 }
 
+// cap / wg_slots: LDS budget of a workgroup and workgroup slots on the chip -- 154 KiB and 256 (one workgroup per CU) for the shipped families;
+// 78 KiB and 512 for the half-CU experiment family 0xE (round 6: two four-wave workgroups per CU, possibly of two different kernels)
 template <int NW, bool HALF = false, int LAY = 1>
-static int launch_conv3x3_wino(const ConvArgs& a0, int NT, int MTW, int force_th, hipStream_t st) {
+static int launch_conv3x3_wino(const ConvArgs& a0, int NT, int MTW, int force_th, hipStream_t st, size_t cap = 154 * 1024, int wg_slots = 256) {
     if (NT < 1 || a0.ntile_n % NT) return RV_EUNSUPPORTED;
     if (NW == 12 && a0.bn_z) return RV_EUNSUPPORTED;      // the fused BatchNorm-backward epilogue does not fit three waves per SIMD without scratch
     ConvLdsArgs aa;
@@ -2823,19 +2825,19 @@ static int launch_conv3x3_wino(const ConvArgs& a0, int NT, int MTW, int force_th
     size_t lds = conv3x3_wino_bytes(NT, TH, a0.W, a0.nchunk > 1 ? 2 : 1);
     // "as many rows as the tile slots hold" (force_th == 0) also means: as many as the LDS holds (a staged row is a whole number of
     // 1 KiB pieces, so e.g. a 114-pixel row takes 8 KiB)
-    while (!force_th && lds > 154 * 1024 && TH > 2) {
+    while (!force_th && lds > cap && TH > 2) {
         TH -= 2;
         lds = conv3x3_wino_bytes(NT, TH, a0.W, a0.nchunk > 1 ? 2 : 1);
     }
     if (a0.nchunk > 1 && wres_env) {
         const size_t lds_res = conv3x3_wino_bytes(NT, TH, a0.W, a0.nchunk);
-        if (lds_res <= 154 * 1024) { aa.wres = 1; lds = lds_res; }
+        if (lds_res <= cap) { aa.wres = 1; lds = lds_res; }
     }
-    if (lds > 154 * 1024) return RV_EUNSUPPORTED;
+    if (lds > cap) return RV_EUNSUPPORTED;
     aa.TH = TH; aa.nbands = cdiv(a0.H, TH);
     aa.total_bands = a0.B * aa.nbands;
     const int nsplit = a0.ntile_n / NT;
-    int wgs = 256 / nsplit;
+    int wgs = wg_slots / nsplit;
     if (wgs < 1) wgs = 1;
     if (wgs > aa.total_bands) wgs = aa.total_bands;
     aa.bands_per_wg = cdiv(aa.total_bands, wgs);
@@ -3107,6 +3109,14 @@ static int conv_fwd_impl(int mode, const float* in, int in_ld, int B, int H, int
                                  : (fam == 10 ? launch_conv3x3_wino<8, true>(a, f_nt, f_mt, f_th, st) : launch_conv3x3_wino<12, true>(a, f_nt, f_mt, f_th, st));
         if (rcw != RV_OK) { rv_set_error("rv_conv_fwd: forced Winograd tile NT=%d MTW=%d TH=%d does not fit", f_nt, f_mt, f_th); return rcw; }
         RV_LAUNCH_CHECK("rv_conv_fwd(winograd)");
+        *sums_done = true;
+        return RV_OK;
+    }
+    if (fam == 14) {   // 0xENM (round 6 EXPERIMENT, never in the shipped table): four-wave half-CU workgroups -- <= 78 KiB of LDS, <= 256 registers, 512 slots
+        if (mode != 0 || R != 4) { rv_set_error("rv_conv_fwd: the Winograd kernel needs a 3x3 conv with Cin %% 16 == 0"); return RV_EUNSUPPORTED; }
+        const int rcw = launch_conv3x3_wino<4, true>(a, f_nt, f_mt, f_th, st, (size_t)78 * 1024, 512);
+        if (rcw != RV_OK) { rv_set_error("rv_conv_fwd: forced half-CU Winograd tile NT=%d MTW=%d TH=%d does not fit", f_nt, f_mt, f_th); return rcw; }
+        RV_LAUNCH_CHECK("rv_conv_fwd(winograd, half CU)");
         *sums_done = true;
         return RV_OK;
     }

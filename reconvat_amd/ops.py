@@ -410,7 +410,7 @@ BF16 = {'fwd': False, 'bwd': False}
 ALGO_BF16 = 1 << 20
 # algo families (bits 8..11) that are fp32 Winograd tiles -- conv3x3_wino_k (0x6 / 0xA / 0xC) and the software-pipelined conv3x3_wino2_k
 # (0x8 / 0x9 / 0xB / 0xD): no bf16-operand form, a bf16 launch of such a shape runs the library-default direct tile instead
-WINOGRAD_FAMILIES = (6, 8, 9, 10, 11, 12, 13)
+WINOGRAD_FAMILIES = (6, 8, 9, 10, 11, 12, 13, 14)
 
 
 class bf16_final_graphs:

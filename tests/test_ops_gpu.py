@@ -236,7 +236,10 @@ WINO_CASES = [(16, 16, 12, 229, 0x611), (32, 32, 22, 114, 0x611), (64, 64, 31, 5
               (32, 32, 24, 114, 0x4811), (64, 64, 16, 28, 0x2811), (128, 128, 10, 14, 0x811), (32, 32, 8, 30, 0x811),
               (64, 64, 31, 57, 0xb12), (16, 16, 12, 229, 0xb12), (96, 48, 21, 57, 0xb12), (64, 64, 31, 57, 0xb21), (128, 128, 40, 28, 0xb21), (192, 96, 20, 28, 0xb21),
               # ... and its 12-wave form (0xDNM: three waves per SIMD, half-chunk patch)
-              (64, 64, 31, 57, 0xad11), (16, 16, 12, 229, 0xd11), (128, 128, 40, 28, 0xd11), (32, 16, 9, 114, 0x4d11), (192, 64, 9, 28, 0xd11), (48, 32, 20, 57, 0xd11)]
+              (64, 64, 31, 57, 0xad11), (16, 16, 12, 229, 0xd11), (128, 128, 40, 28, 0xd11), (32, 16, 9, 114, 0x4d11), (192, 64, 9, 28, 0xd11), (48, 32, 20, 57, 0xd11),
+              # round 6: the half-CU experiment family 0xE (conv3x3_wino_k with four waves, <= 78 KiB of LDS, <= 256 registers, 512 workgroup slots;
+              # never in the shipped table -- tools/pair_probe.py set4, profiles/r06_half_cu_pairs.txt)
+              (128, 128, 40, 28, 0xe11), (64, 64, 31, 57, 0xe11), (64, 128, 20, 28, 0xe11), (192, 96, 20, 28, 0xe11), (32, 32, 8, 30, 0xe11)]
 
 
 @pytest.mark.parametrize('cin,cout,H,W,algo', WINO_CASES)

@@ -86,6 +86,19 @@ def make(spec, tag):
             ops.gemm(a, b, c, splitk=1)
         run.keep = (a, b, c)
         return f'gemm {m}x{n}x{k}', run
+    if p[0] == 'mfma':
+        # rv_debug_mfma_peak: 256-thread workgroups of pure f32 MFMA issue -- no LDS, ~40 registers, no memory traffic: the cleanest possible
+        # MFMA-bound partner (if THIS does not hide a bandwidth-bound kernel, nothing will)
+        import ctypes
+        blocks, iters, nacc = int(p[1]), int(p[2]), int(p[3])
+        fn = ctypes.CDLL(_lib.LIB_PATH).rv_debug_mfma_peak
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        out = torch.empty(4096 * 256, device=dev)
+
+        def run():
+            fn(out.data_ptr(), blocks, iters, nacc, torch.cuda.current_stream().cuda_stream)
+        run.keep = (out,)
+        return f'mfma_peak_k {blocks} wgs x {iters} it, nacc {nacc}', run
     raise SystemExit(f'unknown kernel spec {spec}')
 
 
@@ -124,6 +137,62 @@ def time_graph(g, reps=8):
     return sorted(ts)[len(ts) // 2]
 
 
+def time_two_graphs(gx, gy, reps=8):
+    """The two single-branch graphs replayed CONCURRENTLY on two streams (instead of one forked graph)."""
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    ts = []
+    for _ in range(reps + 1):
+        torch.cuda.synchronize()
+        e0, e1, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cur = torch.cuda.current_stream()
+        e0.record(cur)
+        s1.wait_event(e0); s2.wait_event(e0)
+        with torch.cuda.stream(s1):
+            gx.replay()
+            e1.record(s1)
+        with torch.cuda.stream(s2):
+            gy.replay()
+            e2.record(s2)
+        torch.cuda.synchronize()
+        ts.append(max(e0.elapsed_time(e1), e0.elapsed_time(e2)) * 1e3 / N)
+    return sorted(ts[1:])[len(ts[1:]) // 2]
+
+
+def time_eager_two_streams(fx, fy, reps=5):
+    """N eager launches of each on two streams, issued alternately by the host (no graph at all)."""
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    ts = []
+    for _ in range(reps + 1):
+        torch.cuda.synchronize()
+        e0, e1, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream())
+        s1.wait_event(e0); s2.wait_event(e0)
+        for _i in range(N):
+            with torch.cuda.stream(s1):
+                fx()
+            with torch.cuda.stream(s2):
+                fy()
+        e1.record(s1); e2.record(s2)
+        torch.cuda.synchronize()
+        ts.append(max(e0.elapsed_time(e1), e0.elapsed_time(e2)) * 1e3 / N)
+    return sorted(ts[1:])[len(ts[1:]) // 2]
+
+
+PAIRS3 = [('mfma:256:180:4', 'bn:64:160:57'), ('mfma:256:180:2', 'mfma:256:180:2'), ('conv:64:64:160:57:911', 'bn:64:160:57'), ('bn:64:160:57', 'bn:16:640:229'),
+          ('conv:64:64:160:57:911', 'conv:64:64:160:57:911'), ('conv:64:64:160:57:911', 'attn'), ('attn', 'bn:16:640:229')]
+# round 6, VERDICT r05 item 1: the half-CU family 0xE (four waves, <= 78 KiB of LDS, <= 256 registers, two workgroups per CU) against the
+# shipped full-CU instances of the same layer -- alone, as a pair of two half-CU kernels from two chains, and beside a BatchNorm
+PAIRS4 = [('conv:128:128:80:28:a11', 'conv:128:128:80:28:a11'), ('conv:128:128:80:28:e11', 'conv:128:128:80:28:e11'), ('conv:128:128:80:28:e11', 'bn:128:80:28'),
+          ('conv:64:64:160:57:911', 'conv:64:64:160:57:911'), ('conv:64:64:160:57:e11', 'conv:64:64:160:57:e11'), ('conv:64:64:160:57:e11', 'bn:64:160:57'),
+          ('conv:64:128:80:28:c11', 'conv:64:128:80:28:c11'), ('conv:64:128:80:28:e11', 'conv:64:128:80:28:e11'),
+          ('conv:32:32:320:114:911', 'conv:32:32:320:114:911'), ('conv:32:32:320:114:e11', 'conv:32:32:320:114:e11')]
+PAIRS2 = [
+    # can ANY MFMA-bound kernel hide a bandwidth-bound one?  pure MFMA issue (no LDS, few registers) at 2 and 1 waves per SIMD
+    ('mfma:512:90:4', 'bn:64:160:57'), ('mfma:256:180:4', 'bn:64:160:57'), ('mfma:512:90:4', 'bn:16:640:229'), ('mfma:512:90:4', 'attn'),
+    ('mfma:512:90:4', 'mfma:512:90:4'), ('mfma:256:180:4', 'mfma:256:180:4'),
+    # the LDS-free direct conv kernel (thousands of small workgroups) and the persistent kernel with a two-row band (96 KB of LDS)
+    ('conv:64:64:160:57:1', 'bn:64:160:57'), ('conv:64:64:160:57:2911', 'bn:64:160:57'), ('conv:64:64:160:57:2911', 'conv:64:64:160:57:2911'),
+]
 PAIRS = [
     # the #1 kernel of the step (conv3x3_wino2_k<1,1,8,HALF>: 171 VGPRs -> 160 free per SIMD beside its two waves) and its 230-register sibling
     ('conv:64:64:160:57:911', 'bn:64:160:57'), ('conv:64:64:160:57:811', 'bn:64:160:57'),
@@ -135,13 +204,23 @@ PAIRS = [
 ]
 
 if __name__ == '__main__':
-    pairs = [tuple(a.split('+')) for a in sys.argv[1:]] or PAIRS
+    args = [a for a in sys.argv[1:]]
+    pairs = PAIRS2 if args == ['set2'] else PAIRS3 if args == ['set3'] else PAIRS4 if args == ['set4'] else ([tuple(a.split('+')) for a in args] or PAIRS)
     print(f'# N = {N} launches per branch and graph, B = {B}; microseconds per launch (pair: per launch of each)')
     for xs, ys in pairs:
         nx, fx = make(xs, 'x')
         ny, fy = make(ys, 'y')
-        tx, ty = time_graph(graph_of([fx])), time_graph(graph_of([fy]))
+        try:
+            fx(); fy()
+        except AssertionError as e:
+            print(f'{nx} | {ny}: skipped ({e})')
+            continue
+        gx, gy = graph_of([fx]), graph_of([fy])
+        tx, ty = time_graph(gx), time_graph(gy)
         txy = time_graph(graph_of([fx, fy]))
         tser = time_graph(graph_of([lambda: (fx(), fy())]))
+        t2g = time_two_graphs(gx, gy)
+        teg = time_eager_two_streams(fx, fy)
         hidden = (tx + ty - txy) / min(tx, ty)
-        print(f'{nx:44s} {tx:7.1f} | {ny:44s} {ty:7.1f} | two branches {txy:7.1f} | one branch, alternating {tser:7.1f} | hidden {hidden:5.2f}')
+        print(f'{nx:44s} {tx:7.1f} | {ny:44s} {ty:7.1f} | forked graph {txy:7.1f} (hidden {hidden:5.2f}) | one branch, alternating {tser:7.1f} | '
+              f'two graphs on two streams {t2g:7.1f} (hidden {(tx + ty - t2g) / min(tx, ty):5.2f}) | eager, two streams {teg:7.1f} (hidden {(tx + ty - teg) / min(tx, ty):5.2f})')
