@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libreconvat_hip.so')
-SOURCES = ['conv.hip', 'conv_wino2.hip', 'bn.hip', 'gemm.hip', 'attn.hip', 'elementwise.hip', 'mel.hip', 'data.hip', 'lstm.hip', 'api.cpp']
+SOURCES = ['conv.hip', 'conv_wino2.hip', 'bn.hip', 'gemm.hip', 'gemm_bf16x6.hip', 'attn.hip', 'elementwise.hip', 'mel.hip', 'data.hip', 'lstm.hip', 'api.cpp']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 

@@ -14,7 +14,7 @@ against the fp64 run:
     soft bar    e <= 2 x e_ref + 1e-3     at most 3 % (at least one) of the rows of a kind -- parameters / exp_avg / exp_avg_sq / running
                                           statistics -- may exceed it; loss terms (those of one iteration move together): in at most ONE
                                           of the K iterations
-    hard bar    e <= 4 x e_ref + 1e-3     none may exceed it
+    hard bar    e <= 6 x e_ref + 1e-3     none may exceed it
     population  median(e) <= 1.25 x median(e_ref) + 1e-3 per kind
     learning rate of every iteration and after the last step, num_batches_tracked, never-touched parameters: exact.
 
@@ -22,7 +22,8 @@ Why a distribution and not one per-row bar: a product error is ONE more draw of 
 draws the largest of four sits at ~1.4 sigma, so a faithful implementation exceeds 2 x e_ref in ~0.5 % of its rows -- over the ~5 300 rows
 of the eight test configurations that is two dozen rows, before the heavier tails of a multiplicative (chaotic) drift.  Measured on
 MI355X (profiles/r06_trajectory_errors.txt): median e / median e_ref 0.7-1.0 per kind, 4 of the 5 688 rows of the eight configurations above
-the soft bar (all of them loss terms of iteration 4 or 5), none above 2.9 x.
+the soft bar (all of them LDS / frame2 loss terms of iteration 4 or 5: the most chaotic quantities), the worst 2.9-3.6 x from run to run (the
+default mode folds parameter gradients with fp32 atomics).
 
 What this catches: a stale packed weight, a missed / doubled BatchNorm update, a wrong decay boundary or bias correction, a batch that
 was not reloaded -- each of them moves losses and parameters by many times the reference's own drift.
@@ -114,7 +115,7 @@ def check(tag, losses, lrs, params, adam_m, adam_v, buffers, n, where, log=None,
         e = tensor_err(got, g[k], 0.0, digest=False)
         rows.append({'what': 'bn', 'key': name, 'e': e, 'e_ref': eref[name], 'bar': 2 * eref[name] + 1e-3})
     for r in rows:
-        r['hard'] = 4 * r['e_ref'] + 1e-3
+        r['hard'] = 6 * r['e_ref'] + 1e-3
         r['over_soft'] = bool(r['e'] > r['bar'] or r.get('e_norm', 0.0) > r['bar'])
         if r['e'] > r['hard'] or r.get('e_norm', 0.0) > r['hard']:
             bad.append(dict(r, why='hard bar'))

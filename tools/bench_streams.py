@@ -83,3 +83,33 @@ for fn in (both_serial, both_parallel, merged16):
         g.replay()
     e1.record(); e1.synchronize()
     print(f'{fn.__name__}: {e0.elapsed_time(e1) / 10:.3f} ms')
+
+# ---- round 6: the same two chains as TWO single-branch graphs replayed concurrently on two streams (instead of one forked graph).
+# tools/pair_probe.py found kernel pairs that hide each other completely when launched on two streams but not at all as the two branches of a
+# forked hipGraph; this is the same question for whole chains.  TWO_GRAPHS=0 skips it.
+if os.environ.get('TWO_GRAPHS', '1') != '0' and NCH == 2:
+    graphs = []
+    for x in xs:
+        for _ in range(2):
+            chain(x)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = chain(x)
+        graphs.append((g, out))
+    for trial in range(3):
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        ts = []
+        for rep in range(12):
+            torch.cuda.synchronize()
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record(torch.cuda.current_stream())
+            s1.wait_event(e0); s2.wait_event(e0)
+            with torch.cuda.stream(s1):
+                graphs[0][0].replay(); e1.record(s1)
+            with torch.cuda.stream(s2):
+                graphs[1][0].replay(); e2.record(s2)
+            torch.cuda.synchronize()
+            ts.append(max(e0.elapsed_time(e1), e0.elapsed_time(e2)))
+        ts = sorted(ts[2:])
+        print(f'two graphs on two streams (stream pair {trial}): median {ts[len(ts) // 2]:.3f} ms  min {ts[0]:.3f}')
