@@ -12,6 +12,8 @@
 // (16-byte stores along the contiguous dimension of C).
 #include "common.h"
 #include <stdlib.h>
+#include <mutex>
+#include <atomic>
 
 #define GBM 64
 #define GBN 64
@@ -260,6 +262,117 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(GemmArgs a) {
     gemm_tile<AK, BK_>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
 }
 
+// ---- round 6: larger block tiles for the k-contiguous GEMMs (forward X @ W^T and, through the transposed weight copies, dY @ W) -------------
+// tools/bench_bf16x6.py's ladder showed the 64 x 64 kernel bound by operand movement, not by the matrix pipe: a 64 x 64 tile moves (64 + 64) x K x 4
+// bytes through L2 -> registers -> LDS per 2 x 64 x 64 x K flop (16 flop / byte; the same kernel with its MFMAs all but removed still takes 53 % of its
+// time).  gemm_big_k computes the SAME sums -- per output element the identical sequence of v_mfma_f32_16x16x4_f32 (k-tiles of 32 in order, k = ks + g
+// inside a tile, C = 0 start, the shared epilogue) so results are BIT-IDENTICAL to gemm_mfma_k<true, true> at splitk = 1 -- with a BM x BN block tile of
+// four waves owning (BM/2) x (BN/2) each: 32 flop / byte at 128 x 128, 21 at 128 x 64, 8 scalar fragment reads per 16 MFMAs instead of 4 per 4, and a
+// double-buffered LDS tile (ONE barrier per 32 k).  No split-K / batch / row sums / second destination: rv_gemm routes those to gemm_mfma_k.
+// MEASURED (tools/bench_gemm_big.py, profiles/r06_gemm_big_tiles.txt): bit-identical on every shape and SLOWER on 13 of 15 (x0.56 .. x1.00; 5120 x 1536 x 768:
+// 127 vs 139 us is the one win) -- thousands of small workgroups at 6-8 per CU hide the load -> LDS -> MFMA chain better than 2-3 large ones; the operand-traffic
+// reading of the bf16x6 ladder was wrong.  Kept as an opt-in policy (RV_GEMM_BIG=1 / rv_debug_set_gemm_big) so that the table can be re-measured; default off.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_big_k(GemmArgs a) {
+    constexpr int TY = BM / 32, TX = BN / 32;            // 16 x 16 tiles per wave along m / n (wave grid 2 x 2)
+    constexpr int LA = BM / 32, LB = BN / 32;            // float4 per thread and k-tile
+    extern __shared__ __attribute__((aligned(16))) float smemg[];      // [2][BM][LDK] | [2][BN][LDK]
+    float* As0 = smemg;
+    float* Bs0 = smemg + 2 * BM * LDK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    f32x4 acc[TX][TY];
+#pragma unroll
+    for (int x = 0; x < TX; ++x)
+#pragma unroll
+        for (int y = 0; y < TY; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[LA], rb[LB];
+    auto load = [&](f32x4* r, const int n4, const float* base, const long s_row, const int row0, const int nrows, const int k0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (e >= n4) break;
+            const int idx = tid + e * 256, row = idx >> 3, k = (idx & 7) * 4;
+            const int gr = row0 + row, gk = k0 + k;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (gr < nrows && gk < a.K) {
+                const float* p = base + (long)gr * s_row + gk;
+                if (gk + 3 < a.K) v = *reinterpret_cast<const f32x4u*>(p);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (gk + j < a.K) v[j] = p[j];
+                }
+            }
+            r[e] = v;
+        }
+    };
+    auto store = [&](const f32x4* r, const int n4, float* lds) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (e >= n4) break;
+            const int idx = tid + e * 256, row = idx >> 3, k = (idx & 7) * 4;
+            *reinterpret_cast<f32x4*>(lds + row * LDK + k) = r[e];
+        }
+    };
+    const int ntile = (a.K + GBK - 1) / GBK;
+    load(ra, LA, a.A, a.sam, m0, a.M, 0);
+    load(rb, LB, a.B, a.sbn, n0, a.N, 0);
+    store(ra, LA, As0);
+    store(rb, LB, Bs0);
+    if (ntile > 1) {
+        load(ra, LA, a.A, a.sam, m0, a.M, GBK);
+        load(rb, LB, a.B, a.sbn, n0, a.N, GBK);
+    }
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const float* As = As0 + (t & 1) * BM * LDK;
+        const float* Bs = Bs0 + (t & 1) * BN * LDK;
+        if (t + 1 < ntile) {                   // the next tile (registers) into the other buffer; the one after next leaves for the registers
+            store(ra, LA, As0 + ((t + 1) & 1) * BM * LDK);
+            store(rb, LB, Bs0 + ((t + 1) & 1) * BN * LDK);
+            if (t + 2 < ntile) {
+                load(ra, LA, a.A, a.sam, m0, a.M, (t + 2) * GBK);
+                load(rb, LB, a.B, a.sbn, n0, a.N, (t + 2) * GBK);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < GBK; ks += 4) {
+            float af[TY], bf[TX];
+#pragma unroll
+            for (int y = 0; y < TY; ++y) af[y] = As[(wm + y * 16 + li) * LDK + ks + g];
+#pragma unroll
+            for (int x = 0; x < TX; ++x) bf[x] = Bs[(wn + x * 16 + li) * LDK + ks + g];
+#pragma unroll
+            for (int x = 0; x < TX; ++x)
+#pragma unroll
+                for (int y = 0; y < TY; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[x], af[y], acc[x][y], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // the epilogue of gemm_mfma_k, tile pair by tile pair (bias, activation, accumulate)
+#pragma unroll
+    for (int x0 = 0; x0 < TX; x0 += 2)
+#pragma unroll
+        for (int y0 = 0; y0 < TY; y0 += 2) {
+            f32x4 sub[2][2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) sub[x][y] = acc[x0 + x][y0 + y];
+            gemm_epilogue(a, sub, m0, n0, wm + y0 * 16, wn + x0 * 16, li, g, 0);
+        }
+}
+
+template <int BM, int BN>
+static void launch_gemm_big(const GemmArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+    static std::once_flag once;
+    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)gemm_big_k<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    hipLaunchKernelGGL((gemm_big_k<BM, BN>), dim3(cdiv(a.N, BN), cdiv(a.M, BM)), dim3(256), lds, st, a);
+}
+
 // Grouped launch: a device table of independent problems (all of the same operand orientation), one 1-D grid over the tiles of
 // all of them.  The parameter-gradient GEMMs of a backward pass (M or N of 31 .. 229, K = B*T = 5120: a few dozen workgroups
 // each, latency-bound alone) then run side by side in ONE launch instead of one under-filled launch each.
@@ -291,7 +404,26 @@ __global__ void zero_strided_k(float* c, long scm, long scn, int M, int N) {
     c[m * scm + n * scn] = 0.f;
 }
 
+// block-tile policy of rv_gemm (see gemm_big_k): 0 = always 64 x 64 (DEFAULT: profiles/r06_gemm_big_tiles.txt -- the larger tiles are bit-identical and
+// slower on 13 of 15 shapes), 1 = automatic (RV_GEMM_BIG=1), 2 / 3 = force 128 x 128 / 128 x 64
+static std::atomic<int> g_gemm_big{-1};
+static int gemm_big_mode() {
+    int m = g_gemm_big.load(std::memory_order_relaxed);
+    if (m < 0) {
+        m = getenv("RV_GEMM_BIG") ? atoi(getenv("RV_GEMM_BIG")) : 0;
+        g_gemm_big.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+
 extern "C" {
+
+// experiment / test hook (not part of include/reconvat_hip.h): set the block-tile policy, returns the previous one
+int rv_debug_set_gemm_big(int mode) {
+    const int prev = gemm_big_mode();
+    g_gemm_big.store(mode, std::memory_order_relaxed);
+    return prev;
+}
 
 // C[m*scm + n*scn] (+)= act(sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] + bias[n]);  act: 0 none, 1 sigmoid.
 // splitk > 1 splits the reduction over extra workgroups.  With splitk_ws == NULL the slices accumulate by fp32 atomics (C zeroed
@@ -351,6 +483,23 @@ int rv_gemm(const float* A, long sam, long sak, const float* B, long sbk, long s
         RV_LAUNCH_CHECK("rv_gemm(zero)");
     }
     dim3 grid(cdiv(N, GBN), cdiv(M, GBM), splitk * batch);
+    // larger block tiles for the plain k-contiguous problems (bit-identical sums, see gemm_big_k): the largest tile that still leaves >= 2 workgroups per CU
+    // (>= 1.5 for 128 x 64) -- a short grid of big tiles loses more to the tail than it gains in operand traffic.  RV_GEMM_BIG=0: always 64 x 64.
+    const int big_env = gemm_big_mode();
+    if (big_env && a_kfast && b_kfast && splitk == 1 && batch == 1 && !a_rowsum && !C2 && sak == 1 && sbk == 1 && scn == 1 && M >= 128) {
+        const long wg128 = (long)cdiv(M, 128) * cdiv(N, 128), wg64 = (long)cdiv(M, 128) * cdiv(N, 64);
+        const int force = big_env > 1 ? big_env : 0;              // (2: force 128 x 128, 3: force 128 x 64 -- tests / A-B runs)
+        if (force == 2 || (!force && wg128 >= 512 && (long)cdiv(N, 128) * 128 * 10 <= (long)cdiv(N, 64) * 64 * 11)) {
+            launch_gemm_big<128, 128>(a, st);
+            RV_LAUNCH_CHECK("rv_gemm(128x128)");
+            return RV_OK;
+        }
+        if (force == 3 || (!force && wg64 >= 384)) {
+            launch_gemm_big<128, 64>(a, st);
+            RV_LAUNCH_CHECK("rv_gemm(128x64)");
+            return RV_OK;
+        }
+    }
     if (a_kfast && b_kfast) hipLaunchKernelGGL((gemm_mfma_k<true, true>), grid, dim3(256), 0, st, a);
     else if (a_kfast && !b_kfast) hipLaunchKernelGGL((gemm_mfma_k<true, false>), grid, dim3(256), 0, st, a);
     else if (!a_kfast && b_kfast) hipLaunchKernelGGL((gemm_mfma_k<false, true>), grid, dim3(256), 0, st, a);
