@@ -20,6 +20,7 @@
 // kernels are bound by staging the windows (each row is read 46/16 times, from L2).
 #include "common.h"
 #include <stdlib.h>
+#include <mutex>
 
 // Timing ablations of attn_fwd_k (tools/attn_ablate.sh; wrong results by design; 0 in every product build):
 //   1 no staging (q tile, key / value windows, rel^T) | 2 no score MFMAs | 4 no softmax | 8 no banded apply | 16 return at entry
@@ -391,13 +392,12 @@ static int attn_setup(AttnArgs& a, int dh, const char* who) {
     RV_CHECK_ARG(dh >= 1 && dh <= 256, "%s: head dim %d unsupported", who, dh);
     a.dh = dh;
     a.dhp = (dh + 15) & ~15;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::once_flag attr_once;              // (forward and backward launches come from different threads)
+    std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute((const void*)attn_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         (void)hipFuncSetAttribute((const void*)attn_bwd_q_k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         (void)hipFuncSetAttribute((const void*)attn_bwd_kv_k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        attr_done = true;
-    }
+    });
     return RV_OK;
 }
 

@@ -24,6 +24,7 @@
 // Weight gradients are pixel-reduction GEMMs (wgrad_mfma): per-wave partial sums are written to a
 // workspace and folded by a deterministic second pass (no atomics).
 #include "conv_shared.h"
+#include <mutex>
 
 // ------------------------------------------------------------------------------------------
 // weight packing
@@ -2710,13 +2711,13 @@ static int launch_conv3x3_lds_r(const ConvArgs& a, int NT, int MTW, int TH, int 
 #define RV_L3(nt, mt)                                                                              \
     if (NT == nt && MTW == mt) {                                                                  \
         auto kern = conv3x3_lds_k<R, nt, mt, NW, BF>;                                             \
-        static bool attr_done = false;                                                            \
-        if (!attr_done) {                                                                         \
+        /* (launches come from the autograd thread as well as from the main thread: once_flag, not a plain static bool) */ \
+        static std::once_flag attr_once;                                                          \
+        std::call_once(attr_once, [&] {                                                           \
             /* the kernel also has 1 KiB of static LDS: dynamic + static must stay within the 160 KiB of a CU */ \
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) \
                 (void)hipGetLastError();                                                          \
-            attr_done = true;                                                                     \
-        }                                                                                         \
+        });                                                                                       \
         hipLaunchKernelGGL(kern, grid, blk, lds, st, aa);                                         \
         return RV_OK;                                                                             \
     }
@@ -2849,14 +2850,13 @@ static int launch_conv3x3_wino(const ConvArgs& a0, int NT, int MTW, int force_th
     dim3 grid(wgs * nsplit), blk(NW * 64);
 #define RV_WN(nt, mt)                                                                              \
     if (NT == nt && MTW == mt) {                                                                  \
-        static bool attr_done = false;                                                            \
-        if (!attr_done) {                                                                         \
+        static std::once_flag attr_once;                                                          \
+        std::call_once(attr_once, [] {                                                            \
             if (hipFuncSetAttribute((const void*)conv3x3_wino_k<nt, mt, NW, HALF, LAY, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) \
                 (void)hipGetLastError();                                                          \
             if (hipFuncSetAttribute((const void*)conv3x3_wino_k<nt, mt, NW, HALF, LAY, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) \
                 (void)hipGetLastError();                                                          \
-            attr_done = true;                                                                     \
-        }                                                                                         \
+        });                                                                                       \
         if (a0.bn_z) hipLaunchKernelGGL((conv3x3_wino_k<nt, mt, NW, HALF, LAY, true>), grid, blk, lds, st, aa);  \
         else hipLaunchKernelGGL((conv3x3_wino_k<nt, mt, NW, HALF, LAY, false>), grid, blk, lds, st, aa);         \
         return RV_OK;                                                                             \
