@@ -11,7 +11,8 @@ for r in rows:
         worst[k] = r
 print("# Measured |HIP - reference| / |reference| of every loss term the GPU tests compare (tests/parity_tol.py log of a full\n"
       "# `pytest -m gpu` run on MI355X; worst occurrence per (case, key)).  ref_spread = the REFERENCE's own movement of the VAT\n"
-      "# terms of that case between its 8-thread fp32, 1-thread fp32 and fp64 runs (tests/golden/lds_spread.npz, worst key);\n"
+      "# terms of that case between its 8-thread fp32 golden and its 1- / 2- / 4-thread fp32 and fp64 runs (tests/golden/lds_spread.npz, four-sample\n"
+      "# estimate since round 6 -- the case maxima did not move --, worst key);\n"
       "# tol = max(1e-3, 2 x ref_spread).  Cases: <model>_T64 = run_on_batch fixtures (B=2, 64 frames), _T64_step = the\n"
       "# train_VAT_model fixture, _T640 = the full-segment anchor (B=2, 640 frames; eager and hipGraph two-stream TrainStep).")
 print(f"{'case':18s} {'loss term':28s} {'rel_err':>10s} {'tol':>10s} {'ref_spread':>11s}  where")
