@@ -324,7 +324,7 @@ def measure_in_situ(step_fn, device):
 HBM_PEAK_TBS = 8.0                    # /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s measured for a copy)
 FAMILY = {
     'rv_gemm': 'linear GEMMs', 'rv_gemm_table_run': 'linear GEMMs', 'rv_local_attn_fwd': 'local attention', 'rv_local_attn_bwd': 'local attention',
-    'rv_bn_lrelu_fwd': 'BatchNorm + leaky-ReLU', 'rv_bn_lrelu_bwd': 'BatchNorm + leaky-ReLU',
+    'rv_bn_lrelu_fwd': 'BatchNorm + leaky-ReLU', 'rv_bn_lrelu_fwd_skip': 'BatchNorm + leaky-ReLU', 'rv_bn_lrelu_bwd': 'BatchNorm + leaky-ReLU',
     'rv_melspec_lognorm_fwd': 'log-Mel front-end',
 }
 
@@ -340,6 +340,9 @@ def family_work(name, a):
     if name == 'rv_bn_lrelu_fwd':                 # reads z (+ residual), writes y
         p_, c = a[2], a[3]
         return 0.0, 4.0 * p_ * c * (3 if a[13] else 2)
+    if name == 'rv_bn_lrelu_fwd_skip':            # reads z and x (cin floats per pixel: the block's skip conv is evaluated in place), writes y
+        p_, c, cin = a[2], a[3], a[15]
+        return 0.0, 4.0 * p_ * (2 * c + cin)
     if name == 'rv_bn_lrelu_bwd':                 # reads dy, z, writes dz
         p_, c = a[4], a[5]
         return 0.0, 4.0 * p_ * c * 3

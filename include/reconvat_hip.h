@@ -121,6 +121,15 @@ int rv_bn_lrelu_fwd(const float* z, int z_ld, long P, int C, const float* gamma,
                     float* running_var, long* num_batches_tracked, float momentum, float eps, int training, float slope,
                     const float* res, int res_ld, float* y, int y_ld, float* coef, void* workspace, int sums_ready,
                     void* stream);
+/* the same with the residual evaluated in place: y = leaky_relu(bn(z)) + skip(x), skip = the 1x1 convolution of an encoder block (model/UNet_onset.py:186-201:
+ * `x12 += self.skip(x)`), x [P][cin] at pixel stride x_ld (floats), w [C][cin] (the PyTorch Conv2d weight), b [C] nullable; cin = 1 (block 1: the single-channel
+ * spectrogram, one fma per element) or 16 / 32 / 64 (an fmaf chain per element in the k order of rv_conv_fwd's MFMA kernel; ksplit != 0: the K-split form of
+ * that kernel, algo family 0x5NM).  BIT-IDENTICAL to rv_conv_fwd(mode 1) + rv_bn_lrelu_fwd(res = its output): v_mfma_f32_16x16x4_f32 is a chain of fused
+ * multiply-adds in k order (tools/probes/mfma_f32_order.hip).  Saves the conv launch, the write of its result and the read of it here. */
+int rv_bn_lrelu_fwd_skip(const float* z, int z_ld, long P, int C, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, long* num_batches_tracked, float momentum, float eps, int training, float slope,
+                         const float* x, int x_ld, int cin, const float* w, const float* b, int ksplit, float* y, int y_ld, float* coef,
+                         void* workspace, int sums_ready, void* stream);
 int rv_bn_running_update(float* running_mean, float* running_var, long* num_batches_tracked, const float* coef, int C,
                          float momentum, void* stream);
 /* all deferred running-statistic updates of a step in one launch: table (DEVICE int64 words) = nlayers x {running_mean,

@@ -41,6 +41,7 @@ SIGNATURES = {
     'rv_wgrad_reduce_table': (I, [P, I, L, P]),
     'rv_bn_workspace_bytes': (L, [I]),
     'rv_bn_lrelu_fwd': (I, [P, I, L, I, P, P, P, P, P, F, F, I, F, P, I, P, I, P, P, I, P]),
+    'rv_bn_lrelu_fwd_skip': (I, [P, I, L, I, P, P, P, P, P, F, F, I, F, P, I, I, P, P, I, P, I, P, P, I, P]),
     'rv_bn_running_update': (I, [P, P, P, P, I, F, P]),
     'rv_bn_running_update_table': (I, [P, I, F, P]),
     'rv_bn_lrelu_bwd': (I, [P, I, P, I, L, I, P, F, I, P, I, P, P, I, P, I, P]),

@@ -26,6 +26,14 @@ struct BnArgs {
     const float* dy; int dy_ld;
     float* out; int out_ld;
     const float* res; int res_ld;
+    // fused skip conv (round 6): res[p][c] := skip(x)[p][c], the 1x1 convolution of an encoder block (model/UNet_onset.py:191,198) evaluated HERE instead of
+    // being written by a conv launch and read back.  Bit-identical to that launch: v_mfma_f32_16x16x4_f32 is a chain of fused multiply-adds in k order
+    // starting from C (tools/probes/mfma_f32_order.hip), so a vector-ALU fmaf chain in the conv kernel's k order reproduces it.
+    //   sk_cin == 1 : rank-1 term fma(x[p], w[c], b[c])                      (block 1: conv_small_k<1, C, 1, 1, 1, 0>)
+    //   sk_cin in {16, 32, 64}: dense, weights [C][sk_cin] staged transposed in LDS, chain order of conv_mfma_k<1, 1, 1, 0, 4, ...>: per 16-channel chunk
+    //                 r = 0..3, g = 0..3 -> channel 16 chunk + 4 g + r; sk_ks != 0: the K-split form (family 0x5NM: four partial chains over the chunk
+    //                 ranges of the four waves, added in wave order); then + bias
+    const float* r1_x; int r1_x_ld; const float* r1_w; const float* r1_b; int sk_cin, sk_ks;
     long P; int C;
     double* sums;            // [2C] fp64 accumulators
     const float* coef;       // [4C]: mean, invstd, scale, shift
@@ -129,8 +137,10 @@ __device__ __forceinline__ void bn_coef(const BnArgs& a, const double* fold, int
 // elementwise, 4 channels per thread (C % 4 == 0).  The grid is a multiple of 3 workgroups, so the
 // grid stride is a multiple of every C/4 in the model and a thread keeps ONE channel quad: its
 // coefficients live in registers for the whole kernel.
-template <bool BWD>
+template <bool BWD, int SKIP = 0>
 __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
+    static_assert(!BWD || SKIP == 0, "the fused skip conv exists in the forward kernel only");
+    extern __shared__ __attribute__((aligned(16))) float skw[];        // SKIP: [SKIP][C] transposed skip weights
     const int C = a.C, C4 = C >> 2;
     const long total = a.P * C4;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -167,6 +177,53 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
         }
     };
     fetch(c);
+    f32x4 r1w = (f32x4){0.f, 0.f, 0.f, 0.f}, r1b = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto fetch_r1 = [&](int cc) {
+        if (!BWD && a.r1_x) {
+            if (SKIP == 0) r1w = *reinterpret_cast<const f32x4*>(a.r1_w + cc);
+            if (a.r1_b) r1b = *reinterpret_cast<const f32x4*>(a.r1_b + cc);
+        }
+    };
+    fetch_r1(c);
+    if constexpr (SKIP > 0) {
+        // weights [C][SKIP] (PyTorch layout) -> LDS [SKIP][C]: a thread's four channels of one k are one 16-byte read, the same for every thread of a channel quad
+        for (int i = threadIdx.x; i < SKIP * C; i += blockDim.x) {
+            const int cc = i / SKIP, kk = i - cc * SKIP;
+            skw[kk * C + cc] = a.r1_w[i];
+        }
+        __syncthreads();
+    }
+    // skip(x)[p][c .. c+3] of the dense form (see BnArgs)
+    auto skip_dense = [&](const long p, const int cc0) -> f32x4 {
+        constexpr int NCH = SKIP > 0 ? SKIP / 16 : 1;
+        const float* xp = a.r1_x + p * a.r1_x_ld;
+        auto chunk = [&](f32x4& acc, const int ch) {
+            f32x4 xg[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xg[g] = *reinterpret_cast<const f32x4*>(xp + 16 * ch + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(&skw[(16 * ch + 4 * g + r) * C + cc0]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = fmaf(w4[q], xg[g][r], acc[q]);
+                }
+        };
+        f32x4 tot = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!a.sk_ks) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) chunk(tot, ch);
+        } else {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                f32x4 part = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int ch = (w * NCH) / 4; ch < ((w + 1) * NCH) / 4; ++ch) chunk(part, ch);
+                if (w == 0) tot = part; else tot += part;
+            }
+        }
+        return tot + r1b;                        // (r1b = the bias quad of this thread's channels, 0 without a bias)
+    };
     auto one = [&](const f32x4& z, const f32x4& d, const f32x4& r) -> f32x4 {
         f32x4 o;
         if (!BWD) {
@@ -190,7 +247,7 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
     if (fixed) {
         // the thread keeps its channel quad: pixels p0, p0 + pstep, ... ; four pixels per trip, every load of the trip
         // issued before the first use, no division in the loop
-        constexpr int UNR = BWD ? 4 : 8;          // pixels in flight per thread
+        constexpr int UNR = BWD || SKIP > 0 ? 4 : 8;          // pixels in flight per thread
         const long pstep = stride / C4;
         long p = idx / C4;
         for (; p < a.P; p += UNR * pstep) {
@@ -206,6 +263,15 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
                 else dv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 rv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (!BWD && a.res) rv[u] = *reinterpret_cast<const f32x4*>(a.res + pp * a.res_ld + c);
+                if (!BWD && SKIP == 0 && a.r1_x) {
+                    const float x1 = a.r1_x[pp * a.r1_x_ld];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rv[u][q] = fmaf(x1, r1w[q], r1b[q]);       // bit-identical to conv_small_k<1, C, 1, 1, 1, 0>
+                }
+            }
+            if constexpr (SKIP > 0) {
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) rv[u] = skip_dense(ok[u] ? p + u * pstep : 0, c);
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
@@ -223,12 +289,18 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnArgs a) {
     }
     for (; idx < total; idx += stride) {
         const long p = idx / C4;
-        if (!fixed) { c = (int)(idx - p * C4) * 4; fetch(c); }
+        if (!fixed) { c = (int)(idx - p * C4) * 4; fetch(c); fetch_r1(c); }
         const f32x4 z = *reinterpret_cast<const f32x4*>(a.z + p * a.z_ld + c);
         f32x4 o;
         if (!BWD) {
             f32x4 r = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (a.res) r = *reinterpret_cast<const f32x4*>(a.res + p * a.res_ld + c);
+            if (SKIP == 0 && a.r1_x) {
+                const float x1 = a.r1_x[p * a.r1_x_ld];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r[q] = fmaf(x1, r1w[q], r1b[q]);
+            }
+            if constexpr (SKIP > 0) r = skip_dense(p, c);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float zh = fmaf(z[q], scale[q], shift[q]);
@@ -368,6 +440,38 @@ int rv_bn_lrelu_fwd(const float* z, int z_ld, long P, int C, const float* gamma,
     a.out = y; a.out_ld = y_ld; a.res = res; a.res_ld = res_ld;
     hipLaunchKernelGGL(bn_apply_k<false>, dim3(bn_apply_blocks(P * (C / 4))), dim3(256), 0, st, a);
     RV_LAUNCH_CHECK("rv_bn_lrelu_fwd(apply)");
+    return RV_OK;
+}
+
+// The same with the residual evaluated in place: y = leaky_relu(bn(z), slope) + skip(x), skip = the 1x1 convolution of an encoder block
+// (model/UNet_onset.py:191,198: `x12 += self.skip(x)`), x [P][cin] at pixel stride x_ld, w [C][cin] (the PyTorch weight), b [C] nullable.  cin = 1 (block 1, the
+// single-channel spectrogram: one fma per element) or 16 / 32 / 64 (blocks 2-4: an fmaf chain per element in the k order of the MFMA conv kernel; ksplit != 0
+// reproduces the K-split form of that kernel, algo family 0x5NM).  Results are BIT-IDENTICAL to rv_conv_fwd(mode 1) + rv_bn_lrelu_fwd(res = its output).
+int rv_bn_lrelu_fwd_skip(const float* z, int z_ld, long P, int C, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, long* num_batches_tracked, float momentum, float eps, int training, float slope,
+                         const float* x, int x_ld, int cin, const float* w, const float* b, int ksplit, float* y, int y_ld, float* coef,
+                         void* workspace, int sums_ready, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    RV_CHECK_ARG(C % 4 == 0 && C <= 128, "rv_bn_lrelu_fwd_skip: C=%d must be a multiple of 4 and <= 128", C);
+    RV_CHECK_ARG(cin == 1 || cin == 16 || cin == 32 || cin == 64, "rv_bn_lrelu_fwd_skip: cin=%d (1, 16, 32 or 64)", cin);
+    RV_CHECK_ARG((z_ld % 4) == 0 && (y_ld % 4) == 0 && x && w && x_ld >= cin && (cin == 1 || ((x_ld % 4) == 0 && (((uintptr_t)x) & 15) == 0)),
+                 "rv_bn_lrelu_fwd_skip: bad strides / alignment / null skip operands");
+    BnArgs a = {};
+    a.z = z; a.z_ld = z_ld; a.P = P; a.C = C; a.sums = (double*)workspace; a.slope = slope;
+    a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var; a.nbt = num_batches_tracked;
+    a.coef_out = coef; a.momentum = momentum; a.eps = eps; a.training = training;
+    if (training && !sums_ready) {
+        const int rc = rv_internal_bn_stats(z, z_ld, P, C, a.sums, st);
+        if (rc != RV_OK) return rc;
+    }
+    a.out = y; a.out_ld = y_ld; a.r1_x = x; a.r1_x_ld = x_ld; a.r1_w = w; a.r1_b = b; a.sk_cin = cin; a.sk_ks = ksplit;
+    const dim3 grid(bn_apply_blocks(P * (C / 4)));
+    const size_t lds = (size_t)cin * C * sizeof(float);
+    if (cin == 1) hipLaunchKernelGGL((bn_apply_k<false, 0>), grid, dim3(256), 0, st, a);
+    else if (cin == 16) hipLaunchKernelGGL((bn_apply_k<false, 16>), grid, dim3(256), lds, st, a);
+    else if (cin == 32) hipLaunchKernelGGL((bn_apply_k<false, 32>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((bn_apply_k<false, 64>), grid, dim3(256), lds, st, a);
+    RV_LAUNCH_CHECK("rv_bn_lrelu_fwd_skip(apply)");
     return RV_OK;
 }
 

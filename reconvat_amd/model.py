@@ -13,6 +13,8 @@ PARAMETER CONTAINERS ONLY (they give the reference's parameter names, shapes and
 their ``forward`` is never called -- every numeric step runs through ``reconvat_amd.ops`` (hand-written
 HIP kernels).  Activations are NHWC internally; public tensors keep the reference's shapes.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.init as init
@@ -34,13 +36,24 @@ def _conv(m, x, kind, detach, size=None, share=None):
     return ConvFn.apply(x, _p(m.weight, detach), _p(m.bias, detach), kind, size, None, None, share)
 
 
-def _conv_bn(conv, bn, x, kind, res, detach, bn_in=None, link=None, share=None, dx_colsum=None):
+# encoder blocks: `x12 += skip(x)` with the 1x1 skip conv evaluated inside the BatchNorm apply kernel (ops.BnActFn r1_*, rv_bn_lrelu_fwd_skip) instead of a conv
+# launch writing it and the apply kernel reading it back; results are bit-identical either way.  RV_FUSE_SKIP = 0: never; 1 (default): the first block only (one
+# input channel: a rank-1 term -- 20.36 vs 20.58 ms/step); 2: every block whose separate launch's arithmetic is known (ops.skip_conv_ksplit) -- correct and SLOWER
+# (20.81 ms: the 16 .. 64-term fmaf chains and their LDS weight reads cost the apply kernel more than the conv launch did; profiles/r06_fused_skip_ab.txt)
+FUSE_SKIP = [int(os.environ.get('RV_FUSE_SKIP', '1'))]
+
+
+def _conv_bn(conv, bn, x, kind, res, detach, bn_in=None, link=None, share=None, dx_colsum=None, r1=None):
     """lrelu(bn(conv(x))) (+ res).  In training mode the conv leaves the batch statistics of its output in a
     zeroed fp64 slice (fused epilogue) and the BatchNorm skips its own statistics pass.  ``link`` (a fresh
     ops.BnLink) is handed to the ONE conv that consumes the result as ``bn_in``: that conv's input-gradient kernel
     then also produces this BatchNorm's backward reduction."""
     stats = ARENA.take(ops.bn_ws_doubles(bn.num_features), x.device) if bn.training else None
     z = ConvFn.apply(x, _p(conv.weight, detach), _p(conv.bias, detach), kind, None, stats, bn_in, share, dx_colsum)
+    if r1 is not None:                 # (x1, skip conv, GradShare of x1): the residual is skip(x1), evaluated inside the apply kernel
+        x1, sk, sh1 = r1
+        return BnActFn.apply(z, _p(bn.weight, detach), _p(bn.bias, detach), bn.running_mean, bn.running_var,
+                             bn.num_batches_tracked, None, bn.training, SLOPE, stats, link, x1, _p(sk.weight, detach), _p(sk.bias, detach), sh1)
     return BnActFn.apply(z, _p(bn.weight, detach), _p(bn.bias, detach), bn.running_mean, bn.running_var,
                          bn.num_batches_tracked, res, bn.training, SLOPE, stats, link)
 
@@ -62,8 +75,12 @@ class block(nn.Module):
         share = share if share is not None else GradShare()
         l1 = BnLink()                                                          # a1 feeds conv2 only
         a1 = _conv_bn(self.conv1, self.bn1, x, 'c3', None, detach, link=l1, share=share)
-        sk = _conv(self.skip, x, 'c1', detach, share=share)
-        a2 = _conv_bn(self.conv2, self.bn2, a1, 'c3', sk, detach, bn_in=l1)     # lrelu(bn2(.)) + skip(x)
+        cin = self.skip.in_channels
+        if (FUSE_SKIP[0] >= 1 and cin == 1) or (FUSE_SKIP[0] >= 2 and ops.skip_conv_ksplit(x, self.skip.out_channels) is not None):
+            a2 = _conv_bn(self.conv2, self.bn2, a1, 'c3', None, detach, bn_in=l1, r1=(x, self.skip, share))      # lrelu(bn2(.)) + skip(x), skip evaluated in the apply kernel
+        else:
+            sk = _conv(self.skip, x, 'c1', detach, share=share)
+            a2 = _conv_bn(self.conv2, self.bn2, a1, 'c3', sk, detach, bn_in=l1)     # lrelu(bn2(.)) + skip(x)
         xp = _conv(self.ds, a2, 'down', detach)
         return xp, (a2.shape[1], a2.shape[2])
 

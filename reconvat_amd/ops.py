@@ -1166,12 +1166,38 @@ class UpCatFn(Function):
 # --------------------------------------------------------------------------------------------
 # BatchNorm (train / eval) + leaky ReLU (+ residual)
 # --------------------------------------------------------------------------------------------
+def skip_conv_ksplit(x, cout):
+    """Which arithmetic the SEPARATE launch of the 1x1 skip conv x -> cout channels would use (the fused form inside the BatchNorm apply kernel must reproduce it bit
+    for bit): False = one fmaf chain over the input channels (conv_small_k for one input channel; conv_mfma_k's plain tiles), True = the K-split tile family 0x5NM
+    (four partial chains added in wave order), None = unknown -- on-line tuning, a forced algo, a table entry borrowed from another batch size, or an input that the
+    fused kernel does not take -- in which case the caller keeps the separate launch."""
+    bb, h, wd, cin, ild = _geom(x)
+    if cin == 1:
+        return False
+    if cin not in (16, 32, 64) or ild % 4 or x.data_ptr() % 16 or os.environ.get('RV_FORCE_ALGO_ALL'):
+        return None
+    if AUTOTUNE is False:
+        return False                         # library default tile: choose_tiles, never the K-split family
+    if AUTOTUNE != 'table':
+        return None
+    hit = plans.lookup_conv((1, bb, h, wd, cin, cout, ild, cout, False, False))
+    if hit is None:
+        return False                         # not in the table: library default tile
+    if not hit[1]:
+        return None                          # borrowed from another batch size: its legality is only known after the first launch
+    return ((hit[0] >> 8) & 15) == 5
+
+
 class BnActFn(Function):
     """y = leaky_relu(batch_norm(z)) (+ res).  Training mode updates running_mean / running_var /
     num_batches_tracked in place exactly like nn.BatchNorm2d(momentum=0.1)."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, running_mean, running_var, nbt, res, training, slope, stats=None, link=None):
+    def forward(ctx, z, gamma, beta, running_mean, running_var, nbt, res, training, slope, stats=None, link=None,
+                r1_x=None, r1_w=None, r1_b=None, r1_share=None):
+        """r1_x / r1_w / r1_b (round 6): the residual as a RANK-1 term -- skip(x) of the first encoder block, a 1 -> C 1x1 conv of the single-channel
+        input (model/UNet_onset.py:191,198) -- evaluated inside the apply kernel (rv_bn_lrelu_fwd_r1) instead of a conv launch writing it and this kernel
+        reading it back; the backward launches that conv's input / weight gradients from dy exactly as ConvFn.backward would (r1_share: the GradShare of x)."""
         need_gpu(z, gamma)
         bb, h, wd, c, zld = _geom(z)
         p = bb * h * wd
@@ -1187,23 +1213,68 @@ class BnActFn(Function):
         ws = (stats if ready else ARENA.take(bn_ws_doubles(c), z.device),
               ARENA.take(bn_ws_doubles(c), z.device) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None)
         rld = _geom(res)[4] if res is not None else 0
-        call('rv_bn_lrelu_fwd', ptr(z), zld, p, c, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(nbt),
-             BN_MOMENTUM, BN_EPS, mode, slope, ptr(res), rld, ptr(y), c, ptr(coef), ptr(ws[0]), 1 if ready else 0, stream())
+        ctx.r1 = r1_x is not None
+        if ctx.r1:
+            cin1 = r1_x.shape[-1]
+            assert res is None and tuple(r1_x.shape[:3]) == (bb, h, wd) and r1_w.shape[0] == c and r1_w.numel() == c * cin1 and r1_w.is_contiguous()
+            need_gpu(r1_x, r1_w)
+            ks = skip_conv_ksplit(r1_x, c)
+            assert ks is not None, 'fused skip conv: the tile of the separate launch is not known (ops.fusable_skip decides)'
+            call('rv_bn_lrelu_fwd_skip', ptr(z), zld, p, c, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(nbt),
+                 BN_MOMENTUM, BN_EPS, mode, slope, ptr(r1_x), _geom(r1_x)[4], cin1, ptr(r1_w), ptr(r1_b), 1 if ks else 0, ptr(y), c, ptr(coef), ptr(ws[0]),
+                 1 if ready else 0, stream())
+            ctx.r1_share, ctx.r1_xshape, ctx.r1_params = r1_share, tuple(r1_x.shape), (r1_w, r1_b)
+            ctx.r1_live = bool(ctx.needs_input_grad[12])
+        else:
+            call('rv_bn_lrelu_fwd', ptr(z), zld, p, c, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(nbt),
+                 BN_MOMENTUM, BN_EPS, mode, slope, ptr(res), rld, ptr(y), c, ptr(coef), ptr(ws[0]), 1 if ready else 0, stream())
         ctx.ws = ws
         ctx.link = None
-        if link is not None and training and ws[1] is not None and res is None:
+        if link is not None and training and ws[1] is not None and res is None and not ctx.r1:
             link.z, link.coef, link.ws, link.slope, link.ready = z, coef, ws[1], slope, False
             ctx.link = link
         ctx.training = training
         ctx.slope = slope
         ctx.params = (gamma, beta)
-        ctx.save_for_backward(z, coef)
+        if ctx.r1:
+            ctx.save_for_backward(z, coef, r1_x if ctx.needs_input_grad[12] else None, r1_w)
+        else:
+            ctx.save_for_backward(z, coef)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        z, coef = ctx.saved_tensors
+        if ctx.r1:
+            z, coef, r1_x, r1_w = ctx.saved_tensors
+        else:
+            z, coef = ctx.saved_tensors
         dy = dy.contiguous()
+        dx1 = dw1 = db1 = None
+        if ctx.r1:
+            # the skip conv's own backward (ConvFn.backward of a 'c1' conv with input x, output gradient dy), launched here: it used to be
+            # the first node behind this one on the residual path, so the order of the adds into x's shared gradient is unchanged
+            def r1_input_grad():
+                nonlocal dx1
+                if not ctx.needs_input_grad[11]:
+                    return
+                if ctx.r1_share is not None:
+                    dx1 = ctx.r1_share.dgrad('c1', dy, r1_w, ctx.r1_xshape)
+                else:
+                    dx1 = torch.empty(ctx.r1_xshape, device=dy.device, dtype=torch.float32)
+                    conv_dgrad_into('c1', dy, r1_w, dx1)
+
+            def r1_weight_grad():
+                nonlocal dw1, db1
+                if not ctx.needs_input_grad[12]:
+                    return
+                pw1, pb1 = ctx.r1_params
+                gw1, gb1 = _grad_buf(pw1), _grad_buf(pb1)
+                if gw1 is not None and (gb1 is not None or not ctx.needs_input_grad[13]):
+                    conv_wgrad('c1', r1_x, dy, r1_w, ctx.needs_input_grad[13], gw1, gb1)
+                else:
+                    dw1, db1 = conv_wgrad('c1', r1_x, dy, r1_w, ctx.needs_input_grad[13])
+            for part in ((r1_weight_grad, r1_input_grad) if WGRAD_FIRST[0] else (r1_input_grad, r1_weight_grad)):
+                part()
         bb, h, wd, c, zld = _geom(z)
         p = bb * h * wd
         need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
@@ -1225,7 +1296,7 @@ class BnActFn(Function):
         if direct:
             dg = db = None
         dres = dy if ctx.needs_input_grad[6] else None
-        return (dz if ctx.needs_input_grad[0] else None), dg, db, None, None, None, dres, None, None, None, None
+        return (dz if ctx.needs_input_grad[0] else None), dg, db, None, None, None, dres, None, None, None, None, dx1, dw1, db1, None
 
 
 # --------------------------------------------------------------------------------------------

@@ -229,6 +229,13 @@ def test_rccl_allreduce_executes_on_one_gpu(dev):
         assert p.stdout.strip().splitlines()[-1] == lines[0], 'the JSON line must be the LAST line of stdout: ' + p.stdout[-1500:]
         outs.append(json.loads(lines[0]))
     plain, rccl = outs
+    # the line's own contract: `ms_per_step` = the median of the per-step device times, `value` = whole-job throughput over the
+    # barrier-to-barrier wall clock (`mean_ms_per_step`), and the library's source digest equals the digest of the sources next to it
+    for ln in outs:
+        assert ln['min_ms_per_step'] <= ln['ms_per_step'] <= ln['max_ms_per_step'] and ln['steps'] == 3 and ln['warmup'] == 1 and ln['n_gpus'] == 1
+        assert abs(ln['value'] - 16 * 20.48 / (ln['mean_ms_per_step'] * 1e-3)) <= 1e-3 * ln['value']
+        assert ln['higher_is_better'] is True and ln['scaling'] == 'weak' and ln['dtype'] == 'f32' and ln['vs_baseline'] is None and ln['data'] == 'synthetic'
+        assert ln['config']['source_digest'] == ln['config']['source_digest_of_tree'] and len(ln['config']['source_digest']) == 16
     assert plain['dp_allreduce_calls'] == 0 and rccl['dp_allreduce_calls'] == 4 and rccl['dp_ranks'] == 1 and rccl['dp_backend'] == 'nccl'
     assert rccl['replicas_equal'] is True
     assert abs(rccl['config']['final_loss'] - plain['config']['final_loss']) <= 2e-3 * abs(plain['config']['final_loss'])

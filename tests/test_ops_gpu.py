@@ -935,3 +935,48 @@ def test_wgrad_merger_learns_then_merges(dev):
     assert results[3][2] == ['rv_conv_wgrad_seg', 'rv_conv_wgrad']                    # (learned 2 in the short step: the third pass arrives alone)
     assert rel_err(results[1][0], results[0][0]) < 1e-5 and rel_err(results[1][1], results[0][1]) < 1e-5
     assert rel_err(results[3][0], results[0][0]) < 1e-5
+
+
+@pytest.mark.parametrize('training', [True, False])
+@pytest.mark.parametrize('B,H,W,cin,C', [(2, 24, 57, 1, 16), (3, 12, 57, 16, 32), (2, 9, 28, 32, 64), (2, 10, 14, 64, 128),
+                                         # the shipped shapes (B = 8: the plan table decides the separate launch's tile, incl. the K-split family)
+                                         (8, 640, 229, 1, 16), (8, 320, 114, 16, 32), (8, 160, 57, 32, 64), (8, 80, 28, 64, 128)])
+def test_bn_apply_with_fused_skip_equals_the_separate_skip_conv(dev, training, B, H, W, cin, C):
+    """Round 6: an encoder block's `x12 += skip(x)` (model/UNet_onset.py:191,198; skip = 1x1 conv) evaluated INSIDE the BatchNorm apply kernel
+    (rv_bn_lrelu_fwd_skip: a rank-1 fma for the single-channel block, an fmaf chain in the MFMA kernel's k order for 16 / 32 / 64 input channels -- plain or K-split
+    form, whichever the separate launch would run) must be BIT-IDENTICAL to the conv launch + residual read it replaces: output, running statistics and every
+    gradient (z, gamma, beta, x, skip weight, skip bias; the skip conv's own backward is launched from the fused node)."""
+    from reconvat_amd import ops
+    z0, x0 = rnd(B, H, W, C, seed=1), rnd(B, H, W, cin, seed=2)
+    gam0, bet0 = rnd(C, seed=3) * 0.2 + 1.0, rnd(C, seed=4) * 0.1
+    w0, b0 = rnd(C, cin, 1, 1, seed=5) * (1.0 / cin ** 0.5), rnd(C, seed=6)
+    cot = rnd(B, H, W, C, seed=7).to(dev)
+    assert ops.skip_conv_ksplit(x0.to(dev), C) is not None
+    outs = []
+    for fused in (False, True):
+        z, x = z0.to(dev).requires_grad_(True), x0.to(dev).requires_grad_(True)
+        gam, bet, w, b = (t.to(dev).clone().requires_grad_(True) for t in (gam0, bet0, w0, b0))
+        rm, rv, nbt = torch.zeros(C, device=dev), torch.ones(C, device=dev), torch.zeros((), device=dev, dtype=torch.long)
+        if fused:
+            y = ops.BnActFn.apply(z, gam, bet, rm, rv, nbt, None, training, ops.SLOPE, None, None, x, w, b, None)
+        else:
+            sk = ops.ConvFn.apply(x, w, b, 'c1', None)
+            y = ops.BnActFn.apply(z, gam, bet, rm, rv, nbt, sk, training, ops.SLOPE, None, None)
+        (y * cot).sum().backward()
+        torch.cuda.synchronize()
+        outs.append([y.detach(), rm, rv, nbt, z.grad, gam.grad, bet.grad, x.grad, w.grad, b.grad])
+    names = ['y', 'running_mean', 'running_var', 'num_batches_tracked', 'dz', 'dgamma', 'dbeta', 'dx', 'dw_skip', 'db_skip']
+    for n, a, bb in zip(names, *outs):
+        assert torch.equal(a, bb), (n, float((a.double() - bb.double()).abs().max()))
+    if B * H * W > 100000:
+        return
+    # ... and against torch (the unfused path is covered elsewhere; this pins the fused one on its own)
+    zt, xt = z0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(C, momentum=0.1)
+    bn.train(training)
+    with torch.no_grad():
+        bn.weight.copy_(gam0); bn.bias.copy_(bet0)
+    yt = F.leaky_relu(bn(zt.permute(0, 3, 1, 2))) + F.conv2d(xt.permute(0, 3, 1, 2), w0, b0)          # NCHW views of the NHWC leaves
+    (yt * cot.cpu().permute(0, 3, 1, 2)).sum().backward()
+    assert rel_err(outs[1][0], yt.permute(0, 2, 3, 1)) < 1e-5
+    assert rel_err(outs[1][4], zt.grad) < 1e-4 and rel_err(outs[1][7], xt.grad) < 1e-4
