@@ -53,7 +53,10 @@ def pin_rank_cpus(local_rank=None, local_world=None):
     if n <= 1 or k < 1:
         return cpus
     mine = cpus[r * k:(r + 1) * k]
-    os.sched_setaffinity(0, mine)
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:                 # (a sandbox that does not allow it: the ranks simply share the launcher's CPU set)
+        return cpus
     return mine
 
 

@@ -362,3 +362,25 @@ def test_wgrad_merger_bookkeeping(monkeypatch):
     assert launched == [('c', 4)]
     m.finish()
     assert launched == [('c', 4), ('c', 2)]
+
+
+def test_rank_cpu_affinity_slices():
+    """dp.pin_rank_cpus (round 6): rank r of n pins itself to the r-th of n equal slices of the launcher's CPU set -- checked in child processes (affinity is
+    process state); a rank count larger than the CPU set leaves the set alone."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from reconvat_amd import dp\n"
+        "have = sorted(os.sched_getaffinity(0))\n"
+        "r, n = int(sys.argv[1]), int(sys.argv[2])\n"
+        "mine = dp.pin_rank_cpus(r, n)\n"
+        "k = len(have) // n\n"
+        "want = have[r * k:(r + 1) * k] if (n > 1 and k >= 1) else have\n"
+        "assert mine == want == sorted(os.sched_getaffinity(0)), (mine, want)\n"
+        "print(len(mine))\n")
+    ncpu = len(os.sched_getaffinity(0))
+    for r, n in ((0, 2), (1, 2), (0, 1), (0, 4 * ncpu)):
+        p = subprocess.run([sys.executable, '-c', code, str(r), str(n)], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr[-1500:]
