@@ -832,6 +832,10 @@ def main():
         'param_checksum': int(checksum.item()),
         # gradient all-reduces issued by FlatAdam.step (RCCL, or gloo through pinned host memory): one per optimiser step
         'dp_allreduce_calls': int(getattr(opt, 'allreduce_calls', 0)), 'optimizer_steps': int(opt.step_count.item()),
+        # HBM footprint of this rank up to the end of the timed loop (caching allocator; the captured graph's private pool included):
+        # weights + optimiser state 58 MB, the rest activations of the 8 + 1 passes, workspaces and the parked (x, dY) pairs of the merged weight gradients
+        'device_memory_gb': {'max_allocated': round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
+                             'max_reserved': round(torch.cuda.max_memory_reserved(device) / 2 ** 30, 2)},
     }
     if rank == 0 and world == 1 and args.model == 'onset' and batch_l == args.batch == 8:       # (the roofline / parity legs are written for the headline workload)
         if not args.no_roofline:

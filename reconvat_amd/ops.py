@@ -836,7 +836,10 @@ class WgradMerger:
       path) and re-learns the counts.
     * WHERE it launches decides whether it pays (profiles/r05_wgrad_merge_ab.txt): on the side stream, which is idle while the main chain
       runs the main forward's backward -- merged on the main chain the same launches LOSE 0.14 ms/step, next door they win 0.5.  The
-      launching stream first waits for every other stream a segment was produced on."""
+      launching stream first waits for every other stream a segment was produced on.
+    * Memory: the parked (x, dY) pairs of up to three passes stay alive until the last pass of a layer arrives: +0.8 GB of peak device memory at
+      B = 8 + 8 (bench.py `device_memory_gb.max_allocated`: 6.28 GB merged, 5.48 GB per pass; 7.9 GB reserved either way) -- 0.3 % of the 288 GB of
+      an MI355X, so there is no budget gate; an exception inside the step drops the parked references (`abort`)."""
 
     def __init__(self):
         self.learned = {}          # (mode, key) -> launches per step
