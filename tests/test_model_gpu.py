@@ -699,3 +699,36 @@ def test_six_step_trajectory_vs_reference(dev, tag, deterministic, monkeypatch):
     nograd = set(str(k) for k in tc.gold()[tag + '_nograd'])
     for n in nograd:
         assert float(mm[n].abs().max()) == 0.0 and float(vv[n].abs().max()) == 0.0, n
+
+
+@pytest.mark.parametrize('kind', ['onset', 'frame'])
+def test_fused_skip_conv_leaves_the_whole_step_bit_identical(dev, kind, monkeypatch):
+    """Round 6: `x12 += skip(x)` evaluated inside the BatchNorm apply kernel (model.FUSE_SKIP = 1: block 1's rank-1 form, the shipped setting; 2: the dense form
+    for blocks 2-4 as well) against the separate skip conv launches (0), on a WHOLE VAT + reconstruction step: every loss term -- the chaotic VAT terms included --,
+    every parameter gradient and every running statistic bit for bit.  (Deterministic reduction mode, so that the gradients are comparable bit for bit at all; the
+    fused node launches the skip conv's backward at the position in the stream where its own autograd node used to run, so the adds into the shared input gradient
+    keep their order.)"""
+    from oracle import fixture as fx
+    from reconvat_amd import model as rmodel, ops
+    monkeypatch.setattr(ops, 'DETERMINISTIC', [True])
+    bl, bul = _batches(dev)
+    n_ul, n_l = fx.fixture_noise((2, 1, 64, 229), 'd0_ul').to(dev), fx.fixture_noise((2, 1, 64, 229), 'd0_l').to(dev)
+    res = []
+    for mode in (0, 1, 2):
+        monkeypatch.setattr(rmodel, 'FUSE_SKIP', [mode])
+        m = build(kind, True, dev)
+        seq = [n_ul, n_l]
+        m.vat_loss.noise = lambda t, seq=seq: seq.pop(0).clone()
+        _, losses, _ = m.run_on_batch(bl, bul, True)
+        sum(losses.values()).backward()
+        torch.cuda.synchronize()
+        res.append(({k: float(v.detach()) for k, v in losses.items()}, {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None},
+                    {k: v.clone() for k, v in m.state_dict().items() if 'running' in k or 'num_batches' in k}))
+    for (l1, g1, s1), name in zip(res[1:], ('block 1 fused', 'all blocks fused')):
+        l0, g0, s0 = res[0]
+        assert l0 == l1, (name, {k: (l0[k], l1[k]) for k in l0 if l0[k] != l1[k]})
+        assert set(g0) == set(g1)
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), (name, k, float((g0[k].double() - g1[k].double()).abs().max()))
+        for k in s0:
+            assert torch.equal(s0[k], s1[k]), (name, k)
