@@ -1199,7 +1199,7 @@ class BnActFn(Function):
     def forward(ctx, z, gamma, beta, running_mean, running_var, nbt, res, training, slope, stats=None, link=None,
                 r1_x=None, r1_w=None, r1_b=None, r1_share=None):
         """r1_x / r1_w / r1_b (round 6): the residual as a RANK-1 term -- skip(x) of the first encoder block, a 1 -> C 1x1 conv of the single-channel
-        input (model/UNet_onset.py:191,198) -- evaluated inside the apply kernel (rv_bn_lrelu_fwd_r1) instead of a conv launch writing it and this kernel
+        input (model/UNet_onset.py:191,198) -- evaluated inside the apply kernel (rv_bn_lrelu_fwd_skip; 16 / 32 / 64-channel inputs: the dense form, opt-in) instead of a conv launch writing it and this kernel
         reading it back; the backward launches that conv's input / weight gradients from dy exactly as ConvFn.backward would (r1_share: the GradShare of x)."""
         need_gpu(z, gamma)
         bb, h, wd, c, zld = _geom(z)
